@@ -1,0 +1,70 @@
+"""ctypes binding of libsfmi.so — the C-ABI drop-in boundary (include/sfmi.h).
+
+The product path has NO fallback: if the library is missing or a symbol is
+absent, import-time / call-time errors are raised loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsfmi.so")
+
+_lib = None
+
+c_f32p = C.c_void_p
+c_ptr = C.c_void_p
+i32, i64, sz = C.c_int, C.c_longlong, C.c_size_t
+
+# name -> (restype, argtypes)   -- mirrors include/sfmi.h
+PROTOTYPES = {
+    "sfmi_version": (i32, []),
+    # SDF query
+    "sfmi_sdf_pack_floats": (sz, []),
+    "sfmi_sdf_pack_weights": (i32, [c_ptr] * 11),
+    "sfmi_sdf_query_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, i64, i32, i32, c_ptr]),
+    "sfmi_sdf_query_grid_f32": (i32, [c_ptr, i32, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
+}
+
+
+class SfmiError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SfmiError(
+                f"{LIB_PATH} not found: the HIP extension is REQUIRED (no CPU/eager fallback). "
+                "Build it with `python -m shapeformer_amd.build`.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise SfmiError(f"libsfmi.so does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise SfmiError(f"{what} failed with code {rc}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / numpy array, or None."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,41 @@
+// Shared device helpers for libsfmi (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define SFMI_OK 0
+#define SFMI_EINVAL (-1)
+#define SFMI_ELAUNCH (-2)
+
+#define SFMI_CHECK_LAUNCH()                       \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+// reference constants: vqdif/common.py:260-276 (padding 0.1, "10e-4" == 1e-3)
+#define SFMI_NORM_DIV 1.101f
+#define SFMI_NORM_HI 0.999f
+
+// a2: normalize_3d_coordinate on one coordinate (p already in [-.5,.5])
+__device__ __forceinline__ float sfmi_normalize(float p) {
+  float u = __fdiv_rn(p, SFMI_NORM_DIV) + 0.5f;
+  u = (u >= 1.0f) ? SFMI_NORM_HI : u;
+  u = (u < 0.0f) ? 0.0f : u;
+  return u;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,62 @@
+"""Thin Python wrappers over the C ABI (one function per exported kernel launcher).
+
+Tensors are torch CUDA tensors used purely as device-memory handles; every call
+goes through libsfmi.so (shapeformer_amd/_lib.py).  No eager fallbacks.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _chk_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.SfmiError("libsfmi kernels need CUDA/HIP device tensors (no CPU fallback)")
+
+
+def _c(t, dtype):
+    assert t.dtype == dtype, (t.dtype, dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------- SDF query
+def sdf_pack_weights(sd, prefix="decoder.") -> np.ndarray:
+    """Pack LocalDecoder MLP tensors (reference key names) into the kernel's fragment order."""
+    g = lambda k: np.ascontiguousarray(np.asarray(sd[prefix + k], dtype=np.float32))
+    cat = lambda fmt: np.ascontiguousarray(np.stack([g(fmt.format(i)) for i in range(5)]))
+    out = np.empty(L.lib().sfmi_sdf_pack_floats(), np.float32)
+    arrs = [g("fc_p.weight"), g("fc_p.bias"), cat("fc_c.{}.weight"), cat("fc_c.{}.bias"),
+            cat("blocks.{}.fc_0.weight"), cat("blocks.{}.fc_0.bias"), cat("blocks.{}.fc_1.weight"),
+            cat("blocks.{}.fc_1.bias"), g("fc_out.weight"), g("fc_out.bias"), out]
+    L.check(L.lib().sfmi_sdf_pack_weights(*[a.ctypes.data for a in arrs]), "sfmi_sdf_pack_weights")
+    return out
+
+
+def sdf_query(xyz, grid_cl, wpack, sigmoid=False, out=None):
+    """xyz (B,N,3) in [-1,1]; grid_cl (B,G,G,G,32) channels-last; -> (B,N,1) logits."""
+    _chk_cuda(xyz, grid_cl, wpack)
+    xyz, grid_cl = _c(xyz, torch.float32), _c(grid_cl, torch.float32)
+    B, N, _ = xyz.shape
+    G = grid_cl.shape[1]
+    assert grid_cl.shape == (B, G, G, G, 32)
+    if out is None:
+        out = torch.empty(B, N, 1, device=xyz.device, dtype=torch.float32)
+    L.check(L.lib().sfmi_sdf_query_f32(L.ptr(xyz), L.ptr(grid_cl), L.ptr(wpack), L.ptr(out), B, N, G,
+                                       int(sigmoid), L.stream_ptr()), "sfmi_sdf_query_f32")
+    return out
+
+
+def sdf_query_grid(axis, grid_cl, wpack, sigmoid=False, out=None):
+    """Structured Q^3 'ij' query grid from a Q-entry f32 axis table -> (B,Q^3,1)."""
+    _chk_cuda(axis, grid_cl, wpack)
+    axis, grid_cl = _c(axis, torch.float32), _c(grid_cl, torch.float32)
+    Q = axis.numel()
+    B, G = grid_cl.shape[0], grid_cl.shape[1]
+    if out is None:
+        out = torch.empty(B, Q ** 3, 1, device=axis.device, dtype=torch.float32)
+    L.check(L.lib().sfmi_sdf_query_grid_f32(L.ptr(axis), Q, L.ptr(grid_cl), L.ptr(wpack), L.ptr(out), B, G,
+                                            int(sigmoid), L.stream_ptr()), "sfmi_sdf_query_grid_f32")
+    return out
