@@ -1,0 +1,93 @@
+"""CPU tests: the oracle restatement reproduces the committed golden vectors, which were produced by the
+imported reference itself (oracle/make_golden.py).  Runs anywhere (no GPU, no /root/reference)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import gpt_oracle as GO
+from oracle import tokens_oracle as TO
+from oracle import vqdif_oracle as VO
+from shapeformer_amd import weights as W
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_weight_hash_is_stable():
+    # the generator is the contract between this container, the oracle and the GPU box
+    a = W.make_tensor("encoder.fc_pos.weight", (64, 3))
+    assert a.dtype == np.float32 and a.shape == (64, 3)
+    np.testing.assert_allclose(a.reshape(-1)[:3], [0.06298041343688965, 0.27468132972717285, -0.7566272020339966], rtol=0, atol=1e-6)
+    assert len(W.vqdif_spec(16)) == 122 and sum(int(np.prod(s)) for s in W.vqdif_spec(16).values()) == 18003425
+    assert len(W.vqdif_spec(32)) == 110 and sum(int(np.prod(s)) for s in W.vqdif_spec(32).values()) == 4774049
+    assert len(W.gpt_spec(with_masks=True)) == 419
+    assert sum(int(np.prod(s)) for s in W.gpt_spec().values()) == 324953088
+
+
+def test_tokens_known_answers():
+    z = np.load(os.path.join(G, "tokens_known.npz"))
+    assert np.array_equal(TO.unpack_sparse(z["sp"]), z["unpacked"])
+    p, m = TO.dense2packed(z["testA"])
+    assert np.array_equal(p, z["packedA"]) and m == int(z["modeA"]) == 1
+    d = TO.batch_sparse2dense(p, m, 2, batch_size=2)
+    assert np.array_equal(d, z["testA"])
+    for a, r, (k, pp, t) in zip(z["filt_in"], z["filt_out"], z["filt_par"]):
+        assert np.array_equal(TO.filter_sampling_logits(a, int(k), float(pp), float(t)), r)
+    assert np.array_equal(TO.get_next_cond(z["c_pos"], z["z_pos"], 4096), z["next_cond"])
+    # SURVEY §4 literals
+    assert np.array_equal(TO.filter_sampling_logits([1.01, 1, 1.02], 3, .5, 1.), np.float32([1.01, -np.inf, 1.02]))
+    assert np.array_equal(TO.filter_sampling_logits([2, 1, 0, -1], 3, .7, 1.), np.float32([2, 1, -np.inf, -np.inf]))
+
+
+def test_vqdif16_oracle_vs_reference_vectors(vq16_sd_t):
+    z = np.load(os.path.join(G, "vqdif16_small.npz"))
+    X = torch.from_numpy(z["cloud"])
+    q, mode, enc = VO.quantize_cloud(vq16_sd_t, X)
+    assert int(mode) == int(z["mode"])
+    assert np.array_equal(q.numpy(), z["quant_ind"].astype(np.int64))
+    assert np.array_equal(enc["quant_ind"].numpy(), z["quant_ind_raw"].astype(np.int64))
+    assert np.array_equal(np.packbits(enc["grid_mask"].numpy()), z["grid_mask"])
+    tok, mode2 = TO.batch_dense2sparse(q.numpy(), 512, (4096, 4096))
+    assert np.array_equal(tok, z["tokens"]) and mode2 == int(z["mode2"])
+    assert np.array_equal(TO.batch_dense2sparse(q.numpy(), 40, (4096, 4096))[0], z["tokens_L40"])
+    assert np.array_equal(TO.pack_sparse(tok, (4096, 4096)), z["packed"])
+    Q = int(z["Q"])
+    Xtg = torch.from_numpy(VO.make_grid(Q))[None].expand(2, -1, -1)
+    lg = VO.decode_index(vq16_sd_t, q, Xtg)[..., 0].numpy()
+    np.testing.assert_allclose(lg, z["logits"], atol=1e-4, rtol=1e-5)
+
+
+def test_vqdif32_oracle_vs_reference_vectors():
+    sd = VO.to_torch_sd(W.make_state_dict(W.vqdif_spec(32)))
+    z = np.load(os.path.join(G, "vqdif32_small.npz"))
+    q, mode, enc = VO.quantize_cloud(sd, torch.from_numpy(z["cloud"]))
+    assert int(mode) == int(z["mode"]) and np.array_equal(q.numpy(), z["quant_ind"].astype(np.int64))
+    Q = int(z["Q"])
+    lg = VO.decode_index(sd, q, torch.from_numpy(VO.make_grid(Q))[None])[..., 0].numpy()
+    np.testing.assert_allclose(lg, z["logits"], atol=1e-4, rtol=1e-5)
+
+
+def test_gpt_tiny_oracle_vs_reference_vectors():
+    z = np.load(os.path.join(G, "gpt_tiny.npz"))
+    sd = VO.to_torch_sd(W.make_state_dict(W.gpt_spec(n_embd=64, n_layers=(2, 1), block_size=96)))
+    cfg = GO.GPTCfg(n_embd=64, n_head=4, n_layers=(2, 1), block_size=96)
+    c, zt, ex = (torch.from_numpy(z[k]) for k in ("c_idx", "z_idx", "extra"))
+    assert np.array_equal(TO.extra_indices_AR_N(z["c_idx"], z["z_idx"], 4096), z["extra"])
+    cz = torch.cat([c, zt], 1)
+    L_c = c.shape[1]
+    lg = GO.forward_logits(sd, cfg, cz[:, :-1], ex[:, :-1], L_c, cz[:, 1:])
+    np.testing.assert_allclose(lg[0][:, ::7, ::41].numpy(), z["logits0_sel"], atol=1e-4)
+    np.testing.assert_allclose(lg[1][:, ::7, ::41].numpy(), z["logits1_sel"], atol=1e-4)
+    assert abs(GO.training_loss(sd, cfg, c, zt, ex).item() - float(z["loss"])) < 1e-4
+    steps = int(z["steps"])
+    u = GO.uniforms(0, steps, 3)
+    c1 = c[:1].expand(3, -1, -1).contiguous()
+    out, hist, _ = GO.sample_indices(sd, cfg, c1, steps, u, use_cache=True, stop_early=False)
+    # greedy row == the REFERENCE's own sampled row 0 (shapeformer.py:54-123, best_in_first)
+    n = z["ref_sampled"].shape[1]
+    assert np.array_equal(out[0, :n], z["ref_sampled"][0])
+    a, b = hist[0][0, :n], z["ref_hist0_row0"]
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin) and np.abs(a[fin] - b[fin]).max() < 2e-4
+    assert np.array_equal(out, z["orc_sampled"])
+    np.testing.assert_allclose(GO.compute_log_probs(out, hist), z["orc_logprob"], atol=1e-4)
