@@ -25,6 +25,29 @@ PROTOTYPES = {
     "sfmi_sdf_pack_weights": (i32, [c_ptr] * 11),
     "sfmi_sdf_query_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, i64, i32, i32, c_ptr]),
     "sfmi_sdf_query_grid_f32": (i32, [c_ptr, i32, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
+    # encoder (per-point path)
+    "sfmi_enc_pack_floats": (sz, []),
+    "sfmi_enc_pack_weights": (i32, [c_ptr] * 10),
+    "sfmi_enc_workspace_bytes": (sz, [i32, i32]),
+    "sfmi_encode_points_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
+    # conv / groupnorm / pooling
+    "sfmi_conv_pack_weight": (i32, [c_ptr, i32, i32, i32, c_ptr]),
+    "sfmi_conv3d_cl_f32": (i32, [c_ptr] * 6 + [i32] * 11 + [c_ptr]),
+    "sfmi_gn_splits": (i32, [i32]),
+    "sfmi_groupnorm_coeffs_f32": (i32, [c_ptr] * 6 + [i32, i32, i32, i32, C.c_float, c_ptr]),
+    "sfmi_affine_cl_f32": (i32, [c_ptr] * 4 + [i32, i64, i32, c_ptr]),
+    "sfmi_maxpool2_cl_f32": (i32, [c_ptr, c_ptr, i32, i32, i32, i32, i32, c_ptr]),
+    "sfmi_upcat_cl_f32": (i32, [c_ptr, c_ptr, c_ptr, i32, i32, i32, i32, i32, i32, c_ptr]),
+    # vector quantiser
+    "sfmi_vq_pack_floats": (sz, [i32, i32]),
+    "sfmi_vq_pack_codebook": (i32, [c_ptr, i32, i32, c_ptr]),
+    "sfmi_vq_argmin_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr]),
+    "sfmi_vq_gather_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, c_ptr]),
+    # tokens
+    "sfmi_mode_i32": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr]),
+    "sfmi_apply_mask_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr]),
+    "sfmi_dense2sparse_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, i32, i32, i32, c_ptr]),
+    "sfmi_sparse2dense_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, i32, i32, c_ptr]),
 }
 
 

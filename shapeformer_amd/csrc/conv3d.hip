@@ -1,0 +1,341 @@
+// Channels-last 3-D convolution as an implicit GEMM on f32 MFMA (gfx950), plus the GroupNorm /
+// pooling / concat helpers around it.
+//
+// Replaces the cuDNN conv3d + ATen group_norm/relu/max_pool3d/interpolate/cat launches of
+// Downsampler (updown.py:101-118), UNet3D (unet3d.py:79-144,195-293,449-474) and Upsampler
+// (updown.py:119-132).  Layout is (B,D,H,W,C) so that a voxel's channels are one contiguous line —
+// the layout the SDF-query kernel gathers from.  Fusions done here instead of separate passes:
+//   * GroupNorm APPLY of the producer is folded into this conv's input load (x*scale[b,c]+shift[b,c],
+//     zero padding applied after the affine, as the reference pads the normalised tensor);
+//   * nearest x2 upsampling is an address shift (>>1) on the input coordinate, never materialised;
+//   * bias / ReLU in the epilogue.
+// GEMM view: D[co][voxel] = sum_{tap,cin} W[tap][co][cin] * X[voxel+tap][cin]; A = weights, B = activations,
+// 32x32x2 f32 MFMA (exact f32).  Workgroup = 4 waves, LDS double-buffered K-chunks of 16 input channels,
+// global->register prefetch of chunk c+1 overlapped with the MFMAs of chunk c, one barrier per chunk.
+#include "sfmi_common.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define KC 16
+#define LDS_STRIDE 20  // floats per row: 16 + 4 pad -> conflict-free ds_read_b128 over 16 consecutive rows
+
+struct ConvArgs {
+  const float* x; const float* wT; const float* in_scale; const float* in_shift; const float* bias; float* y;
+  int B, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, KS, stride, pad, up, relu;
+};
+
+template <int CO_TILES, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
+  constexpr int N_T = 32 * CO_TILES * WM;
+  constexpr int M_T = 64 * WN;
+  constexpr int W_ROWS = (N_T * 4 + 255) / 256;  // weight float4 rows per thread
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* act_lds = lds;                              // [2][M_T][LDS_STRIDE]
+  float* wgt_lds = lds + 2 * M_T * LDS_STRIDE;       // [2][N_T][LDS_STRIDE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, pl = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  const int srow = tid >> 2, seg = tid & 3;
+  const long long M = (long long)a.B * a.Do * a.Ho * a.Wo;
+  const long long m0 = (long long)blockIdx.x * M_T;
+  const int n0 = blockIdx.y * N_T;
+  const int Dv = a.Di << a.up, Hv = a.Hi << a.up, Wv = a.Wi << a.up;
+
+  // decode the output voxels this thread stages
+  int vb[WN], vz[WN], vy[WN], vx[WN];
+  bool vok[WN];
+#pragma unroll
+  for (int i = 0; i < WN; ++i) {
+    long long m = m0 + srow + 64 * i;
+    vok[i] = m < M;
+    if (!vok[i]) m = M - 1;
+    int xw = (int)(m % a.Wo); long long r = m / a.Wo;
+    int yh = (int)(r % a.Ho); r /= a.Ho;
+    int zd = (int)(r % a.Do);
+    vb[i] = (int)(r / a.Do); vz[i] = zd * a.stride - a.pad; vy[i] = yh * a.stride - a.pad; vx[i] = xw * a.stride - a.pad;
+  }
+  const int cpt = a.Cin / KC;                 // chunks per tap
+  const int nchunks = a.KS * a.KS * a.KS * cpt;
+
+  f32x4 ra[WN], rw[W_ROWS];
+  auto load_chunk = [&](int c) {
+    const int tap = c / cpt, c0 = (c - tap * cpt) * KC + seg * 4;
+    const int dz = tap / (a.KS * a.KS), dy = (tap / a.KS) % a.KS, dx = tap % a.KS;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int iz = vz[i] + dz, iy = vy[i] + dy, ix = vx[i] + dx;
+      const bool ok = vok[i] && iz >= 0 && iz < Dv && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const long long off = ((((long long)vb[i] * a.Di + (iz >> a.up)) * a.Hi + (iy >> a.up)) * a.Wi + (ix >> a.up)) * a.Cin + c0;
+        v = *reinterpret_cast<const f32x4*>(a.x + off);
+        if (a.in_scale) {
+          const f32x4 s = *reinterpret_cast<const f32x4*>(a.in_scale + (long long)vb[i] * a.Cin + c0);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(a.in_shift + (long long)vb[i] * a.Cin + c0);
+          v = v * s + t;
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < W_ROWS; ++i) {
+      const int row = srow + 64 * i;
+      if (row < N_T) rw[i] = *reinterpret_cast<const f32x4*>(a.wT + ((long long)tap * a.Cout + n0 + row) * a.Cin + c0);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+      *reinterpret_cast<f32x4*>(act_lds + ((buf * M_T) + srow + 64 * i) * LDS_STRIDE + seg * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < W_ROWS; ++i) {
+      const int row = srow + 64 * i;
+      if (row < N_T) *reinterpret_cast<f32x4*>(wgt_lds + ((buf * N_T) + row) * LDS_STRIDE + seg * 4) = rw[i];
+    }
+  };
+
+  f32x16 acc[CO_TILES][2];
+#pragma unroll
+  for (int i = 0; i < CO_TILES; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
+
+  load_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    store_chunk(buf);
+    __syncthreads();
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const float* ab = act_lds + (buf * M_T + wn * 64 + pl) * LDS_STRIDE + 4 * hi;
+    const float* wb = wgt_lds + (buf * N_T + wm * CO_TILES * 32 + pl) * LDS_STRIDE + 4 * hi;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x4 bf[2], af[CO_TILES];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(ab + j * 32 * LDS_STRIDE + sub * 8);
+#pragma unroll
+      for (int i = 0; i < CO_TILES; ++i) af[i] = *reinterpret_cast<const f32x4*>(wb + i * 32 * LDS_STRIDE + sub * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < CO_TILES; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = MFMA(af[i][q], bf[j][q], acc[i][j]);
+    }
+  }
+
+  // epilogue: lane (voxel, hi) holds couts 8g+4hi+j of each co tile -> 4 float4 stores per tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long long m = m0 + wn * 64 + j * 32 + pl;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < CO_TILES; ++i) {
+      const int cob = n0 + (wm * CO_TILES + i) * 32 + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (a.bias) v = v + *reinterpret_cast<const f32x4*>(a.bias + cob + 8 * g);
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(a.y + m * a.Cout + cob + 8 * g) = v;
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// per-(b,channel) sum / sum-of-squares partials in f64, deterministic two-level reduction
+// x: (B,V,C) ; partial: (B,S,C,2) f64 ; WG (b, split) covers rows [split*rows_per, ...)
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ x, double* __restrict__ partial,
+                                                         int V, int C, int S) {
+  __shared__ double red[256 * 8];
+  const int b = blockIdx.y, sp = blockIdx.x, tid = threadIdx.x;
+  const int cg = C / 4;        // float4 groups per row (C <= 1024 -> cg <= 256)
+  const int rpp = 256 / cg;    // rows per pass
+  const int rows_per = (V + S - 1) / S;
+  const int v0 = sp * rows_per, v1 = min(V, v0 + rows_per);
+  const int g = tid % cg, ro = tid / cg;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (ro < rpp)
+    for (int v = v0 + ro; v < v1; v += rpp) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(x + ((long long)b * V + v) * C + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j] += (double)t[j]; q[j] += (double)t[j] * (double)t[j]; }
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s[j]; red[tid * 8 + 4 + j] = q[j]; }
+  __syncthreads();
+  if (ro == 0) {
+    for (int r = 1; r < rpp; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j] += red[(tid + r * cg) * 8 + j]; q[j] += red[(tid + r * cg) * 8 + 4 + j]; }
+    double* o = partial + (((long long)b * S + sp) * C + 4 * g) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[2 * j] = s[j]; o[2 * j + 1] = q[j]; }
+  }
+}
+
+// GroupNorm(groups, eps) coefficients: scale[b,c] = gamma[c]*rstd[b,g], shift[b,c] = beta[c]-mean*scale
+__global__ void gn_coeffs_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                 int V, int C, int S, int groups, float eps) {
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= groups) return;
+  const int cpg = C / groups;
+  double s = 0, q = 0;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+    for (int sp = 0; sp < S; ++sp) {
+      const double* p = partial + (((long long)b * S + sp) * C + c) * 2;
+      s += p[0]; q += p[1];
+    }
+  const double n = (double)V * cpg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    const float sc = gamma[c] * rstd;
+    scale[b * C + c] = sc;
+    shift[b * C + c] = beta[c] - (float)mean * sc;
+  }
+}
+
+__global__ void affine_cl_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, float* __restrict__ y, long long V, int C, long long total4) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int cg = C / 4;
+  const int c4 = (int)(i % cg);
+  const long long row = i / cg;
+  const int b = (int)(row / V);
+  const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+  const f32x4 s = *reinterpret_cast<const f32x4*>(scale + (long long)b * C + 4 * c4);
+  const f32x4 t = *reinterpret_cast<const f32x4*>(shift + (long long)b * C + 4 * c4);
+  reinterpret_cast<f32x4*>(y)[i] = v * s + t;
+}
+
+__global__ void maxpool2_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int Do, int Ho, int Wo, int C) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = C / 4;
+  const long long total = (long long)B * Do * Ho * Wo * cg;
+  if (i >= total) return;
+  const int c4 = (int)(i % cg); long long r = i / cg;
+  const int xo = (int)(r % Wo); r /= Wo;
+  const int yo = (int)(r % Ho); r /= Ho;
+  const int zo = (int)(r % Do); const int b = (int)(r / Do);
+  const int Di = 2 * Do, Hi = 2 * Ho, Wi = 2 * Wo;
+  f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const long long off = ((((long long)b * Di + 2 * zo + (d >> 2)) * Hi + 2 * yo + ((d >> 1) & 1)) * Wi + 2 * xo + (d & 1)) * C + 4 * c4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+    m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+  }
+  reinterpret_cast<f32x4*>(y)[i] = m;
+}
+
+// out (B,D,H,W,Cs+Cu) = cat[ skip (B,D,H,W,Cs), nearest_x2( low (B,D/2,H/2,W/2,Cu) ) ]  (unet3d.py:268-283)
+__global__ void upcat_cl_kernel(const float* __restrict__ skip, const float* __restrict__ low, float* __restrict__ y,
+                                int B, int D, int H, int W, int Cs, int Cu) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = Cs + Cu, cg = C / 4;
+  const long long total = (long long)B * D * H * W * cg;
+  if (i >= total) return;
+  const int c = 4 * (int)(i % cg); long long r = i / cg;
+  const int xo = (int)(r % W); r /= W;
+  const int yo = (int)(r % H); r /= H;
+  const int zo = (int)(r % D); const int b = (int)(r / D);
+  f32x4 v;
+  if (c < Cs)
+    v = *reinterpret_cast<const f32x4*>(skip + ((((long long)b * D + zo) * H + yo) * W + xo) * Cs + c);
+  else
+    v = *reinterpret_cast<const f32x4*>(low + ((((long long)b * (D / 2) + (zo >> 1)) * (H / 2) + (yo >> 1)) * (W / 2) + (xo >> 1)) * Cu + (c - Cs));
+  reinterpret_cast<f32x4*>(y)[i] = v;
+}
+
+extern "C" {
+
+// host: torch Conv3d weight (Cout,Cin,k,k,k) -> [tap][Cout][Cin]
+int sfmi_conv_pack_weight(const float* w, int Cout, int Cin, int KS, float* out) {
+  if (!w || !out) return SFMI_EINVAL;
+  const int T = KS * KS * KS;
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < T; ++t) out[((size_t)t * Cout + co) * Cin + ci] = w[((size_t)co * Cin + ci) * T + t];
+  return SFMI_OK;
+}
+
+// replaces nn.Conv3d (+ fused input GroupNorm-apply, nearest-x2 upsample, bias, ReLU); see file header.
+// x (B,Di,Hi,Wi,Cin) -> y (B,Do,Ho,Wo,Cout), Do = ((Di<<up) + 2*pad - KS)/stride + 1.
+int sfmi_conv3d_cl_f32(const float* x, const float* wT, const float* in_scale, const float* in_shift,
+                       const float* bias, float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int KS,
+                       int stride, int pad, int up, int relu, void* stream) {
+  if (!x || !wT || !y || B <= 0 || Cin % KC || Cout % 32 || (KS != 1 && KS != 2 && KS != 3)) return SFMI_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return SFMI_EINVAL;
+  ConvArgs a;
+  a.x = x; a.wT = wT; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.y = y;
+  a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KS = KS; a.stride = stride; a.pad = pad;
+  a.up = up; a.relu = relu;
+  a.Do = ((Di << up) + 2 * pad - KS) / stride + 1;
+  a.Ho = ((Hi << up) + 2 * pad - KS) / stride + 1;
+  a.Wo = ((Wi << up) + 2 * pad - KS) / stride + 1;
+  const long long M = (long long)B * a.Do * a.Ho * a.Wo;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cout % 128 == 0) {
+    constexpr int M_T = 128, N_T = 128;
+    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
+    hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+  } else if (Cout % 64 == 0) {
+    constexpr int M_T = 256, N_T = 64;
+    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
+    hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+  } else {
+    constexpr int M_T = 256, N_T = 32;
+    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
+    hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+  }
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+int sfmi_gn_splits(int V) { return V >= 32768 ? 64 : (V >= 4096 ? 16 : (V >= 512 ? 4 : 1)); }
+
+// replaces nn.GroupNorm statistics (unet3d.py:66, updown.py): x (B,V,C) -> scale/shift (B,C) such that
+// GN(x) == x*scale + shift.  partial: workspace of B*sfmi_gn_splits(V)*C*2 doubles.
+int sfmi_groupnorm_coeffs_f32(const float* x, const float* gamma, const float* beta, float* scale, float* shift,
+                              double* partial, int B, int V, int C, int groups, float eps, void* stream) {
+  if (!x || !gamma || !beta || !scale || !shift || !partial || C % 4 || C > 1024 || C % groups || groups > 64) return SFMI_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = sfmi_gn_splits(V);
+  hipLaunchKernelGGL(chan_stats_kernel, dim3(S, B), dim3(256), 0, st, x, partial, V, C, S);
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(64), 0, st, partial, gamma, beta, scale, shift, V, C, S, groups, eps);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+int sfmi_affine_cl_f32(const float* x, const float* scale, const float* shift, float* y, int B, long long V, int C, void* stream) {
+  if (!x || !scale || !shift || !y || C % 4) return SFMI_EINVAL;
+  const long long total4 = (long long)B * V * (C / 4);
+  hipLaunchKernelGGL(affine_cl_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, V, C, total4);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+int sfmi_maxpool2_cl_f32(const float* x, float* y, int B, int Do, int Ho, int Wo, int C, void* stream) {
+  if (!x || !y || C % 4) return SFMI_EINVAL;
+  const long long total = (long long)B * Do * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool2_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, B, Do, Ho, Wo, C);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+int sfmi_upcat_cl_f32(const float* skip, const float* low, float* y, int B, int D, int H, int W, int Cs, int Cu, void* stream) {
+  if (!skip || !low || !y || Cs % 4 || Cu % 4) return SFMI_EINVAL;
+  const long long total = (long long)B * D * H * W * ((Cs + Cu) / 4);
+  hipLaunchKernelGGL(upcat_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, skip, low, y, B, D, H, W, Cs, Cu);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+}  // extern "C"

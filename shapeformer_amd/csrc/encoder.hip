@@ -1,0 +1,296 @@
+// VQDIF LocalPoolPointnet per-point path for gfx950 (reference: shapeformer/models/vqdif/enc.py:95-140,
+// layers.py:39-48, common.py:260-321; torch_scatter.scatter_max / scatter_mean call sites enc.py:70-74,103-110).
+//
+// MI355X design (not the reference's dense-grid dataflow):
+//   * the 64^3 cell id is computed ONCE (it is identical for the 4 pooling passes and the mean);
+//   * a cell's "segment" is named by its lowest point index (atomicMin on a 1 MB/shape int map), so the
+//     per-pass pooled maxima live in a compact (B,T,32) buffer instead of a 33.5 MB/shape dense grid;
+//   * max is order-independent -> integer-ordered atomicMax gives bit-exact, deterministic results;
+//   * the grid mean accumulates in 2^-32 fixed point (int64 atomics): associative, hence deterministic
+//     and order-independent, and more accurate than an f32 running sum;
+//   * the per-point MLP blocks run on f32 MFMA (32x32x2) with activations in the C/D register layout
+//     (same chaining trick as sdf_query.hip), weights staged per workgroup in LDS.
+#include "sfmi_common.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define ENC_G 64
+
+// packed per-block weights (floats): [fc0_lo 1024][fc0_hi 1024][sc_lo 1024][sc_hi 1024][fc1 1024][b0 32][b1 32]
+#define ENC_BLK_FLOATS (5 * 1024 + 64)
+// block-0 kernel additionally needs fc_pos: [half][2][64] = 256 floats ; last block needs fc_c: 1024 + 32
+#define ENC_OFF_BLK(k) ((k) * ENC_BLK_FLOATS)
+#define ENC_OFF_FCPOS (5 * ENC_BLK_FLOATS)
+#define ENC_OFF_FCC (ENC_OFF_FCPOS + 256)
+#define ENC_PACK_FLOATS (ENC_OFF_FCC + 1024 + 32)
+
+__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.0f); }
+
+// monotone float <-> int key (signed compare order == float order, NaN-free inputs)
+__device__ __forceinline__ int fkey(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// ---------------------------------------------------------------------------------------------
+// E0: cell ids (a2,a3), per-cell representative (segment id), latent occupancy mask (enc.py:85-91)
+// ---------------------------------------------------------------------------------------------
+__global__ void enc_cells_kernel(const float* __restrict__ cloud,  // (B,T,3) in [-1,1]
+                                 int* __restrict__ cell,            // (B,T)
+                                 int* __restrict__ rep,             // (B,G^3) pre-filled with 0x7f7f7f7f
+                                 unsigned char* __restrict__ mask,  // (B,R,R,R) pre-zeroed, [z][y][x]
+                                 int B, int T, int R) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * T) return;
+  int b = (int)(i / T), t = (int)(i - (long long)b * T);
+  const float* p = cloud + i * 3;
+  float ux = sfmi_normalize(p[0] * 0.5f), uy = sfmi_normalize(p[1] * 0.5f), uz = sfmi_normalize(p[2] * 0.5f);
+  int cx = (int)(ux * (float)ENC_G), cy = (int)(uy * (float)ENC_G), cz = (int)(uz * (float)ENC_G);
+  int c = cx + ENC_G * (cy + ENC_G * cz);  // common.py:300-321 'original' order
+  cell[i] = c;
+  atomicMin(&rep[(long long)b * ENC_G * ENC_G * ENC_G + c], t);
+  int mx = (int)(ux * (float)R), my = (int)(uy * (float)R), mz = (int)(uz * (float)R);
+  mask[(((long long)b * R + mz) * R + my) * R + mx] = 1;
+}
+
+// one 32x32 layer: acc += W * x  (x in C/D layout, optional ReLU on the fly)
+template <bool RELU>
+__device__ __forceinline__ void layer32(const f32x4* __restrict__ Wl, const f32x16& x, f32x16& acc) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 w = Wl[64 * g];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = MFMA(w[j], RELU ? relu(x[4 * g + j]) : x[4 * g + j], acc);
+  }
+}
+
+__device__ __forceinline__ void bias_init(const float* __restrict__ b, int hi, f32x16& acc) {
+  const f32x4* bp = reinterpret_cast<const f32x4*>(b + 4 * hi);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v = bp[2 * g];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[4 * g + j] = v[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// E1..E5: one ResnetBlockFC stage per launch (the pooling between stages is a global dependency).
+//   STAGE 0 : x = fc_pos(p)                      (enc.py:125-127)
+//   STAGE k : x = cat[net_{k-1}, pooled_{k-1}]   (enc.py:128-131)
+//   out net_k ; atomicMax into segmax_k (k<4) ; k==4: c = fc_c(net) -> fixed-point mean accumulators
+// ---------------------------------------------------------------------------------------------
+template <int STAGE>
+__global__ __launch_bounds__(256) void enc_block_kernel(
+    const float* __restrict__ cloud, const int* __restrict__ cell, const int* __restrict__ rep,
+    const float* __restrict__ net_in,     // (B,T,32)
+    const int* __restrict__ segmax_in,    // (B,T,32) ordered-int keys
+    float* __restrict__ net_out,          // (B,T,32)
+    int* __restrict__ segmax_out,         // (B,T,32) pre-filled 0x80808080
+    long long* __restrict__ csum,         // (B,T,32) pre-zeroed   (STAGE 4)
+    int* __restrict__ ccount,             // (B,T)    pre-zeroed   (STAGE 4)
+    const float* __restrict__ wpack, int B, int T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // stage weights: block STAGE (+ fc_pos for 0, + fc_c for 4)
+  {
+    const f32x4* s = reinterpret_cast<const f32x4*>(wpack + ENC_OFF_BLK(STAGE));
+    f32x4* d = reinterpret_cast<f32x4*>(lds);
+    for (int i = threadIdx.x; i < ENC_BLK_FLOATS / 4; i += blockDim.x) d[i] = s[i];
+    if (STAGE == 0) {
+      const f32x4* s2 = reinterpret_cast<const f32x4*>(wpack + ENC_OFF_FCPOS);
+      f32x4* d2 = reinterpret_cast<f32x4*>(lds + ENC_BLK_FLOATS);
+      for (int i = threadIdx.x; i < 256 / 4; i += blockDim.x) d2[i] = s2[i];
+    }
+    if (STAGE == 4) {
+      const f32x4* s2 = reinterpret_cast<const f32x4*>(wpack + ENC_OFF_FCC);
+      f32x4* d2 = reinterpret_cast<f32x4*>(lds + ENC_BLK_FLOATS);
+      for (int i = threadIdx.x; i < (1024 + 32) / 4; i += blockDim.x) d2[i] = s2[i];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, hi = lane >> 5, pl = lane & 31;
+  const long long total = (long long)B * T;
+  const long long ntiles = (total + 31) >> 5;
+  const long long wave_gid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const f32x4* L = reinterpret_cast<const f32x4*>(lds) + lane;
+
+  for (long long tile = wave_gid; tile < ntiles; tile += nwaves) {
+    long long i = tile * 32 + pl;
+    const bool valid = i < total;
+    if (!valid) i = total - 1;
+    const int b = (int)(i / T);
+    const long long seg = (long long)b * T + rep[(long long)b * ENC_G * ENC_G * ENC_G + cell[i]];
+
+    f32x16 xlo, xhi;
+    if (STAGE == 0) {
+      const float* p = cloud + i * 3;
+      const float hx = p[0] * 0.5f, hy = p[1] * 0.5f, hz = p[2] * 0.5f;  // vqdif.py:36 Xbd/2
+      const float* fp = lds + ENC_BLK_FLOATS;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { xlo[t] = 0.0f; xhi[t] = 0.0f; }
+      xlo = MFMA(fp[lane], hi ? hy : hx, xlo);
+      xlo = MFMA(fp[64 + lane], hi ? 1.0f : hz, xlo);
+      xhi = MFMA(fp[128 + lane], hi ? hy : hx, xhi);
+      xhi = MFMA(fp[192 + lane], hi ? 1.0f : hz, xhi);
+    } else {
+      const f32x4* np_ = reinterpret_cast<const f32x4*>(net_in + i * 32 + 4 * hi);
+      const int4* sp = reinterpret_cast<const int4*>(segmax_in + seg * 32 + 4 * hi);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = np_[2 * g];
+        int4 k = sp[2 * g];
+        xlo[4 * g + 0] = v[0]; xlo[4 * g + 1] = v[1]; xlo[4 * g + 2] = v[2]; xlo[4 * g + 3] = v[3];
+        xhi[4 * g + 0] = fkey_inv(k.x); xhi[4 * g + 1] = fkey_inv(k.y);
+        xhi[4 * g + 2] = fkey_inv(k.z); xhi[4 * g + 3] = fkey_inv(k.w);
+      }
+    }
+    // h = fc_0(relu(x)) + b0 ; out = shortcut(x) + fc_1(relu(h)) + b1      (layers.py:39-48)
+    f32x16 h, o;
+    bias_init(lds + 5 * 1024, hi, h);
+    layer32<true>(L + 0 * 256, xlo, h);
+    layer32<true>(L + 1 * 256, xhi, h);
+    bias_init(lds + 5 * 1024 + 32, hi, o);
+    layer32<false>(L + 2 * 256, xlo, o);
+    layer32<false>(L + 3 * 256, xhi, o);
+    layer32<true>(L + 4 * 256, h, o);
+
+    if (STAGE < 4) {
+      if (valid) {
+        f32x4* op = reinterpret_cast<f32x4*>(net_out + i * 32 + 4 * hi);
+        int* sm = segmax_out + seg * 32 + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+          op[2 * g] = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicMax(sm + 8 * g + j, fkey(o[4 * g + j]));
+        }
+      }
+    } else {
+      // c = fc_c(net) (enc.py:133) -> fixed-point accumulate for the per-cell mean (enc.py:70-74)
+      f32x16 c;
+      bias_init(lds + ENC_BLK_FLOATS + 1024, hi, c);
+      layer32<false>(reinterpret_cast<const f32x4*>(lds + ENC_BLK_FLOATS) + lane, o, c);
+      if (valid) {
+        long long* sp = csum + seg * 32 + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            long long q = __double2ll_rn((double)c[4 * g + j] * 4294967296.0);
+            atomicAdd(reinterpret_cast<unsigned long long*>(sp + 8 * g + j), (unsigned long long)q);
+          }
+        if (hi == 0) atomicAdd(ccount + seg, 1);
+      }
+    }
+  }
+}
+
+// E6: write the per-cell means into the dense channels-last (B,G,G,G,32) grid (pre-zeroed).
+__global__ void enc_grid_mean_kernel(const int* __restrict__ cell, const int* __restrict__ rep,
+                                     const long long* __restrict__ csum, const int* __restrict__ ccount,
+                                     float* __restrict__ grid, int B, int T) {
+  long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long i = gid >> 5;
+  int ch = (int)(gid & 31);
+  if (i >= (long long)B * T) return;
+  int b = (int)(i / T), t = (int)(i - (long long)b * T);
+  int c = cell[i];
+  if (rep[(long long)b * ENC_G * ENC_G * ENC_G + c] != t) return;  // only the representative writes
+  double s = (double)csum[i * 32 + ch] * (1.0 / 4294967296.0);
+  grid[((long long)b * ENC_G * ENC_G * ENC_G + c) * 32 + ch] = (float)(s / (double)ccount[i]);
+}
+
+extern "C" {
+
+size_t sfmi_enc_pack_floats(void) { return ENC_PACK_FLOATS; }
+
+static void pack_frag(const float* W, int ld, int col0, float* out) {  // W[co][col0 + k], k<32
+  for (int g = 0; g < 4; ++g)
+    for (int l = 0; l < 64; ++l)
+      for (int j = 0; j < 4; ++j) out[(g * 64 + l) * 4 + j] = W[(l & 31) * ld + col0 + 8 * g + 4 * (l >> 5) + j];
+}
+
+// Host packer. blocks: 5x {fc_0.weight(32,64), fc_0.bias, fc_1.weight(32,32), fc_1.bias, shortcut.weight(32,64)}
+int sfmi_enc_pack_weights(const float* fc_pos_w /*64x3*/, const float* fc_pos_b /*64*/, const float* fc0_w,
+                          const float* fc0_b, const float* fc1_w, const float* fc1_b, const float* sc_w,
+                          const float* fc_c_w /*32x32*/, const float* fc_c_b, float* out) {
+  if (!fc_pos_w || !out) return SFMI_EINVAL;
+  for (int k = 0; k < 5; ++k) {
+    float* o = out + ENC_OFF_BLK(k);
+    pack_frag(fc0_w + k * 2048, 64, 0, o);
+    pack_frag(fc0_w + k * 2048, 64, 32, o + 1024);
+    pack_frag(sc_w + k * 2048, 64, 0, o + 2048);
+    pack_frag(sc_w + k * 2048, 64, 32, o + 3072);
+    pack_frag(fc1_w + k * 1024, 32, 0, o + 4096);
+    for (int c = 0; c < 32; ++c) {
+      o[5120 + c] = fc0_b[k * 32 + c];
+      o[5152 + c] = fc1_b[k * 32 + c];
+    }
+  }
+  float* fp = out + ENC_OFF_FCPOS;
+  for (int half = 0; half < 2; ++half)
+    for (int l = 0; l < 64; ++l) {
+      int co = half * 32 + (l & 31), hi = l >> 5;
+      fp[half * 128 + l] = fc_pos_w[co * 3 + (hi ? 1 : 0)];
+      fp[half * 128 + 64 + l] = hi ? fc_pos_b[co] : fc_pos_w[co * 3 + 2];
+    }
+  pack_frag(fc_c_w, 32, 0, out + ENC_OFF_FCC);
+  for (int c = 0; c < 32; ++c) out[ENC_OFF_FCC + 1024 + c] = fc_c_b[c];
+  return SFMI_OK;
+}
+
+size_t sfmi_enc_workspace_bytes(int B, int T) {
+  size_t bt = (size_t)B * T;
+  // cell(4) + rep map + 2 net buffers + 2 segmax buffers + csum + ccount
+  return bt * 4 + (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + 1024;
+}
+
+// replaces LocalPoolPointnet.forward up to scatter_mean (enc.py:115-140 minus the Downsampler):
+// cloud (B,T,3) -> dense channels-last mean grid (B,64,64,64,32) + latent occupancy mask (B,R,R,R) u8.
+int sfmi_encode_points_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask,
+                           int* cell_out /*optional (B,T)*/, void* workspace, int B, int T, int R, void* stream_) {
+  if (!cloud || !wpack || !grid_cl || !mask || !workspace || B <= 0 || T <= 0 || R <= 0) return SFMI_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  const size_t bt = (size_t)B * T;
+  char* w = (char*)workspace;
+  int* cell = (int*)w; w += bt * 4;
+  int* rep = (int*)w; w += (size_t)B * ENC_G * ENC_G * ENC_G * 4;
+  float* net[2]; net[0] = (float*)w; w += bt * 128; net[1] = (float*)w; w += bt * 128;
+  int* sm[2]; sm[0] = (int*)w; w += bt * 128; sm[1] = (int*)w; w += bt * 128;
+  long long* csum = (long long*)w; w += bt * 256;
+  int* ccount = (int*)w;
+  hipMemsetAsync(rep, 0x7f, (size_t)B * ENC_G * ENC_G * ENC_G * 4, st);
+  hipMemsetAsync(mask, 0, (size_t)B * R * R * R, st);
+  hipMemsetAsync(csum, 0, bt * 256 + bt * 4, st);
+  hipMemsetAsync(grid_cl, 0, (size_t)B * ENC_G * ENC_G * ENC_G * 32 * 4, st);
+  int nb = (int)((bt + 255) / 256);
+  hipLaunchKernelGGL(enc_cells_kernel, dim3(nb), dim3(256), 0, st, cloud, cell, rep, mask, B, T, R);
+  const long long tiles = (long long)(bt + 31) / 32;
+  int grid = (int)((tiles + 3) / 4);
+  if (grid > 2048) grid = 2048;
+  const size_t lds0 = (ENC_BLK_FLOATS + 256) * 4, ldsk = ENC_BLK_FLOATS * 4, lds4 = (ENC_BLK_FLOATS + 1056) * 4;
+  hipMemsetAsync(sm[0], 0x80, bt * 128, st);
+  hipLaunchKernelGGL(enc_block_kernel<0>, dim3(grid), dim3(256), lds0, st, cloud, cell, rep, nullptr, nullptr, net[0],
+                     sm[0], nullptr, nullptr, wpack, B, T);
+  hipMemsetAsync(sm[1], 0x80, bt * 128, st);
+  hipLaunchKernelGGL(enc_block_kernel<1>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[0], sm[0], net[1],
+                     sm[1], nullptr, nullptr, wpack, B, T);
+  hipMemsetAsync(sm[0], 0x80, bt * 128, st);
+  hipLaunchKernelGGL(enc_block_kernel<2>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[1], sm[1], net[0],
+                     sm[0], nullptr, nullptr, wpack, B, T);
+  hipMemsetAsync(sm[1], 0x80, bt * 128, st);
+  hipLaunchKernelGGL(enc_block_kernel<3>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[0], sm[0], net[1],
+                     sm[1], nullptr, nullptr, wpack, B, T);
+  hipLaunchKernelGGL(enc_block_kernel<4>, dim3(grid), dim3(256), lds4, st, cloud, cell, rep, net[1], sm[1], nullptr,
+                     nullptr, csum, ccount, wpack, B, T);
+  long long nthr = (long long)bt * 32;
+  hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, cell, rep, csum,
+                     ccount, grid_cl, B, T);
+  if (cell_out) hipMemcpyAsync(cell_out, cell, bt * 4, hipMemcpyDeviceToDevice, st);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+}  // extern "C"
