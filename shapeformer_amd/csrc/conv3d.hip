@@ -20,7 +20,9 @@
 
 struct ConvArgs {
   const float* x; const float* wT; const float* in_scale; const float* in_shift; const float* bias; float* y;
-  int B, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, KS, stride, pad, up, relu;
+  const float* resid;                     // optional residual added in the epilogue (same row mapping as y)
+  long long out_group, out_group_stride;  // output row remap: m -> (m/out_group)*out_group_stride + m%out_group
+  int B, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, KS, stride, pad, up, relu /*0 none, 1 relu, 2 gelu(erf)*/;
 };
 
 template <int CO_TILES, int WM, int WN>
@@ -128,8 +130,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
   // epilogue: lane (voxel, hi) holds couts 8g+4hi+j of each co tile -> 4 float4 stores per tile
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const long long m = m0 + wn * 64 + j * 32 + pl;
-    if (m >= M) continue;
+    const long long m_in = m0 + wn * 64 + j * 32 + pl;
+    if (m_in >= M) continue;
+    const long long m = a.out_group ? (m_in / a.out_group) * a.out_group_stride + m_in % a.out_group : m_in;
 #pragma unroll
     for (int i = 0; i < CO_TILES; ++i) {
       const int cob = n0 + (wm * CO_TILES + i) * 32 + 4 * hi;
@@ -137,7 +140,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
       for (int g = 0; g < 4; ++g) {
         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         if (a.bias) v = v + *reinterpret_cast<const f32x4*>(a.bias + cob + 8 * g);
-        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (a.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (a.relu == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+        }
+        if (a.resid) v = v + *reinterpret_cast<const f32x4*>(a.resid + m * a.Cout + cob + 8 * g);
         *reinterpret_cast<f32x4*>(a.y + m * a.Cout + cob + 8 * g) = v;
       }
     }
@@ -254,6 +262,27 @@ __global__ void upcat_cl_kernel(const float* __restrict__ skip, const float* __r
   reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
+static int conv_dispatch(const ConvArgs& a, void* stream) {
+  const int Cout = a.Cout;
+  const long long M = (long long)a.B * a.Do * a.Ho * a.Wo;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cout % 128 == 0) {
+    constexpr int M_T = 128, N_T = 128;
+    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
+    hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+  } else if (Cout % 64 == 0) {
+    constexpr int M_T = 256, N_T = 64;
+    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
+    hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+  } else {
+    constexpr int M_T = 256, N_T = 32;
+    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
+    hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+  }
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
 extern "C" {
 
 // host: torch Conv3d weight (Cout,Cin,k,k,k) -> [tap][Cout][Cin]
@@ -276,27 +305,25 @@ int sfmi_conv3d_cl_f32(const float* x, const float* wT, const float* in_scale, c
   ConvArgs a;
   a.x = x; a.wT = wT; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.y = y;
   a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KS = KS; a.stride = stride; a.pad = pad;
-  a.up = up; a.relu = relu;
+  a.up = up; a.relu = relu; a.resid = nullptr; a.out_group = 0; a.out_group_stride = 0;
   a.Do = ((Di << up) + 2 * pad - KS) / stride + 1;
   a.Ho = ((Hi << up) + 2 * pad - KS) / stride + 1;
   a.Wo = ((Wi << up) + 2 * pad - KS) / stride + 1;
-  const long long M = (long long)B * a.Do * a.Ho * a.Wo;
-  hipStream_t st = (hipStream_t)stream;
-  if (Cout % 128 == 0) {
-    constexpr int M_T = 128, N_T = 128;
-    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
-    hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
-  } else if (Cout % 64 == 0) {
-    constexpr int M_T = 256, N_T = 64;
-    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
-    hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
-  } else {
-    constexpr int M_T = 256, N_T = 32;
-    dim3 grid((unsigned)((M + M_T - 1) / M_T), Cout / N_T);
-    hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
-  }
-  SFMI_CHECK_LAUNCH();
-  return SFMI_OK;
+  return conv_dispatch(a, stream);
+}
+
+// Plain row-major GEMM through the same kernel (a 1x1x1 "conv" over M rows):
+//   y[remap(m)][n] = act( sum_k x[m][k] * W[n][k] + bias[n] ) + resid[remap(m)][n]
+// used by the transformer PREFILL (mingpt.py:46-111 Linear layers at M = B*L_c rows).
+int sfmi_gemm_f32(const float* x, const float* W, const float* bias, const float* resid, float* y, long long M, int N,
+                  int K, int act, long long out_group, long long out_group_stride, void* stream) {
+  if (!x || !W || !y || M <= 0 || K % KC || N % 32 || M > 0x7fffffffLL) return SFMI_EINVAL;
+  ConvArgs a;
+  a.x = x; a.wT = W; a.in_scale = nullptr; a.in_shift = nullptr; a.bias = bias; a.y = y; a.resid = resid;
+  a.out_group = out_group; a.out_group_stride = out_group_stride;
+  a.B = 1; a.Di = 1; a.Hi = 1; a.Wi = (int)M; a.Do = 1; a.Ho = 1; a.Wo = (int)M; a.Cin = K; a.Cout = N; a.KS = 1;
+  a.stride = 1; a.pad = 0; a.up = 0; a.relu = act;
+  return conv_dispatch(a, stream);
 }
 
 int sfmi_gn_splits(int V) { return V >= 32768 ? 64 : (V >= 4096 ? 16 : (V >= 512 ? 4 : 1)); }

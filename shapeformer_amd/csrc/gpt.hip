@@ -1,0 +1,634 @@
+// CondTupleGPT (20+4 pre-LN blocks, two tuple heads) KV-cached sampling for gfx950.
+//
+// Replaces the reference's host-driven loop that re-forwards the WHOLE prefix every step
+// (shapeformer.py:54-123 -> mingpt.py:297-310, ~113 TFLOP/sequence) with a KV-cached decode step
+// (valid by SURVEY Appendix A11) made of a handful of weight-streaming kernels that read all
+// per-row state (lengths, tokens) from device memory, so one captured hipGraph replays every step:
+//
+//   rowprep   x = resid + sum_s partial[s] + bias (+ token-embedding add) ; LayerNorm -> xn
+//             (mingpt.py:103-111 residual adds, :256-286 embeddings, LN eps 1e-5)
+//   skinny    out[m][n] = sum_k x[m][k] W[n][k]  for M <= 64 rows on f32 MFMA 32x32x2, weights
+//             pre-packed in MFMA-fragment order (every wave-load = 1 KiB contiguous), split-K across
+//             workgroups -> raw partials (deterministic: the consumer sums them in fixed order)
+//   attn      one workgroup per (row, head): new q/k/v from the QKV partials, KV append, softmax(QK^T/8)V
+//             over the row's own cached length (rows are ragged)            (mingpt.py:73-91)
+//   sample    sampling_masker + filter_sampling_logits + inverse-CDF draw   (representers.py:120-155,
+//             common.py:260-299) fused per row: radix-select top-k, bitonic sort of the candidates,
+//             top-p cut, counter-hash uniforms (no host RNG, no per-step D2H of (B,4097) logits)
+#include "sfmi_common.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------
+// rowprep
+// ------------------------------------------------------------------------------------------------
+struct RowPrepArgs {
+  // EMBED source (mode 0): token tables
+  const float *E0, *E1, *Ex, *pos_emb, *cond_pos_emb;
+  const int *seq, *len, *Lc;  // (B,Lmax,2), (B), (B)
+  // ACCUM source (mode 1)
+  const float* resid_in;   // (M,D)
+  const float* part;       // (S,M,D) or null
+  const float* bias;       // (D) or null
+  const float* Eadd;       // optional: add Eadd[seq[b][t+1][0]] (stage-1 input, mingpt.py:294/309)
+  // outputs
+  float* resid_out;        // (M,D) or null
+  float* xn;               // (M,D) or null (LayerNorm output)
+  const float *gamma, *beta;
+  int mode, S, M, D, Lmax, P /*0: decode (t = len[b]-1); >0: prefill rows m=(b,t), t<P*/, end0;
+};
+
+__global__ __launch_bounds__(256) void rowprep_kernel(RowPrepArgs a) {
+  __shared__ float red[8];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int b = a.P ? m / a.P : m;
+  int t;
+  if (a.P) { t = m - b * a.P; } else { t = a.len ? a.len[b] - 1 : 0; }
+  const int lc = a.Lc ? a.Lc[b] : 0;
+  if (a.P) { int tmax = lc - 2; if (tmax < 0) tmax = 0; if (t > tmax) t = tmax; }  // padded prefill rows: harmless clamp
+  const int nq = a.D / 4;
+  f32x4 v[4];
+  float s = 0.f;
+  int pos = 0, val = 0, ext = 0;
+  if (a.mode == 0) {
+    const int* tk = a.seq + ((long long)b * a.Lmax + t) * 2;
+    pos = tk[0]; val = tk[1];
+    if (t < lc) {
+      ext = pos;  // representers.py:191 cond token -> own pos
+    } else if (pos == a.end0) {
+      ext = a.end0;
+    } else {      // representers.py:432-442: first cond pos > pos (cond ascending, ends with end token)
+      int lo = 0, hi = lc;
+      const int* cs = a.seq + (long long)b * a.Lmax * 2;
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (cs[2 * mid] > pos) hi = mid; else lo = mid + 1; }
+      ext = cs[2 * (lo < lc ? lo : lc - 1)];
+    }
+  }
+  int addrow = -1;
+  if (a.mode == 1 && a.Eadd) addrow = a.seq[((long long)b * a.Lmax + t + 1) * 2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = tid + it * 256;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    v[it] = x;
+    if (q >= nq) continue;
+    if (a.mode == 0) {
+      const f32x4 e0 = reinterpret_cast<const f32x4*>(a.E0 + (long long)pos * a.D)[q];
+      const f32x4 e1 = reinterpret_cast<const f32x4*>(a.E1 + (long long)val * a.D)[q];
+      const f32x4 ex = reinterpret_cast<const f32x4*>(a.Ex + (long long)ext * a.D)[q];
+      const float* pe = t < lc ? a.cond_pos_emb + (long long)t * a.D : a.pos_emb + (long long)(t - lc) * a.D;
+      x = ((e0 + e1) + ex) + reinterpret_cast<const f32x4*>(pe)[q];  // mingpt.py:285 order
+    } else {
+      x = reinterpret_cast<const f32x4*>(a.resid_in + (long long)m * a.D)[q];
+      if (a.part) {
+        f32x4 p = reinterpret_cast<const f32x4*>(a.part + (long long)m * a.D)[q];
+        for (int sp = 1; sp < a.S; ++sp) p = p + reinterpret_cast<const f32x4*>(a.part + ((long long)sp * a.M + m) * a.D)[q];
+        if (a.bias) p = p + reinterpret_cast<const f32x4*>(a.bias)[q];
+        x = x + p;
+      }
+      if (addrow >= 0) x = x + reinterpret_cast<const f32x4*>(a.Eadd + (long long)addrow * a.D)[q];
+    }
+    if (a.resid_out) reinterpret_cast<f32x4*>(a.resid_out + (long long)m * a.D)[q] = x;
+    v[it] = x;
+    s += (x[0] + x[1]) + (x[2] + x[3]);
+  }
+  if (!a.xn) return;
+  // LayerNorm (two-pass, biased variance, eps 1e-5)
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)a.D;
+  float qv = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    if (tid + it * 256 >= nq) continue;
+    const f32x4 d = v[it] - mean;
+    qv += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+  }
+  qv = wave_sum(qv);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = qv;
+  __syncthreads();
+  const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)a.D + 1e-5f);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = tid + it * 256;
+    if (q >= nq) continue;
+    const f32x4 g = reinterpret_cast<const f32x4*>(a.gamma)[q], be = reinterpret_cast<const f32x4*>(a.beta)[q];
+    reinterpret_cast<f32x4*>(a.xn + (long long)m * a.D)[q] = (v[it] - mean) * rstd * g + be;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM: out[m][n] = sum_k x[m][k] * W[n][k],  M <= 32*MT rows
+//   Wp packed [N/32][K/8][64][4];  grid (N/32, S);  NW waves split the WG's k-slice; LDS reduce.
+//   epi 0: raw partial -> out[(s*M + m)*ldo + n] ; 1: + bias, GELU(erf) ; 2: + bias   (1,2 need S == 1)
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int M, int N, int K, int kslice, int ldo, int epi) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NW][MT*16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, pl = lane & 31;
+  const int nt = blockIdx.x, sp = blockIdx.y;
+  const int kw = kslice / NW;
+  const int k0 = sp * kslice + wave * kw;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((long long)nt * (K / 8) + k0 / 8) * 64 + lane;
+  const float* xr[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    int m = j * 32 + pl;
+    if (m >= M) m = M - 1;
+    xr[j] = x + (long long)m * K + k0 + 4 * hi;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[j][t] = 0.f;
+  const int steps = kw / 8;
+#pragma unroll 4
+  for (int st = 0; st < steps; ++st) {
+    const f32x4 w = wp[st * 64];
+    f32x4 xb[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) xb[j] = *reinterpret_cast<const f32x4*>(xr[j] + st * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[j] = MFMA(w[q], xb[j][q], acc[j]);
+  }
+  // cross-wave reduction through LDS
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) lds[((wave * MT + j) * 16 + t) * 64 + lane] = acc[j][t];
+  __syncthreads();
+  for (int item = wave; item < MT * 4; item += NW) {
+    const int j = item >> 2, g = item & 3;
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] += lds[((w * MT + j) * 16 + 4 * g + e) * 64 + lane];
+    const int m = j * 32 + pl;
+    const int n = nt * 32 + 8 * g + 4 * hi;
+    if (m < M && n < N) {
+      if (epi) {
+        r = r + *reinterpret_cast<const f32x4*>(bias + n);
+        if (epi == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
+        }
+      }
+      *reinterpret_cast<f32x4*>(out + ((long long)sp * M + m) * ldo + n) = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode attention: grid (B, H), 256 threads; head dim 64 (or any multiple of 4 up to 64)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv_part /*(S,M,3D) q|k|v*/,
+                                                          const float* __restrict__ bqkv /*(3D)*/, float* __restrict__ Kc,
+                                                          float* __restrict__ Vc /*(B,Lmax,D)*/, const int* __restrict__ len,
+                                                          float* __restrict__ y /*(M,D)*/, int S, int M, int D, int Lmax,
+                                                          int HD, float scale) {
+  __shared__ float qs[64], kn[64], vn[64], sc[1024], red[8], yacc[4][64];
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = len[b] - 1;  // position being processed
+  const int nq4 = HD / 4;    // float4 per head row
+  if (tid < HD) {
+    float q = bqkv[h * HD + tid], k = bqkv[D + h * HD + tid], v = bqkv[2 * D + h * HD + tid];
+    for (int s = 0; s < S; ++s) {
+      const float* p = qkv_part + ((long long)s * M + b) * 3 * D + h * HD + tid;
+      q += p[0]; k += p[D]; v += p[2 * D];
+    }
+    qs[tid] = q * scale; kn[tid] = k; vn[tid] = v;
+    Kc[((long long)b * Lmax + t) * D + h * HD + tid] = k;
+    Vc[((long long)b * Lmax + t) * D + h * HD + tid] = v;
+  }
+  __syncthreads();
+  // scores: 16 lanes per key (float4 each), 4 keys per wave instruction
+  const int c4 = lane & 15, kk = lane >> 4;
+  f32x4 qf = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < nq4) qf = *reinterpret_cast<const f32x4*>(qs + 4 * c4);
+  float lmax = -INFINITY;
+  for (int i0 = 0; i0 <= t; i0 += 16) {
+    const int i = i0 + wave * 4 + kk;
+    float d = 0.f;
+    if (i <= t && c4 < nq4) {
+      const f32x4 kf = (i == t) ? *reinterpret_cast<const f32x4*>(kn + 4 * c4)
+                                : *reinterpret_cast<const f32x4*>(Kc + ((long long)b * Lmax + i) * D + h * HD + 4 * c4);
+      d = (qf[0] * kf[0] + qf[1] * kf[1]) + (qf[2] * kf[2] + qf[3] * kf[3]);
+    }
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+    if (i <= t) {
+      if (c4 == 0) sc[i] = d;
+      lmax = fmaxf(lmax, d);
+    }
+  }
+  lmax = wave_max(lmax);
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float ls = 0.f;
+  for (int i = tid; i <= t; i += 256) {
+    const float e = __expf(sc[i] - gmax);
+    sc[i] = e;
+    ls += e;
+  }
+  ls = wave_sum(ls);
+  if (lane == 0) red[4 + wave] = ls;
+  __syncthreads();
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+  // y = sum_i p_i V[i]
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i0 = 0; i0 <= t; i0 += 16) {
+    const int i = i0 + wave * 4 + kk;
+    if (i <= t && c4 < nq4) {
+      const f32x4 vf = (i == t) ? *reinterpret_cast<const f32x4*>(vn + 4 * c4)
+                                : *reinterpret_cast<const f32x4*>(Vc + ((long long)b * Lmax + i) * D + h * HD + 4 * c4);
+      acc = acc + vf * sc[i];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { acc[e] += __shfl_xor(acc[e], 16, 64); acc[e] += __shfl_xor(acc[e], 32, 64); }
+  if (kk == 0 && c4 < nq4) *reinterpret_cast<f32x4*>(&yacc[wave][4 * c4]) = acc;
+  __syncthreads();
+  if (tid < HD) y[(long long)b * D + h * HD + tid] = ((yacc[0][tid] + yacc[1][tid]) + (yacc[2][tid] + yacc[3][tid])) * inv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prefill attention (causal, flash-style): grid (B, H, ceil(P/64)); qkv (B*P, 3D) rows m=(b,t); HD == 64
+//   each thread: query qi = tid>>2, dims [16*(tid&3), +16); also writes the K/V rows of its query block
+//   into the caches.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
+                                                           float* __restrict__ Vc, const int* __restrict__ Lc,
+                                                           float* __restrict__ y /*(B*P,D)*/, int P, int D, int Lmax,
+                                                           float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[64][64], Vs[64][64];
+  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x;
+  const int n = min(P, max(Lc[b] - 1, 0));  // valid prefill positions of this row
+  const int q0 = qb * 64;
+  if (q0 >= n) return;
+  const int qi = tid >> 2, c16 = tid & 3;
+  const int tq = q0 + qi;
+  const bool qok = tq < n;
+  f32x4 qf[4];
+  {
+    const float* qp = qkv + ((long long)b * P + (qok ? tq : q0)) * 3 * D + h * 64 + 16 * c16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qf[e] = reinterpret_cast<const f32x4*>(qp)[e] * scale;
+  }
+  float mrun = -INFINITY, lrun = 0.f;
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kend = min(n, q0 + 64);
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      const int tk = min(k0 + r, n - 1);
+      const float* src = qkv + ((long long)b * P + tk) * 3 * D + h * 64 + 4 * c;
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(src + D), vv = *reinterpret_cast<const f32x4*>(src + 2 * D);
+      *reinterpret_cast<f32x4*>(&Ks[r][4 * c]) = kv;
+      *reinterpret_cast<f32x4*>(&Vs[r][4 * c]) = vv;
+      if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
+        *reinterpret_cast<f32x4*>(Kc + ((long long)b * Lmax + k0 + r) * D + h * 64 + 4 * c) = kv;
+        *reinterpret_cast<f32x4*>(Vc + ((long long)b * Lmax + k0 + r) * D + h * 64 + 4 * c) = vv;
+      }
+    }
+    __syncthreads();
+    const int jn = min(64, kend - k0);
+    for (int j = 0; j < jn; ++j) {
+      const f32x4* kr = reinterpret_cast<const f32x4*>(&Ks[j][16 * c16]);
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const f32x4 kf = kr[e]; d += (qf[e][0] * kf[0] + qf[e][1] * kf[1]) + (qf[e][2] * kf[2] + qf[e][3] * kf[3]); }
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
+      if (k0 + j > tq) d = -INFINITY;  // causal
+      const float mnew = fmaxf(mrun, d);
+      if (mnew == -INFINITY) continue;
+      const float corr = __expf(mrun - mnew), p = __expf(d - mnew);
+      lrun = lrun * corr + p;
+      const f32x4* vr = reinterpret_cast<const f32x4*>(&Vs[j][16 * c16]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] * corr + vr[e] * p;
+      mrun = mnew;
+    }
+  }
+  if (qok) {
+    const float inv = 1.0f / lrun;
+    float* yp = y + ((long long)b * P + tq) * D + h * 64 + 16 * c16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) reinterpret_cast<f32x4*>(yp)[e] = acc[e] * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused sampler: one workgroup per row
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned fkey_u(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float sf_uniform(unsigned seed, unsigned idx) {  // == weights.hash_unit element idx
+  unsigned h = idx * 0x9E3779B1u + seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+struct SampleArgs {
+  const float* part;  // (S,M,ldv) logits partials (heads have no bias)
+  int* seq; int* len; const int* Lc;
+  float* logp;        // (B,max_steps,2) log-prob of the drawn token under the masked logits, or null
+  float* hist;        // (B,max_steps,V) masked logits history for this tuple element, or null
+  const int* force;   // (B,max_steps,2) teacher-forced tokens (parity tests), or null
+  int S, M, V, ldv, Lmax, tuple_i, end0, end1, top_k, greedy_row0, mask_invalid, mask_completion, max_steps, advance;
+  float top_p, temperature;
+  unsigned seed;
+};
+
+#define SMP_MAXC 512
+#define SMP_BIG 8192
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+  __shared__ float lg[4352];
+  __shared__ unsigned hist[256];
+  __shared__ float cval_s[SMP_MAXC];
+  __shared__ int cidx_s[SMP_MAXC];
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // big path: [NS] values + [NS] indices
+  // candidate buffer: 512 static entries normally; the whole (padded) vocabulary when top_k is 0 or > 512
+  const bool big = a.top_k <= 0 || a.top_k > SMP_MAXC;
+  const int NS = big ? SMP_BIG : SMP_MAXC;
+  float* cval = big ? dyn_lds : cval_s;
+  int* cidx = big ? reinterpret_cast<int*>(dyn_lds + SMP_BIG) : cidx_s;
+  __shared__ float redf[8];
+  __shared__ int redi[8];
+  __shared__ unsigned s_prefix, s_need;
+  __shared__ int s_cnt, s_choice;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = a.len[b], lc = a.Lc[b];
+  const int j = L - lc;  // step index of this row
+  const int* row = a.seq + (long long)b * a.Lmax * 2;
+  const int last_pos = row[2 * (L - 1)];
+  const int cur_pos = row[2 * L];  // valid for tuple 1 (pos just sampled)
+  // next cond position > last_pos (representers.py:141-150), cond list + [end0+1]
+  int next_cond = a.end0 + 1;
+  if (a.tuple_i == 0 && a.mask_completion) {
+    int lo = 0, hi = lc;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (row[2 * mid] > last_pos) hi = mid; else lo = mid + 1; }
+    if (lo < lc) next_cond = row[2 * lo];
+  }
+  // ---- masked logits (sampling_masker) ------------------------------------------------------
+  float lmax = -INFINITY;
+  int amax = 0;
+  for (int v = tid; v < a.V; v += 256) {
+    float x = a.part[(long long)b * a.ldv + v];
+    for (int s = 1; s < a.S; ++s) x += a.part[((long long)s * a.M + b) * a.ldv + v];
+    if (a.tuple_i == 1) {
+      if (cur_pos == a.end0) x = (v == a.end1) ? 1.0f : -INFINITY;
+    } else {
+      if (a.mask_invalid && j > 0 && v <= last_pos && v != a.end0) x = -INFINITY;
+      if (a.mask_completion && v > next_cond) x = -INFINITY;
+    }
+    lg[v] = x;
+    if (a.hist) a.hist[((long long)b * a.max_steps + j) * a.V + v] = x;
+    if (x > lmax) { lmax = x; amax = v; }
+  }
+  // block argmax (lowest index on ties) + logsumexp
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(lmax, o, 64);
+    const int oi = __shfl_xor(amax, o, 64);
+    if (om > lmax || (om == lmax && oi < amax)) { lmax = om; amax = oi; }
+  }
+  if (lane == 0) { redf[wave] = lmax; redi[wave] = amax; }
+  __syncthreads();
+  float gmax = redf[0];
+  int gidx = redi[0];
+  for (int w = 1; w < 4; ++w)
+    if (redf[w] > gmax || (redf[w] == gmax && redi[w] < gidx)) { gmax = redf[w]; gidx = redi[w]; }
+  float se = 0.f;
+  for (int v = tid; v < a.V; v += 256) se += __expf(lg[v] - gmax);
+  se = wave_sum(se);
+  if (lane == 0) redf[4 + wave] = se;
+  __syncthreads();
+  const float lse = gmax + __logf((redf[4] + redf[5]) + (redf[6] + redf[7]));
+
+  int choice = gidx;
+  const bool greedy = (a.greedy_row0 && b == 0) || a.top_k == 1 || a.force != nullptr;
+  if (!greedy) {
+    // ---- top-k threshold by MSB-first radix select on order-preserving keys of lg/T ----------
+    const float invT = 1.0f / a.temperature;
+    int k = a.top_k > 0 ? min(a.top_k, a.V) : a.V;
+    if (tid == 0) { s_prefix = 0u; s_need = (unsigned)k; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      hist[tid] = 0u;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+      const unsigned pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int v = tid; v < a.V; v += 256) {
+        const unsigned key = fkey_u(lg[v] * invT);
+        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned need = s_need, bin = 255u;
+        for (int q = 255; q >= 0; --q) {
+          if (hist[q] >= need) { bin = (unsigned)q; break; }
+          need -= hist[q];
+        }
+        s_need = need;
+        s_prefix = prefix | (bin << shift);
+      }
+      __syncthreads();
+    }
+    const unsigned kth = s_prefix;  // key of the k-th largest value
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int v = tid; v < a.V; v += 256) {
+      const float x = lg[v] * invT;
+      if (x > -INFINITY && fkey_u(x) >= kth) {
+        const int slot = atomicAdd(&s_cnt, 1);
+        if (slot < NS) { cval[slot] = x; cidx[slot] = v; }
+      }
+    }
+    __syncthreads();
+    const int C = min(s_cnt, NS);
+    for (int i = tid; i < NS; i += 256)
+      if (i >= C) { cval[i] = -INFINITY; cidx[i] = 0x7fffffff; }
+    __syncthreads();
+    // bitonic sort of NS entries (value desc, index asc); each thread owns NS/512 compare-exchange pairs
+    for (int sz = 2; sz <= NS; sz <<= 1)
+      for (int st = sz >> 1; st > 0; st >>= 1) {
+        for (int pr = tid; pr < NS / 2; pr += 256) {
+          const int i = ((pr / st) * 2 * st) + (pr % st), p = i + st;
+          const bool up = (i & sz) == 0;
+          const float va = cval[i], vb = cval[p];
+          const int ia = cidx[i], ib = cidx[p];
+          const bool a_first = va > vb || (va == vb && ia < ib);
+          if (a_first != up) { cval[i] = vb; cval[p] = va; cidx[i] = ib; cidx[p] = ia; }
+        }
+        __syncthreads();
+      }
+    if (tid == 0) {
+      // top-p (common.py:271-284): drop sorted i>=1 where cumsum(softmax)[i-1] > p
+      const float m0 = cval[0];
+      int keep = C;
+      if (a.top_p > 0.f) {
+        float tot = 0.f;
+        for (int i = 0; i < C; ++i) tot += __expf(cval[i] - m0);
+        float cum = 0.f;
+        keep = 1;
+        for (int i = 0; i + 1 < C; ++i) {
+          cum += __expf(cval[i] - m0) / tot;
+          if (cum > a.top_p) break;
+          keep = i + 2;
+        }
+      }
+      // inverse-CDF draw (oracle/tokens_oracle.py:sample_filtered convention)
+      const float u = sf_uniform(a.seed, (unsigned)((j * 2 + a.tuple_i) * (int)gridDim.x + b));
+      float tot = 0.f;
+      for (int i = 0; i < keep; ++i) tot += __expf(cval[i] - m0);
+      const float thr = u * tot;
+      float cs = 0.f;
+      int pick = keep - 1;
+      for (int i = 0; i < keep; ++i) {
+        cs += __expf(cval[i] - m0);
+        if (cs > thr) { pick = i; break; }
+      }
+      s_choice = cidx[pick];
+    }
+    __syncthreads();
+    choice = s_choice;
+  }
+  if (a.force && j < a.max_steps) choice = a.force[((long long)b * a.max_steps + j) * 2 + a.tuple_i];
+  if (tid == 0) {
+    a.seq[((long long)b * a.Lmax + L) * 2 + a.tuple_i] = choice;
+    if (a.logp && j < a.max_steps) a.logp[((long long)b * a.max_steps + j) * 2 + a.tuple_i] = lg[choice] - lse;
+    if (a.advance) a.len[b] = L + 1;
+  }
+}
+
+__global__ void set_len_kernel(int* len, const int* src, int B, int delta) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) len[i] = src[i] + delta;
+}
+
+extern "C" {
+
+// host: Linear weight (N,K) row-major -> MFMA-fragment order [ceil(N/32)][K/8][64][4] (rows >= N zero)
+size_t sfmi_skinny_pack_floats(int N, int K) { return (size_t)((N + 31) / 32) * 32 * K; }
+int sfmi_skinny_pack_weight(const float* W, int N, int K, float* out) {
+  if (!W || !out || K % 8) return SFMI_EINVAL;
+  const int NT = (N + 31) / 32;
+  for (int nt = 0; nt < NT; ++nt)
+    for (int k8 = 0; k8 < K / 8; ++k8)
+      for (int l = 0; l < 64; ++l) {
+        const int n = nt * 32 + (l & 31);
+        for (int j = 0; j < 4; ++j) {
+          const int k = k8 * 8 + 4 * (l >> 5) + j;
+          out[(((size_t)nt * (K / 8) + k8) * 64 + l) * 4 + j] = n < N ? W[(size_t)n * K + k] : 0.0f;
+        }
+      }
+  return SFMI_OK;
+}
+
+// replaces nn.Linear at decode time (M <= 64 rows). out: (S,M,ldo) raw partials (epi 0) or final (epi 1/2, S==1).
+int sfmi_skinny_gemm_f32(const float* x, const float* Wp, const float* bias, float* out, int M, int N, int K, int S,
+                         int ldo, int epi, void* stream) {
+  if (!x || !Wp || !out || M <= 0 || M > 64 || S <= 0 || K % (8 * S) || (epi && (S != 1 || !bias))) return SFMI_EINVAL;
+  const int NT = (N + 31) / 32;
+  const int kslice = K / S;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(NT, S);
+  const int MT = M > 32 ? 2 : 1;
+  const int nw = (MT == 1 && kslice % 64 == 0 && kslice >= 512) ? 8 : 4;
+  if (kslice % (8 * nw)) return SFMI_EINVAL;
+  const size_t lds = (size_t)nw * MT * 16 * 64 * 4;
+  if (MT == 1 && nw == 4) hipLaunchKernelGGL((skinny_gemm_kernel<1, 4>), grid, dim3(256), lds, st, x, Wp, bias, out, M, N, K, kslice, ldo, epi);
+  else if (MT == 1) hipLaunchKernelGGL((skinny_gemm_kernel<1, 8>), grid, dim3(512), lds, st, x, Wp, bias, out, M, N, K, kslice, ldo, epi);
+  else hipLaunchKernelGGL((skinny_gemm_kernel<2, 4>), grid, dim3(256), lds, st, x, Wp, bias, out, M, N, K, kslice, ldo, epi);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// replaces get_embeddings (mingpt.py:256-286) + the AR_N extra index (representers.py:188-196,432-442)
+// (+ LayerNorm ln1 of the first block).  P == 0: one row per sequence at t = len[b]-1; P > 0: prefill rows (b,t<P).
+int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
+                       const int* seq, const int* len, const int* Lc, float* resid_out, float* xn, const float* gamma,
+                       const float* beta, int B, int P, int D, int Lmax, int end0, void* stream) {
+  if (!E0 || !E1 || !Ex || !pos_emb || !cond_pos_emb || !seq || !len || !Lc || D % 4 || D > 4096) return SFMI_EINVAL;
+  RowPrepArgs a = {};
+  a.E0 = E0; a.E1 = E1; a.Ex = Ex; a.pos_emb = pos_emb; a.cond_pos_emb = cond_pos_emb; a.seq = seq; a.len = len; a.Lc = Lc;
+  a.resid_out = resid_out; a.xn = xn; a.gamma = gamma; a.beta = beta; a.mode = 0; a.M = P ? B * P : B; a.D = D; a.Lmax = Lmax;
+  a.P = P; a.end0 = end0;
+  hipLaunchKernelGGL(rowprep_kernel, dim3(a.M), dim3(256), 0, (hipStream_t)stream, a);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// replaces the residual adds + LayerNorm of Block.forward (mingpt.py:107-111): x = resid + sum_s part[s] + bias
+// (+ tok_embs[0][next pos], mingpt.py:294) ; resid_out = x ; xn = LN(x)
+int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* bias, const float* Eadd, const int* seq,
+                         const int* len, const int* Lc, float* resid_out, float* xn, const float* gamma, const float* beta,
+                         int S, int M, int P, int D, int Lmax, void* stream) {
+  if (!resid_in || D % 4 || D > 4096 || (Eadd && (!seq || !len))) return SFMI_EINVAL;
+  RowPrepArgs a = {};
+  a.resid_in = resid_in; a.part = part; a.bias = bias; a.Eadd = Eadd; a.seq = seq; a.len = len; a.Lc = Lc;
+  a.resid_out = resid_out; a.xn = xn; a.gamma = gamma; a.beta = beta; a.mode = 1; a.S = S; a.M = M; a.D = D; a.Lmax = Lmax; a.P = P;
+  hipLaunchKernelGGL(rowprep_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, a);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// replaces CausalSelfAttention.forward for ONE new position per row with a KV cache (mingpt.py:73-91)
+int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc, float* Vc, const int* len, float* y,
+                             int S, int B, int D, int H, int Lmax, void* stream) {
+  if (!qkv_part || !bqkv || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
+  const int HD = D / H;
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, qkv_part, bqkv, Kc, Vc, len, y, S, B, D,
+                     Lmax, HD, 1.0f / sqrtf((float)HD));
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// causal self-attention over the conditioning prefix (positions 0..Lc[b]-2), also fills the KV caches
+int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* Lc, float* y, int B, int P, int D, int H,
+                              int Lmax, void* stream) {
+  if (!qkv || !Kc || !Vc || !Lc || !y || D / H != 64 || P <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(attn_prefill_kernel, dim3(B, H, (P + 63) / 64), dim3(256), 0, (hipStream_t)stream, qkv, Kc, Vc, Lc, y, P, D,
+                     Lmax, 0.125f);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// replaces sampling_masker + sample_logits for one tuple element (representers.py:120-155, common.py:260-299,
+// shapeformer.py:91-106); advance != 0 also appends the token (len += 1).
+int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, float* logp, float* hist, const int* force, int S, int B, int V,
+                        int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p, float temperature,
+                        int greedy_row0, int mask_invalid, int mask_completion, int max_steps, unsigned seed, int advance,
+                        void* stream) {
+  if (!part || !seq || !len || !Lc || V > 4352 || temperature <= 0.f) return SFMI_EINVAL;
+  SampleArgs a;
+  a.part = part; a.seq = seq; a.len = len; a.Lc = Lc; a.logp = logp; a.hist = hist; a.force = force; a.S = S; a.M = B; a.V = V; a.ldv = ldv;
+  a.Lmax = Lmax; a.tuple_i = tuple_i; a.end0 = end0; a.end1 = end1; a.top_k = top_k; a.greedy_row0 = greedy_row0;
+  a.mask_invalid = mask_invalid; a.mask_completion = mask_completion; a.max_steps = max_steps; a.advance = advance;
+  a.top_p = top_p; a.temperature = temperature; a.seed = seed;
+  const size_t dyn = (top_k <= 0 || top_k > SMP_MAXC) ? (size_t)SMP_BIG * 8 : 0;
+  hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), dyn, (hipStream_t)stream, a);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+int sfmi_set_len_i32(int* len, const int* src, int B, int delta, void* stream) {
+  if (!len || !src) return SFMI_EINVAL;
+  hipLaunchKernelGGL(set_len_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, len, src, B, delta);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""Host-side mirror of CondTupleGPT + ShapeFormer.sample_indices over libsfmi (HIP, gfx950).
+
+Mirrors shapeformer/models/shapeformer/transformer/mingpt.py:185-319 (state-dict key names, two-stage
+tuple head) and shapeformer/models/shapeformer/shapeformer.py:54-130 (`sample_indices` / `sample`),
+re-designed as prefill + KV-cached decode: every arithmetic step is a C-ABI call into libsfmi.so
+(csrc/gpt.hip, csrc/conv3d.hip:sfmi_gemm_f32); the decode step reads all per-row state from device
+memory and is captured once in a hipGraph (torch.cuda.CUDAGraph is only the capture/replay plumbing).
+
+Rows are ragged: each of the B sequences has its own condition length Lc[b]; row b reproduces what the
+reference computes for that shape alone at batch size 1 (its inference driver asserts batch_size == 1,
+shapeformer.py:227).  No CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import weights as W
+
+
+def _t(sd, k, dev):
+    v = sd[k]
+    if isinstance(v, np.ndarray):
+        v = torch.from_numpy(v)
+    return v.to(dev, torch.float32).contiguous()
+
+
+def pack_skinny(w: torch.Tensor) -> torch.Tensor:
+    """(N,K) row-major -> MFMA-fragment order [ceil(N/32)][K/8][64][4] (same as sfmi_skinny_pack_weight)."""
+    N, K = w.shape
+    NT = (N + 31) // 32
+    if NT * 32 != N:
+        w = torch.cat([w, w.new_zeros(NT * 32 - N, K)], 0)
+    return w.view(NT, 32, K // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+class _Layer:
+    pass
+
+
+class CondTupleGPT:
+    S_QKV, S_PROJ, S_FC2, S_HEAD = 4, 8, 8, 2
+
+    def __init__(self, state_dict=None, n_embd=1024, n_head=16, n_layers=(20, 4), block_size=812,
+                 vocab_sizes=(4097, 4097), extra_vocab_sizes=(4097,), end_tokens=(4096, 4096), device="cuda:0",
+                 tuple_n=2, **_ignored):
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise L.SfmiError("CondTupleGPT needs a HIP device (no CPU fallback)")
+        L.lib()
+        assert tuple_n == 2 and len(n_layers) == 2 and vocab_sizes[0] == vocab_sizes[1]
+        self.D, self.H, self.n_layers, self.Lmax = n_embd, n_head, tuple(n_layers), block_size
+        self.V, self.end = vocab_sizes[0], tuple(end_tokens)
+        self.Vpad = (self.V + 31) // 32 * 32
+        self.S_QKV, self.S_PROJ, self.S_HEAD = (self._splits(n_embd, s) for s in (self.S_QKV, self.S_PROJ, self.S_HEAD))
+        self.S_FC2 = self._splits(4 * n_embd, self.S_FC2)
+        sd = state_dict if state_dict is not None else self._hash_state_dict()
+        self.load_state_dict(sd)
+        self._state = None
+        self._graph = None
+
+    def get_block_size(self):
+        return self.Lmax
+
+    def _hash_state_dict(self):
+        spec = W.gpt_spec(self.D, self.n_layers, self.Lmax, (self.V, self.V), (self.V,))
+        return {k: W.make_tensor_torch(k, shp, self.dev) for k, shp in spec.items()}
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd):
+        dev = self.dev
+        g = lambda k: _t(sd, k, dev)
+        self.pos_emb = g("pos_emb").view(-1, self.D)
+        self.cond_pos_emb = g("cond_pos_emb").view(-1, self.D)
+        self.E = [g("tok_embs.0.weight"), g("tok_embs.1.weight")]
+        self.Ex = g("extra_tok_embs.0.weight")
+        self.layers = []
+        for s, nl in enumerate(self.n_layers):
+            for n in range(nl):
+                p = f"blocks.{s}.{n}."
+                ly = _Layer()
+                ly.ln1 = (g(p + "ln1.weight"), g(p + "ln1.bias"))
+                ly.ln2 = (g(p + "ln2.weight"), g(p + "ln2.bias"))
+                # fused QKV rows: [query | key | value] (csrc/gpt.hip attn kernels expect this order)
+                ly.wqkv = torch.cat([g(p + "attn.query.weight"), g(p + "attn.key.weight"), g(p + "attn.value.weight")], 0).contiguous()
+                ly.bqkv = torch.cat([g(p + "attn.query.bias"), g(p + "attn.key.bias"), g(p + "attn.value.bias")], 0).contiguous()
+                ly.wproj, ly.bproj = g(p + "attn.proj.weight"), g(p + "attn.proj.bias")
+                ly.wfc1, ly.bfc1 = g(p + "mlp.0.weight"), g(p + "mlp.0.bias")
+                ly.wfc2, ly.bfc2 = g(p + "mlp.2.weight"), g(p + "mlp.2.bias")
+                ly.pqkv, ly.pproj, ly.pfc1, ly.pfc2 = (pack_skinny(w) for w in (ly.wqkv, ly.wproj, ly.wfc1, ly.wfc2))
+                ly.stage = s
+                self.layers.append(ly)
+        self.head_ln = [(g(f"heads.{s}.0.weight"), g(f"heads.{s}.0.bias")) for s in range(2)]
+        self.head_w = [g(f"heads.{s}.1.weight") for s in range(2)]
+        self.head_p = [pack_skinny(w) for w in self.head_w]
+
+    # ------------------------------------------------------------------ state
+    def _alloc(self, B, max_steps):
+        key = (B, max_steps)
+        if self._state is not None and self._state["key"] == key:
+            return self._state
+        dev, D = self.dev, self.D
+        f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        st = dict(key=key,
+                  seq=torch.zeros(B, self.Lmax + 1, 2, device=dev, dtype=torch.int32),
+                  len=torch.zeros(B, device=dev, dtype=torch.int32), Lc=torch.zeros(B, device=dev, dtype=torch.int32),
+                  resid=f(B, D), xn=f(B, D), qkv=f(self.S_QKV, B, 3 * D), y=f(B, D), proj=f(self.S_PROJ, B, D),
+                  h=f(B, 4 * D), fc2=f(self.S_FC2, B, D), logit=f(self.S_HEAD, B, self.Vpad),
+                  Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
+                  logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32))
+        self._state = st
+        self._graph = None
+        return st
+
+    # ------------------------------------------------------------------ C-ABI wrappers
+    @staticmethod
+    def _splits(K, S):
+        while S > 1 and (K // S) % 32:
+            S //= 2
+        return S
+
+    def _skinny(self, x, wp, bias, out, M, N, K, S, ldo, epi):
+        L.check(L.lib().sfmi_skinny_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), M, N, K, S, ldo, epi,
+                                             L.stream_ptr()), "sfmi_skinny_gemm_f32")
+
+    def _rowprep(self, resid_in, part, bias, S, M, resid_out, xn, ln, Eadd=None, P=0, st=None):
+        L.check(L.lib().sfmi_gpt_rowprep_f32(L.ptr(resid_in), L.ptr(part), L.ptr(bias), L.ptr(Eadd),
+                                             L.ptr(st["seq"]) if st else None, L.ptr(st["len"]) if st else None,
+                                             L.ptr(st["Lc"]) if st else None, L.ptr(resid_out), L.ptr(xn),
+                                             L.ptr(ln[0]) if ln else None, L.ptr(ln[1]) if ln else None, S, M, P, self.D,
+                                             self.Lmax + 1, L.stream_ptr()), "sfmi_gpt_rowprep_f32")
+
+    def _embed(self, st, B, P, resid, xn, ln):
+        L.check(L.lib().sfmi_gpt_embed_f32(L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb),
+                                           L.ptr(self.cond_pos_emb), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
+                                           L.ptr(resid), L.ptr(xn), L.ptr(ln[0]), L.ptr(ln[1]), B, P, self.D, self.Lmax + 1,
+                                           self.end[0], L.stream_ptr()), "sfmi_gpt_embed_f32")
+
+    def _gemm(self, x, w, bias, resid, y, M, N, K, act=0, og=0, ogs=0):
+        L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, og, ogs,
+                                      L.stream_ptr()), "sfmi_gemm_f32")
+
+    # ------------------------------------------------------------------ prefill (positions 0..Lc[b]-2)
+    def prefill(self, st, B, P):
+        D, dev = self.D, self.dev
+        M = B * P
+        f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        resid, xn, qkv, y, h = f(M, D), f(M, D), f(M, 3 * D), f(M, D), f(M, 4 * D)
+        self._embed(st, B, P, resid, xn, self.layers[0].ln1)
+        for li, ly in enumerate(self.layers):
+            self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
+            L.check(L.lib().sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]), L.ptr(st["Lc"]),
+                                                      L.ptr(y), B, P, D, self.H, self.Lmax + 1, L.stream_ptr()), "attn_prefill")
+            self._gemm(y, ly.wproj, ly.bproj, resid, resid, M, D, D)
+            self._rowprep(resid, None, None, 0, M, None, xn, ly.ln2)
+            self._gemm(xn, ly.wfc1, ly.bfc1, None, h, M, 4 * D, D, act=2)
+            self._gemm(h, ly.wfc2, ly.bfc2, resid, resid, M, D, 4 * D)
+            nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
+            if nxt is None:
+                break
+            if nxt.stage != ly.stage:   # stage boundary: x += tok_embs[0][next pos] (mingpt.py:294)
+                self._rowprep(resid, None, None, 0, M, resid, xn, nxt.ln1, Eadd=self.E[0], P=P, st=st)
+            else:
+                self._rowprep(resid, None, None, 0, M, None, xn, nxt.ln1)
+
+    # ------------------------------------------------------------------ one decode step (graph-capturable)
+    def decode_step(self, st, B, sp):
+        D = self.D
+        lib = L.lib()
+        self._embed(st, B, 0, st["resid"], st["xn"], self.layers[0].ln1)
+        for li, ly in enumerate(self.layers):
+            self._skinny(st["xn"], ly.pqkv, None, st["qkv"], B, 3 * D, D, self.S_QKV, 3 * D, 0)
+            L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(ly.bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
+                                                 L.ptr(st["len"]), L.ptr(st["y"]), self.S_QKV, B, D, self.H, self.Lmax + 1,
+                                                 L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
+            self._skinny(st["y"], ly.pproj, None, st["proj"], B, D, D, self.S_PROJ, D, 0)
+            self._rowprep(st["resid"], st["proj"], ly.bproj, self.S_PROJ, B, st["resid"], st["xn"], ly.ln2)
+            self._skinny(st["xn"], ly.pfc1, ly.bfc1, st["h"], B, 4 * D, D, 1, 4 * D, 1)
+            self._skinny(st["h"], ly.pfc2, None, st["fc2"], B, D, 4 * D, self.S_FC2, D, 0)
+            last_of_stage = li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage
+            ln_next = self.head_ln[ly.stage] if last_of_stage else self.layers[li + 1].ln1
+            self._rowprep(st["resid"], st["fc2"], ly.bfc2, self.S_FC2, B, st["resid"], st["xn"], ln_next)
+            if last_of_stage:
+                s = ly.stage
+                self._skinny(st["xn"], self.head_p[s], None, st["logit"], B, self.V, D, self.S_HEAD, self.Vpad, 0)
+                hist = sp["hist"][s] if sp.get("hist") is not None else None
+                L.check(lib.sfmi_gpt_sample_f32(L.ptr(st["logit"]), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
+                                                L.ptr(st["logp"]), L.ptr(hist), L.ptr(sp.get("force")), self.S_HEAD, B, self.V, self.Vpad, self.Lmax + 1,
+                                                s, self.end[0], self.end[1], sp["top_k"], sp["top_p"], sp["temperature"],
+                                                int(sp["best_in_first"]), int(sp["mask_invalid"]),
+                                                int(sp["mask_invalid_completion"]), sp["max_steps"], sp["seed"], int(s == 1),
+                                                L.stream_ptr()), "sfmi_gpt_sample_f32")
+                if s == 0:
+                    self._rowprep(st["resid"], None, None, 0, B, st["resid"], st["xn"], self.layers[li + 1].ln1,
+                                  Eadd=self.E[0], st=st)
+
+    # ------------------------------------------------------------------ sample_indices
+    @torch.no_grad()
+    def sample(self, c_tokens, Lc, max_steps=512, top_k=100, top_p=0.4, temperature=1.0, best_in_first=True,
+               mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True, use_graph=True,
+               return_logits=False, check_every=32, force_tokens=None):
+        """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32.
+
+        Returns dict(samples (B,steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
+        Mirrors ShapeFormer.sample_indices (shapeformer.py:54-123); torch.multinomial is replaced by an
+        inverse-CDF draw on counter-hash uniforms (oracle/gpt_oracle.py:uniforms)."""
+        B = c_tokens.shape[0]
+        if B > 64:
+            raise L.SfmiError("decode kernels support up to 64 rows per call")
+        Lc_host = Lc.cpu().tolist()
+        Lc_max = max(Lc_host)
+        steps = min(max_steps, self.Lmax - Lc_max)   # never exceed block_size (stop, don't crop)
+        st = self._alloc(B, max_steps)
+        st["seq"].zero_()
+        st["seq"][:, :c_tokens.shape[1]] = c_tokens.to(self.dev, torch.int32)
+        st["Lc"].copy_(Lc.to(self.dev, torch.int32))
+        st["len"].copy_(st["Lc"])
+        st["logp"].zero_()
+        hist = None
+        if return_logits:
+            hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
+        sp = dict(top_k=int(top_k), top_p=float(top_p), temperature=float(temperature), best_in_first=best_in_first,
+                  mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion, max_steps=int(max_steps),
+                  seed=W._fnv1a32(f"sample-uniforms-{seed}"), hist=hist)
+        if force_tokens is not None:   # (B,max_steps,2) teacher forcing for stepwise parity tests
+            ft = torch.zeros(B, max_steps, 2, dtype=torch.int32)
+            ft[:, :force_tokens.shape[1]] = torch.as_tensor(force_tokens).to(torch.int32)
+            sp["force"] = ft.to(self.dev)
+            use_graph = False
+        P = Lc_max - 1
+        if P > 0:
+            self.prefill(st, B, P)
+        done = 0
+        if use_graph and steps > 1:
+            gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force"))), return_logits)
+            if self._graph is None or self._graph[0] != gkey or return_logits:
+                side = torch.cuda.Stream(device=self.dev)
+                side.wait_stream(torch.cuda.current_stream())
+                saved = {k: st[k].clone() for k in ("seq", "len", "logp")}
+                with torch.cuda.stream(side):
+                    self.decode_step(st, B, sp)      # warm-up outside capture
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                for k, v in saved.items():
+                    st[k].copy_(v)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.decode_step(st, B, sp)
+                for k, v in saved.items():           # capture does not execute, but keep state pristine
+                    st[k].copy_(v)
+                self._graph = (gkey, g)
+            g = self._graph[1]
+            while done < steps:
+                n = min(check_every, steps - done) if stop_early else steps - done
+                for _ in range(n):
+                    g.replay()
+                done += n
+                if stop_early and self._all_ended(st, B):
+                    break
+        else:
+            while done < steps:
+                self.decode_step(st, B, sp)
+                done += 1
+                if stop_early and done % check_every == 0 and self._all_ended(st, B):
+                    break
+        ln = st["len"].cpu().tolist()
+        nsteps = max(l - c for l, c in zip(ln, Lc_host))
+        out = torch.full((B, nsteps, 2), 0, dtype=torch.int64)
+        seq = st["seq"].cpu()
+        for b in range(B):
+            out[b] = seq[b, Lc_host[b]:Lc_host[b] + nsteps].long()
+        res = dict(samples=out, log_prob=st["logp"][:, :nsteps].cpu(), steps=nsteps)
+        if return_logits:
+            res["logits_history"] = [h[:, :nsteps].cpu() for h in hist]
+        return res
+
+    def _all_ended(self, st, B):
+        seq, ln = st["seq"], st["len"].long()
+        last = seq[torch.arange(B, device=self.dev), ln - 1].long()
+        end = torch.tensor(self.end, device=self.dev)
+        return bool((last == end).any(-1).all().item())   # shapeformer.py:112-115

@@ -224,3 +224,46 @@ def gpt_spec(n_embd=1024, n_layers=(20, 4), block_size=812, vocab_sizes=(4097, 4
 def make_state_dict(spec, prefix: str = "") -> "OrderedDict[str, np.ndarray]":
     """Generate every tensor of `spec`; the hash key is the un-prefixed name."""
     return OrderedDict((prefix + k, make_tensor(k, shp)) for k, shp in spec.items())
+
+
+# --------------------------------------------------------------------------
+# same generator on a torch device (bit-identical to the numpy path; used so the
+# 325 M-parameter transformer can be materialised on the GPU in milliseconds)
+# --------------------------------------------------------------------------
+def hash_unit_torch(key: str, n: int, device):
+    import torch
+    M = 0xFFFFFFFF
+    h = torch.arange(n, dtype=torch.int64, device=device)
+    h = (h * 0x9E3779B1 + _fnv1a32(key)) & M
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & M
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & M
+    h = h ^ (h >> 16)
+    return (h >> 8).to(torch.float32) * (1.0 / (1 << 24))
+
+
+def make_tensor_torch(key: str, shape, device):
+    import torch
+    shape = tuple(int(s) for s in shape)
+    kind = _kind(key, shape)
+    n = int(np.prod(shape)) if len(shape) else 1
+    if kind in ("tril", "zeros"):
+        return torch.from_numpy(make_tensor(key, shape)).to(device)
+
+    def uni(k, lo, hi):
+        u = hash_unit_torch(k, n, device)
+        lo32, d32 = np.float32(lo), np.float32(hi - lo)
+        return (float(lo32) + u * float(d32)).reshape(shape)
+
+    if kind == "norm_w":
+        return uni(key, 0.9, 1.1)
+    if kind in ("norm_b", "bias"):
+        return uni(key, -0.1, 0.1)
+    if kind == "emb":
+        return uni(key.replace("z_avg", "embedding.weight"), -1.0, 1.0)
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+    s = math.sqrt(3.0 / fan_in)
+    if kind == "head":
+        s *= 4.0
+    return uni(key, -s, s)
