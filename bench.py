@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — shapes/sec completed (VQDIF-16 encode + 512-step AR sample + 128^3 SDF extract) on MI355X.
+
+One "step" = one batch of `--batch` synthetic partial clouds taken through the whole hot path
+(SURVEY.md §8(d) unit of work): encode 16384-point partial cloud -> (pos,code) tokens -> prefill +
+512 KV-cached decode steps of the 20+4-layer d=1024 CondTupleGPT (early exit disabled) -> dense code
+grid -> UNet3D + Upsampler -> fused SDF query on the 128^3 lattice -> sigmoid occupancy.
+Inputs are resident in HBM before the timed region; weights are hash-generated (no checkpoints ship).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: shapes are independent -> each rank processes its own batch, no data-path collective
+("weak" scaling); only the timing barrier / max-over-ranks uses RCCL.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="shapes per GPU per step (BASELINE config: batch 16)")
+    ap.add_argument("--ar-steps", type=int, default=512)
+    ap.add_argument("--decode-res", type=int, default=128)
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def ev_time(fn, n, warm=2):
+    """Average ms per call measured with HIP events on the stream the kernels are launched on."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def kernel_rooflines(vq, gpt, B, dev):
+    """Per-kernel live timings (HIP events) at the bench shapes + algorithmic bytes/flops."""
+    from shapeformer_amd import ops
+    out = []
+    D = gpt.D
+    st = gpt._alloc(B, 512)
+    ly = gpt.layers[0]
+    HBM, F32 = 8000.0, 157.3  # GB/s, TFLOP/s peaks (MI355X_MICROARCH.md)
+
+    def add(name, ms, bound, alg, unit_scale, peak, unit, note):
+        ach = alg / (ms * 1e-3) / unit_scale
+        out.append(dict(kernel=name, bound=bound, ms=round(ms, 5), achieved=round(ach, 2), peak=peak, unit=unit,
+                        frac=round(ach / peak, 4), note=note))
+
+    # decode-step weight streaming GEMMs (dominant by time): bytes = N*K*4 weights + M*K*4 x + S*M*N*4 partials
+    for nm, wp, bias, outb, N, K, S, ldo, epi in (
+            ("skinny_gemm fc1 (1024->4096,+GELU)", ly.pfc1, ly.bfc1, st["h"], 4 * D, D, 1, 4 * D, 1),
+            ("skinny_gemm fc2 (4096->1024)", ly.pfc2, None, st["fc2"], D, 4 * D, gpt.S_FC2, D, 0),
+            ("skinny_gemm qkv (1024->3072)", ly.pqkv, None, st["qkv"], 3 * D, D, gpt.S_QKV, 3 * D, 0),
+            ("skinny_gemm proj (1024->1024)", ly.pproj, None, st["proj"], D, D, gpt.S_PROJ, D, 0)):
+        x = st["h"] if K == 4 * D else st["xn"]
+        # rotate over the 24 layers' weights so the 256 MB Infinity Cache cannot serve them (as in the real step)
+        ws = [getattr(l, {"fc1": "pfc1", "fc2": "pfc2", "qkv": "pqkv", "pro": "pproj"}[nm.split()[1][:3]]) for l in gpt.layers]
+        it = [0]
+
+        def f():
+            w = ws[it[0] % len(ws)]
+            it[0] += 1
+            gpt._skinny(x, w, bias, outb, B, N, K, S, ldo, epi)
+        ms = ev_time(f, 48)
+        add(nm, ms, "hbm", N * K * 4 + B * K * 4 + S * B * N * 4, 1e9, HBM, "GB/s", f"M={B}, split-K {S}")
+    # SDF query (north-star kernel): MFMA-bound, 31 488 FLOP/pt
+    Q = 128
+    grid = torch.randn(B, 64, 64, 64, 32, device=dev)
+    axis = torch.linspace(-1, 1, Q, device=dev)
+    o = torch.empty(B, Q ** 3, 1, device=dev)
+    ms = ev_time(lambda: ops.sdf_query_grid(axis, grid, vq.sdf_w, sigmoid=True, out=o), 5)
+    add("sdf_query_kernel<grid> 128^3", ms, "mfma", B * Q ** 3 * 31488, 1e12, F32, "TFLOP/s",
+        f"{B}x128^3 pts; algorithmic HBM {(B * Q ** 3 * 4 + B * 33.55e6) / (ms * 1e-3) / 1e9:.0f} GB/s")
+    del grid, o
+    return out
+
+
+def cpu_baseline(points, ar_steps, decode_res):
+    """Oracle (CPU restatement pinned to the reference) timed on the host cores, bounded sample (~10-30 s)."""
+    from oracle import gpt_oracle as GO, tokens_oracle as TO, vqdif_oracle as VO
+    from shapeformer_amd import synthetic, weights as W
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sdv = VO.to_torch_sd(W.make_state_dict(W.vqdif_spec(16)))
+    X = torch.from_numpy(synthetic.make_batch(314, 1, n_partial=points)["Xct"])
+    with torch.no_grad():
+        t = time.time(); q, mode, enc = VO.quantize_cloud(sdv, X); t_enc = time.time() - t
+        tok, m2 = TO.batch_dense2sparse(q.numpy(), 406, (4096, 4096))
+        Lc = tok.shape[1]
+        t = time.time(); grid = VO.decoder_grid(sdv, VO.get_code(sdv, q)); t_grid = time.time() - t
+        nq = 128 ** 3 // 8  # 1/8 of the 128^3 lattice, scaled up
+        pts = torch.from_numpy(VO.make_grid(decode_res))[None, :nq]
+        t = time.time(); VO.sdf_query(sdv, grid, pts); t_sdf = (time.time() - t) * (decode_res ** 3 / nq)
+        # AR sampling in the reference's formulation (full-prefix recompute, shapeformer.py:86-89): time one step at
+        # three prefix lengths and integrate over the 512 steps (a full run is ~minutes/sequence on CPU)
+        spec = W.gpt_spec()
+        sdg = {k: torch.from_numpy(W.make_tensor(k, s)) for k, s in spec.items()}
+        cfg = GO.GPTCfg()
+        ts = []
+        Ls = [Lc, Lc + ar_steps // 2, min(Lc + ar_steps - 1, 811)]
+        for Lp in Ls:
+            idx = torch.randint(0, 4096, (1, Lp, 2))
+            ex = torch.randint(0, 4096, (1, Lp, 1))
+            t = time.time(); GO.forward_logits(sdg, cfg, idx, ex, Lc, idx); ts.append(time.time() - t)
+        # trapezoid over steps
+        t_ar = (ts[0] + ts[1]) / 2 * (ar_steps / 2) + (ts[1] + ts[2]) / 2 * (ar_steps / 2)
+    total = t_enc + t_ar + t_grid + t_sdf
+    return dict(value=round(1.0 / total, 6), unit="shapes/s", cores=cores, kind="port",
+                sample=(f"oracle (torch-CPU fp32 restatement pinned to the reference), 1 shape: encode {t_enc:.2f}s + "
+                        f"UNet/upsample {t_grid:.2f}s + 1/8 of the 128^3 SDF query scaled ({t_sdf:.2f}s) + no-KV-cache AR "
+                        f"step timed at L={Ls} ({ts[0]:.2f}/{ts[1]:.2f}/{ts[2]:.2f}s) integrated over {ar_steps} steps "
+                        f"({t_ar:.0f}s)"))
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from shapeformer_amd import synthetic
+    from shapeformer_amd.gpt import CondTupleGPT
+    from shapeformer_amd.pipeline import ShapeCompletion
+    from shapeformer_amd.vqdif import VQDIF
+
+    vq = VQDIF(res=16, device=dev)
+    gpt = CondTupleGPT(device=dev)
+    pipe = ShapeCompletion(vq, gpt)
+    B = a.batch
+    Xct = torch.from_numpy(synthetic.make_batch(314 + rank * B, B, n_partial=a.points)["Xct"]).to(dev)
+
+    def step(i):
+        return pipe.complete(Xct, max_steps=a.ar_steps, decode_res=a.decode_res, seed=i, stop_early=False, sigmoid=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        r = step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        r = step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    occ = r["occupancy"]
+    sanity = dict(ar_steps_done=int(r["steps"]), occ_mean=round(float(occ.mean().item()), 4),
+                  Lc_mean=round(float(r["Lc"].float().mean().item()), 1))
+
+    if rank == 0:
+        line = {
+            "metric": "shapes/sec completed (64^3 VQDIF + 512-tok AR sample + 128^3 SDF extract)",
+            "value": round(world * B * a.steps / dt, 4), "unit": "shapes/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"shape completion, {B} shapes/GPU/step: VQDIF-16 encode of {a.points}-pt partial cloud -> "
+                                    f"tokens -> CondTupleGPT 20+4 layers d1024 prefill + {a.ar_steps} KV-cached decode steps "
+                                    f"(top_k 100, top_p 0.4, early exit off) -> UNet3D+Upsampler -> {a.decode_res}^3 SDF query"),
+                       "batch_per_gpu": B, "ar_steps": a.ar_steps, "decode_res": a.decode_res, "parallelism": f"shard{world}",
+                       "weights": "hash-generated (no checkpoints ship)"},
+            "sanity": sanity,
+        }
+        if not a.no_roofline:
+            ks = kernel_rooflines(vq, gpt, B, dev)
+            dom = ks[0]  # fc1 skinny GEMM: largest single weight stream of the decode step (see DESIGN.md / profiles/)
+            line["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                                "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"]}
+            line["kernels"] = ks
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.points, a.ar_steps, a.decode_res)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

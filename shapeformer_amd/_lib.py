@@ -44,10 +44,10 @@ PROTOTYPES = {
     "sfmi_vq_argmin_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr]),
     "sfmi_vq_gather_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, c_ptr]),
     # tokens
-    "sfmi_mode_i32": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr]),
-    "sfmi_apply_mask_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr]),
-    "sfmi_dense2sparse_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, i32, i32, i32, c_ptr]),
-    "sfmi_sparse2dense_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, i32, i32, c_ptr]),
+    "sfmi_mode_i32": (i32, [c_ptr, i64, i32, i32, c_ptr, c_ptr, c_ptr]),
+    "sfmi_apply_mask_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, c_ptr]),
+    "sfmi_dense2sparse_i32": (i32, [c_ptr, c_ptr, i32, c_ptr, c_ptr, i32, i32, i32, i32, i32, i32, c_ptr]),
+    "sfmi_sparse2dense_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, c_ptr, i32, i32, i32, i32, i32, c_ptr]),
     # transformer
     "sfmi_gemm_f32": (i32, [c_ptr] * 5 + [i64, i32, i32, i32, i64, i64, c_ptr]),
     "sfmi_skinny_pack_floats": (sz, [i32, i32]),

@@ -6,17 +6,20 @@
 // tokens, so no host sync is needed to size tensors (the reference syncs to build (B,Lmax+1,2)).
 #include "sfmi_common.h"
 
-__global__ void hist_kernel(const int* __restrict__ idx, int* __restrict__ hist, long long n, int K) {
+// rows > 1: one histogram per row of n/rows elements (per-shape mode, the reference's batch-1 inference)
+__global__ void hist_kernel(const int* __restrict__ idx, int* __restrict__ hist, long long n, int K, long long per_row) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     int v = idx[i];
-    if (v >= 0 && v < K) atomicAdd(&hist[v], 1);
+    if (v >= 0 && v < K) atomicAdd(&hist[(i / per_row) * K + v], 1);
   }
 }
 
 // most frequent value, smallest on ties (torch.unique+argmax / torch.mode semantics)
-__global__ __launch_bounds__(256) void mode_select_kernel(const int* __restrict__ hist, int K, int* __restrict__ mode) {
+__global__ __launch_bounds__(256) void mode_select_kernel(const int* __restrict__ hist_all, int K, int* __restrict__ mode_all) {
   __shared__ int sc[256], sv[256];
+  const int* hist = hist_all + (long long)blockIdx.x * K;
+  int* mode = mode_all + blockIdx.x;
   int bc = -1, bv = 0;
   for (int v = threadIdx.x; v < K; v += 256) {
     int c = hist[v];
@@ -36,19 +39,20 @@ __global__ __launch_bounds__(256) void mode_select_kernel(const int* __restrict_
 
 // vqdif.py:54-57: quant_ind = mode everywhere, raw index inside the occupancy mask
 __global__ void apply_mask_kernel(const int* __restrict__ idx, const unsigned char* __restrict__ mask,
-                                  const int* __restrict__ mode, int* __restrict__ out, long long n) {
+                                  const int* __restrict__ mode, int* __restrict__ out, long long n, long long per_row) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = mask[i] ? idx[i] : *mode;
+  if (i < n) out[i] = mask[i] ? idx[i] : mode[i / per_row];
 }
 
 // common.py:151-168 + 84-123: row b = all cells != mode in ascending pos, then the end-token pair.
 __global__ __launch_bounds__(256) void dense2sparse_kernel(const int* __restrict__ q, const int* __restrict__ mode_p,
                                                            int* __restrict__ tokens /*(B,Lpad,2)*/, int* __restrict__ len,
-                                                           int ncell, int Lpad, int max_length, int end0, int end1) {
+                                                           int ncell, int Lpad, int max_length, int end0, int end1,
+                                                           int mode_stride) {
   __shared__ int wsum[4];
   __shared__ int base;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mode = *mode_p;
+  const int mode = mode_p[b * mode_stride];
   const int keep_max = max_length - 1;  // room for the forced end token (common.py:118-122)
   int* row = tokens + (long long)b * Lpad * 2;
   for (int i = tid; i < Lpad; i += 256) { row[2 * i] = end0; row[2 * i + 1] = end1; }
@@ -81,14 +85,16 @@ __global__ __launch_bounds__(256) void dense2sparse_kernel(const int* __restrict
 
 // common.py:126-140 + 171-189: drop rows where ANY... no: keep rows where BOTH elements differ from their
 // end token; dense filled with *empty, dense[b][pos] = val.
-__global__ void sparse2dense_kernel(const int* __restrict__ tokens, const int* __restrict__ len, const int* __restrict__ empty_p,
-                                    int* __restrict__ dense, int ncell, int Lpad, int end0, int end1) {
+__global__ void sparse2dense_kernel(const int* __restrict__ tokens, const int* __restrict__ start, const int* __restrict__ len,
+                                    const int* __restrict__ empty_p, int* __restrict__ dense, int ncell, int Lpad, int end0,
+                                    int end1, int empty_stride) {
   const int b = blockIdx.x;
-  const int empty = *empty_p;
+  const int empty = empty_p[b * empty_stride];
   for (int i = threadIdx.x; i < ncell; i += blockDim.x) dense[(long long)b * ncell + i] = empty;
   __syncthreads();
+  const int r0 = start ? start[b] : 0;
   const int n = len ? min(len[b], Lpad) : Lpad;
-  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+  for (int r = r0 + threadIdx.x; r < n; r += blockDim.x) {
     const int pos = tokens[((long long)b * Lpad + r) * 2], val = tokens[((long long)b * Lpad + r) * 2 + 1];
     if (pos != end0 && val != end1 && pos >= 0 && pos < ncell) dense[(long long)b * ncell + pos] = val;
   }
@@ -97,39 +103,45 @@ __global__ void sparse2dense_kernel(const int* __restrict__ tokens, const int* _
 extern "C" {
 
 // replaces pth_get_mode / torch.mode (common.py:20-23,155). hist: K ints of workspace.
-int sfmi_mode_i32(const int* idx, long long n, int K, int* hist, int* mode_out, void* stream) {
-  if (!idx || !hist || !mode_out || n <= 0 || K <= 0) return SFMI_EINVAL;
+// rows == 1: whole-tensor mode (vqdif.py:53 / common.py:155); rows > 1: one mode per row of n/rows elements.
+// hist: rows*K ints of workspace; mode_out: rows ints.
+int sfmi_mode_i32(const int* idx, long long n, int K, int rows, int* hist, int* mode_out, void* stream) {
+  if (!idx || !hist || !mode_out || n <= 0 || K <= 0 || rows <= 0 || n % rows) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(hist, 0, (size_t)K * 4, st);
-  hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, hist, n, K);
-  hipLaunchKernelGGL(mode_select_kernel, dim3(1), dim3(256), 0, st, hist, K, mode_out);
+  hipMemsetAsync(hist, 0, (size_t)K * rows * 4, st);
+  hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, hist, n, K, n / rows);
+  hipLaunchKernelGGL(mode_select_kernel, dim3(rows), dim3(256), 0, st, hist, K, mode_out);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
 
 // replaces vqdif.py:54-57
-int sfmi_apply_mask_i32(const int* idx, const unsigned char* mask, const int* mode, int* out, long long n, void* stream) {
-  if (!idx || !mask || !mode || !out || n <= 0) return SFMI_EINVAL;
-  hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, mask, mode, out, n);
+int sfmi_apply_mask_i32(const int* idx, const unsigned char* mask, const int* mode, int* out, long long n, int mode_rows,
+                        void* stream) {
+  if (!idx || !mask || !mode || !out || n <= 0 || mode_rows <= 0 || n % mode_rows) return SFMI_EINVAL;
+  hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, mask, mode, out, n,
+                     n / mode_rows);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
 
 // replaces batch_dense2sparse/unpack_sparse (common.py:84-123,151-168), ragged rows (see header)
-int sfmi_dense2sparse_i32(const int* q, const int* mode, int* tokens, int* len, int B, int ncell, int Lpad,
+int sfmi_dense2sparse_i32(const int* q, const int* mode, int mode_per_row, int* tokens, int* len, int B, int ncell, int Lpad,
                           int max_length, int end0, int end1, void* stream) {
   if (!q || !mode || !tokens || !len || B <= 0 || ncell <= 0 || Lpad <= 0 || max_length <= 0) return SFMI_EINVAL;
   hipLaunchKernelGGL(dense2sparse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, mode, tokens, len, ncell, Lpad,
-                     max_length, end0, end1);
+                     max_length, end0, end1, mode_per_row ? 1 : 0);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
 
 // replaces pack_sparse + batch_sparse2dense (common.py:126-140,171-189); len may be NULL (use all Lpad rows)
-int sfmi_sparse2dense_i32(const int* tokens, const int* len, const int* empty, int* dense, int B, int ncell, int Lpad,
-                          int end0, int end1, void* stream) {
+// rows r in [start[b] (or 0), len[b] (or Lpad)) of row b are scattered; empty: scalar or per-row.
+int sfmi_sparse2dense_i32(const int* tokens, const int* start, const int* len, const int* empty, int empty_per_row, int* dense,
+                          int B, int ncell, int Lpad, int end0, int end1, void* stream) {
   if (!tokens || !empty || !dense || B <= 0 || ncell <= 0 || Lpad <= 0) return SFMI_EINVAL;
-  hipLaunchKernelGGL(sparse2dense_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, len, empty, dense, ncell, Lpad, end0, end1);
+  hipLaunchKernelGGL(sparse2dense_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, start, len, empty, dense, ncell, Lpad,
+                     end0, end1, empty_per_row ? 1 : 0);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

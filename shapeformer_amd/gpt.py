@@ -199,7 +199,7 @@ class CondTupleGPT:
     @torch.no_grad()
     def sample(self, c_tokens, Lc, max_steps=512, top_k=100, top_p=0.4, temperature=1.0, best_in_first=True,
                mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True, use_graph=True,
-               return_logits=False, check_every=32, force_tokens=None):
+               return_logits=False, check_every=32, force_tokens=None, to_host=True):
         """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32.
 
         Returns dict(samples (B,steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
@@ -264,6 +264,8 @@ class CondTupleGPT:
                 done += 1
                 if stop_early and done % check_every == 0 and self._all_ended(st, B):
                     break
+        if not to_host:   # device-resident result for the completion pipeline (no D2H of tokens)
+            return dict(state=st, steps=done)
         ln = st["len"].cpu().tolist()
         nsteps = max(l - c for l, c in zip(ln, Lc_host))
         out = torch.full((B, nsteps, 2), 0, dtype=torch.int64)

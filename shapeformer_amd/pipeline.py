@@ -1,0 +1,53 @@
+"""Shape-completion driver: partial cloud -> VQDIF tokens -> AR sampling -> dense code grid -> occupancy.
+
+The compute half of the reference's inference drivers, as plain functions returning the same dict keys:
+`VisShapeFormer.compute_batch` + `vis_ind`/`decode_sample_indices` (shapeformer.py:222-260,332-391) and
+`VisSparseRecon3D.compute_batch` (vqdif.py:243-269).  Rendering / mesh IO are out of scope (SURVEY §8 f).
+Everything stays on the device between stages; every stage is a libsfmi (HIP) call.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import tokens as T
+
+
+class ShapeCompletion:
+    def __init__(self, vq, gpt, voxel_res=16, block_size=812, end_tokens=(4096, 4096)):
+        self.vq, self.gpt = vq, gpt
+        self.R, self.end = voxel_res, tuple(end_tokens)
+        self.max_length = block_size // 2  # representers.py:65
+
+    @torch.no_grad()
+    def encode_cloud(self, cloud):
+        """ShapeRepresenter.encode_cloud (representers.py:69-77), one empty code per shape (batch-1 semantics)."""
+        q, mode, raw, mask, latent = self.vq.quantize_cloud_dev(cloud, per_shape_mode=True)
+        B = q.shape[0]
+        mode2 = T.mode_i32(q, self.vq.K + 1, rows=B)  # batch_dense2sparse recomputes the mode (common.py:155)
+        tok, ln = T.dense2sparse_dev(q, mode2, self.max_length, self.end, Lpad=self.max_length)
+        return dict(quant_ind=q, empty_index=mode2, c_tokens=tok, Lc=ln, grid_mask=mask)
+
+    @torch.no_grad()
+    def complete(self, Xct, max_steps=512, decode_res=128, top_k=100, top_p=0.4, temperature=1.0, seed=0,
+                 best_in_first=False, stop_early=True, sigmoid=True, mask_invalid=True, mask_invalid_completion=True):
+        """One (pos,val) sequence per input cloud -> dict(samples tokens, dense code grid, occupancy (B,Q^3))."""
+        enc = self.encode_cloud(Xct)
+        g = self.gpt
+        res = g.sample(enc["c_tokens"], enc["Lc"], max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature,
+                       best_in_first=best_in_first, mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion,
+                       seed=seed, stop_early=stop_early, to_host=False)
+        st = res["state"]
+        dense = T.sparse2dense_dev(st["seq"], st["len"], enc["empty_index"], self.R, self.end, start=st["Lc"])
+        out = self.vq.decode_index(dense, grid_Q=decode_res, sigmoid=sigmoid)
+        return dict(c_ind=enc["c_tokens"], Lc=enc["Lc"], empty_index=enc["empty_index"], state=st, steps=res["steps"],
+                    dense=dense, occupancy=out["logits"][..., 0], log_prob=st["logp"])
+
+    @torch.no_grad()
+    def reconstruct(self, Xbd, decode_res=128, max_length=512, sigmoid=False):
+        """VisSparseRecon3D.compute_batch (vqdif.py:243-269): quantize -> sparse -> dense -> decode_index."""
+        q, mode, raw, mask, latent = self.vq.quantize_cloud_dev(Xbd, per_shape_mode=False)
+        mode2 = T.mode_i32(q, self.vq.K + 1)
+        tok, ln = T.dense2sparse_dev(q, mode2, max_length, self.end, Lpad=max_length)
+        dense = T.sparse2dense_dev(tok, ln, mode2, self.R, self.end)
+        out = self.vq.decode_index(dense, grid_Q=decode_res, sigmoid=sigmoid)
+        return dict(logits=out["logits"], quant_ind=raw, sparse=(tok, ln), grid_mask=mask, dense=dense)

@@ -11,11 +11,12 @@ import torch
 from . import _lib as L
 
 
-def mode_i32(idx, vocab, hist=None, out=None):
+def mode_i32(idx, vocab, rows=1):
+    """rows=1: whole-tensor mode (reference batch semantics); rows=B: one mode per shape."""
     dev = idx.device
-    hist = hist if hist is not None else torch.empty(vocab, device=dev, dtype=torch.int32)
-    out = out if out is not None else torch.empty(1, device=dev, dtype=torch.int32)
-    L.check(L.lib().sfmi_mode_i32(L.ptr(idx), idx.numel(), vocab, L.ptr(hist), L.ptr(out), L.stream_ptr()), "sfmi_mode_i32")
+    hist = torch.empty(rows * vocab, device=dev, dtype=torch.int32)
+    out = torch.empty(rows, device=dev, dtype=torch.int32)
+    L.check(L.lib().sfmi_mode_i32(L.ptr(idx), idx.numel(), vocab, rows, L.ptr(hist), L.ptr(out), L.stream_ptr()), "sfmi_mode_i32")
     return out
 
 
@@ -29,18 +30,18 @@ def dense2sparse_dev(q, mode, max_length, end_tokens, Lpad=None, tokens=None, le
     Lpad = Lpad or max_length
     tokens = tokens if tokens is not None else torch.empty(B, Lpad, 2, device=q.device, dtype=torch.int32)
     length = length if length is not None else torch.empty(B, device=q.device, dtype=torch.int32)
-    L.check(L.lib().sfmi_dense2sparse_i32(L.ptr(q), L.ptr(mode), L.ptr(tokens), L.ptr(length), B, ncell, Lpad, max_length,
+    L.check(L.lib().sfmi_dense2sparse_i32(L.ptr(q), L.ptr(mode), int(mode.numel() > 1), L.ptr(tokens), L.ptr(length), B, ncell, Lpad, max_length,
                                           int(end_tokens[0]), int(end_tokens[1]), L.stream_ptr()), "sfmi_dense2sparse_i32")
     return tokens, length
 
 
-def sparse2dense_dev(tokens, length, empty, dense_res, end_tokens, dim=3, out=None):
-    """tokens (B,Lpad,2) int32, len (B,) or None, empty (1,) int32 -> dense (B,R,R,R) int32."""
+def sparse2dense_dev(tokens, length, empty, dense_res, end_tokens, dim=3, out=None, start=None):
+    """tokens (B,Lpad,2) int32, len (B,) or None, empty (1,) or (B,) int32, optional per-row start -> dense (B,R,R,R) int32."""
     tokens = tokens.contiguous()
     B, Lpad, _ = tokens.shape
     ncell = dense_res ** dim
     out = out if out is not None else torch.empty((B,) + (dense_res,) * dim, device=tokens.device, dtype=torch.int32)
-    L.check(L.lib().sfmi_sparse2dense_i32(L.ptr(tokens), L.ptr(length), L.ptr(empty), L.ptr(out), B, ncell, Lpad,
+    L.check(L.lib().sfmi_sparse2dense_i32(L.ptr(tokens), L.ptr(start), L.ptr(length), L.ptr(empty), int(empty.numel() > 1), L.ptr(out), B, ncell, Lpad,
                                           int(end_tokens[0]), int(end_tokens[1]), L.stream_ptr()), "sfmi_sparse2dense_i32")
     return out
 

@@ -175,19 +175,24 @@ class VQDIF:
         L.check(L.lib().sfmi_vq_gather_f32(L.ptr(self.codebook), L.ptr(ind32), L.ptr(out), N, self.d, L.stream_ptr()), "sfmi_vq_gather_f32")
         return out
 
-    def mode_of(self, idx, name="mode"):
-        hist = self._buf("hist", (self.K + 1,), torch.int32)
-        mode = self._buf(name, (1,), torch.int32)
-        L.check(L.lib().sfmi_mode_i32(L.ptr(idx), idx.numel(), self.K + 1, L.ptr(hist), L.ptr(mode), L.stream_ptr()), "sfmi_mode_i32")
+    def mode_of(self, idx, name="mode", rows=1):
+        hist = self._buf("hist", (rows * (self.K + 1),), torch.int32)
+        mode = self._buf(name, (rows,), torch.int32)
+        L.check(L.lib().sfmi_mode_i32(L.ptr(idx), idx.numel(), self.K + 1, rows, L.ptr(hist), L.ptr(mode), L.stream_ptr()), "sfmi_mode_i32")
         return mode
 
-    def quantize_cloud_dev(self, cloud):
-        """Device-resident quantize_cloud: (quant_ind int32 (B,R,R,R), mode int32 (1,), raw idx, mask u8)."""
+    def quantize_cloud_dev(self, cloud, per_shape_mode=False):
+        """Device-resident quantize_cloud: (quant_ind int32 (B,R,R,R), mode int32, raw idx, mask u8, latent).
+
+        per_shape_mode=False reproduces the reference on a batch (ONE mode over the whole batch, vqdif.py:53);
+        True gives every shape its own empty code = the reference run shape-by-shape at batch size 1, which is
+        how its inference drivers call it (shapeformer.py:227 asserts batch_size == 1)."""
         latent, mask = self.encode_cl(cloud)
         raw = self.quantize_cl(latent)
-        mode = self.mode_of(raw)
+        rows = raw.shape[0] if per_shape_mode else 1
+        mode = self.mode_of(raw, rows=rows)
         q = self._buf("quant_ind", tuple(raw.shape), torch.int32)
-        L.check(L.lib().sfmi_apply_mask_i32(L.ptr(raw), L.ptr(mask), L.ptr(mode), L.ptr(q), raw.numel(), L.stream_ptr()), "sfmi_apply_mask_i32")
+        L.check(L.lib().sfmi_apply_mask_i32(L.ptr(raw), L.ptr(mask), L.ptr(mode), L.ptr(q), raw.numel(), rows, L.stream_ptr()), "sfmi_apply_mask_i32")
         return q, mode, raw, mask, latent
 
     def quantize_cloud(self, cloud):
