@@ -53,6 +53,9 @@ PROTOTYPES = {
     "sfmi_skinny_pack_floats": (sz, [i32, i32]),
     "sfmi_skinny_pack_weight": (i32, [c_ptr, i32, i32, c_ptr]),
     "sfmi_skinny_gemm_f32": (i32, [c_ptr] * 4 + [i32] * 6 + [c_ptr]),
+    "sfmi_skinny16_pack_floats": (sz, [i32, i32]),
+    "sfmi_skinny16_pack_weight": (i32, [c_ptr, i32, i32, c_ptr]),
+    "sfmi_skinny16_gemm_f32": (i32, [c_ptr] * 4 + [i32] * 6 + [c_ptr]),
     "sfmi_gpt_embed_f32": (i32, [c_ptr] * 12 + [i32] * 5 + [c_ptr]),
     "sfmi_gpt_rowprep_f32": (i32, [c_ptr] * 11 + [i32] * 5 + [c_ptr]),
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr]),
@@ -73,6 +76,9 @@ def lib():
             raise SfmiError(
                 f"{LIB_PATH} not found: the HIP extension is REQUIRED (no CPU/eager fallback). "
                 "Build it with `python -m shapeformer_amd.build`.")
+        # torch's bundled HIP runtime (same SONAME libamdhip64.so.7) must be the one in the process BEFORE
+        # libsfmi.so is loaded, otherwise two runtimes coexist and our launches see "no device" (hipError 100).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             try:

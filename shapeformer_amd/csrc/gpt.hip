@@ -185,17 +185,84 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode attention: grid (B, H), 256 threads; head dim 64 (or any multiple of 4 up to 64)
+// skinny GEMM for M <= 16 rows on v_mfma_f32_16x16x4_f32: n-tile = 16 output columns per workgroup
+// (N/16 x S workgroups -> every CU streams weights even for N = 1024), Wp16 packed [N/16][K/16][64][4]
+// (lane (n=l&15, q=l>>4) holds W[n][16*k16 + 4q + j]); each wave issues UN weight + UN activation
+// float4 loads before its MFMAs so that ~UN KiB per wave are in flight.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv_part /*(S,M,3D) q|k|v*/,
-                                                          const float* __restrict__ bqkv /*(3D)*/, float* __restrict__ Kc,
-                                                          float* __restrict__ Vc /*(B,Lmax,D)*/, const int* __restrict__ len,
-                                                          float* __restrict__ y /*(M,D)*/, int S, int M, int D, int Lmax,
-                                                          int HD, float scale) {
-  __shared__ float qs[64], kn[64], vn[64], sc[1024], red[8], yacc[4][64];
-  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void skinny16_gemm_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                int M, int N, int K, int kslice, int ldo, int epi) {
+  __shared__ __attribute__((aligned(16))) float red[NW][4][64];
+  constexpr int UN = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
+  const int nt = blockIdx.x, sp = blockIdx.y;
+  const int kw = kslice / NW;
+  const int k0 = sp * kslice + wave * kw;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((long long)nt * (K / 16) + k0 / 16) * 64 + lane;
+  const int m = ml < M ? ml : M - 1;
+  const float* xr = x + (long long)m * K + k0 + 4 * q;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const int steps = kw / 16;
+  for (int s0 = 0; s0 < steps; s0 += UN) {
+    f32x4 w[UN], xb[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int st = (s0 + u < steps) ? s0 + u : steps - 1;
+      w[u] = wp[st * 64];
+      xb[u] = *reinterpret_cast<const f32x4*>(xr + st * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (s0 + u < steps) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][j], xb[u][j], acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] += red[w][e][lane];
+    const int n = nt * 16 + 4 * q;
+    if (ml < M && n < N) {
+      if (epi) {
+        r = r + *reinterpret_cast<const f32x4*>(bias + n);
+        if (epi == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
+        }
+      }
+      *reinterpret_cast<f32x4*>(out + ((long long)sp * M + ml) * ldo + n) = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode attention: grid (B, H), 1024 threads (16 waves); head dim HD <= 64, multiple of 4.
+// KV cache layout is (B, H, Lmax, HD): one (row, head)'s keys are CONTIGUOUS, so a wave-instruction reads
+// 4 keys x 256 B = 1 KiB coalesced; 16 lanes share a key (float4 each), 4 independent loads are in
+// flight per lane (unrolled), all 16 waves of the workgroup stream disjoint keys.
+// ------------------------------------------------------------------------------------------------
+#define ATT_WAVES 16
+__global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restrict__ qkv_part /*(S,M,3D) q|k|v*/,
+                                                           const float* __restrict__ bqkv /*(3D)*/, float* __restrict__ Kc,
+                                                           float* __restrict__ Vc /*(B,H,Lmax,HD)*/, const int* __restrict__ len,
+                                                           float* __restrict__ y /*(M,D)*/, int S, int M, int D, int Lmax,
+                                                           int HD, float scale) {
+  __shared__ __attribute__((aligned(16))) float qs[64], kn[64], vn[64], sc[1024], red[2 * ATT_WAVES], yacc[ATT_WAVES][64];
+  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = len[b] - 1;  // position being processed
-  const int nq4 = HD / 4;    // float4 per head row
+  const int nq4 = HD / 4;
+  float* Kb = Kc + ((long long)b * H + h) * Lmax * HD;
+  float* Vb = Vc + ((long long)b * H + h) * Lmax * HD;
   if (tid < HD) {
     float q = bqkv[h * HD + tid], k = bqkv[D + h * HD + tid], v = bqkv[2 * D + h * HD + tid];
     for (int s = 0; s < S; ++s) {
@@ -203,58 +270,72 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
       q += p[0]; k += p[D]; v += p[2 * D];
     }
     qs[tid] = q * scale; kn[tid] = k; vn[tid] = v;
-    Kc[((long long)b * Lmax + t) * D + h * HD + tid] = k;
-    Vc[((long long)b * Lmax + t) * D + h * HD + tid] = v;
+    Kb[(long long)t * HD + tid] = k;
+    Vb[(long long)t * HD + tid] = v;
   }
   __syncthreads();
-  // scores: 16 lanes per key (float4 each), 4 keys per wave instruction
   const int c4 = lane & 15, kk = lane >> 4;
+  const bool cok = c4 < nq4;
   f32x4 qf = {0.f, 0.f, 0.f, 0.f};
-  if (c4 < nq4) qf = *reinterpret_cast<const f32x4*>(qs + 4 * c4);
+  if (cok) qf = *reinterpret_cast<const f32x4*>(qs + 4 * c4);
   float lmax = -INFINITY;
-  for (int i0 = 0; i0 <= t; i0 += 16) {
-    const int i = i0 + wave * 4 + kk;
-    float d = 0.f;
-    if (i <= t && c4 < nq4) {
-      const f32x4 kf = (i == t) ? *reinterpret_cast<const f32x4*>(kn + 4 * c4)
-                                : *reinterpret_cast<const f32x4*>(Kc + ((long long)b * Lmax + i) * D + h * HD + 4 * c4);
-      d = (qf[0] * kf[0] + qf[1] * kf[1]) + (qf[2] * kf[2] + qf[3] * kf[3]);
+  // keys i = it*64 + wave*4 + kk ; 4 iterations in flight
+  for (int i0 = 0; i0 <= t; i0 += 256) {
+    f32x4 kf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 + wave * 4 + kk;
+      kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < t && cok) kf[u] = *reinterpret_cast<const f32x4*>(Kb + (long long)i * HD + 4 * c4);
+      else if (i == t && cok) kf[u] = *reinterpret_cast<const f32x4*>(kn + 4 * c4);
     }
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-    if (i <= t) {
-      if (c4 == 0) sc[i] = d;
-      lmax = fmaxf(lmax, d);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 + wave * 4 + kk;
+      float d = (qf[0] * kf[u][0] + qf[1] * kf[u][1]) + (qf[2] * kf[u][2] + qf[3] * kf[u][3]);
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+      if (i <= t) {
+        if (c4 == 0) sc[i] = d;
+        lmax = fmaxf(lmax, d);
+      }
     }
   }
   lmax = wave_max(lmax);
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
-  const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float ls = 0.f;
-  for (int i = tid; i <= t; i += 256) {
-    const float e = __expf(sc[i] - gmax);
-    sc[i] = e;
-    ls += e;
-  }
-  ls = wave_sum(ls);
-  if (lane == 0) red[4 + wave] = ls;
-  __syncthreads();
-  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
-  // y = sum_i p_i V[i]
+  float gmax = red[0];
+#pragma unroll
+  for (int w = 1; w < ATT_WAVES; ++w) gmax = fmaxf(gmax, red[w]);
+  // y = sum_i p_i V[i], p_i = exp(s_i - gmax); the 1/sum is applied at the end
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int i0 = 0; i0 <= t; i0 += 16) {
-    const int i = i0 + wave * 4 + kk;
-    if (i <= t && c4 < nq4) {
-      const f32x4 vf = (i == t) ? *reinterpret_cast<const f32x4*>(vn + 4 * c4)
-                                : *reinterpret_cast<const f32x4*>(Vc + ((long long)b * Lmax + i) * D + h * HD + 4 * c4);
-      acc = acc + vf * sc[i];
+  float ls = 0.f;
+  for (int i0 = 0; i0 <= t; i0 += 256) {
+    f32x4 vf[4];
+    float pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 + wave * 4 + kk;
+      vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pr[u] = 0.f;
+      if (i < t && cok) vf[u] = *reinterpret_cast<const f32x4*>(Vb + (long long)i * HD + 4 * c4);
+      else if (i == t && cok) vf[u] = *reinterpret_cast<const f32x4*>(vn + 4 * c4);
+      if (i <= t) pr[u] = __expf(sc[i] - gmax);
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc = acc + vf[u] * pr[u]; ls += pr[u]; }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) { acc[e] += __shfl_xor(acc[e], 16, 64); acc[e] += __shfl_xor(acc[e], 32, 64); }
-  if (kk == 0 && c4 < nq4) *reinterpret_cast<f32x4*>(&yacc[wave][4 * c4]) = acc;
+  ls += __shfl_xor(ls, 16, 64); ls += __shfl_xor(ls, 32, 64);  // every c4 lane holds the wave's sum over its kk keys
+  if (kk == 0 && cok) *reinterpret_cast<f32x4*>(&yacc[wave][4 * c4]) = acc;
+  if (lane == 0) red[ATT_WAVES + wave] = ls;
   __syncthreads();
-  if (tid < HD) y[(long long)b * D + h * HD + tid] = ((yacc[0][tid] + yacc[1][tid]) + (yacc[2][tid] + yacc[3][tid])) * inv;
+  if (tid < HD) {
+    float o = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) { o += yacc[w][tid]; l += red[ATT_WAVES + w]; }
+    y[(long long)b * D + h * HD + tid] = o / l;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,8 +376,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
       *reinterpret_cast<f32x4*>(&Ks[r][4 * c]) = kv;
       *reinterpret_cast<f32x4*>(&Vs[r][4 * c]) = vv;
       if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
-        *reinterpret_cast<f32x4*>(Kc + ((long long)b * Lmax + k0 + r) * D + h * 64 + 4 * c) = kv;
-        *reinterpret_cast<f32x4*>(Vc + ((long long)b * Lmax + k0 + r) * D + h * 64 + 4 * c) = vv;
+        const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * 64 + 4 * c;  // (B,H,Lmax,64)
+        *reinterpret_cast<f32x4*>(Kc + co) = kv;
+        *reinterpret_cast<f32x4*>(Vc + co) = vv;
       }
     }
     __syncthreads();
@@ -556,6 +638,41 @@ int sfmi_skinny_gemm_f32(const float* x, const float* Wp, const float* bias, flo
   return SFMI_OK;
 }
 
+// M <= 16 variant on the 16x16x4 MFMA; Wp16 = [ceil(N/16)][K/16][64][4] (sfmi_skinny16_pack_weight)
+size_t sfmi_skinny16_pack_floats(int N, int K) { return (size_t)((N + 15) / 16) * 16 * K; }
+int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out) {
+  if (!W || !out || K % 16) return SFMI_EINVAL;
+  const int NT = (N + 15) / 16;
+  for (int nt = 0; nt < NT; ++nt)
+    for (int k16 = 0; k16 < K / 16; ++k16)
+      for (int l = 0; l < 64; ++l) {
+        const int n = nt * 16 + (l & 15);
+        for (int j = 0; j < 4; ++j) {
+          const int k = k16 * 16 + 4 * (l >> 4) + j;
+          out[(((size_t)nt * (K / 16) + k16) * 64 + l) * 4 + j] = n < N ? W[(size_t)n * K + k] : 0.0f;
+        }
+      }
+  return SFMI_OK;
+}
+int sfmi_skinny16_gemm_f32(const float* x, const float* Wp16, const float* bias, float* out, int M, int N, int K, int S,
+                           int ldo, int epi, void* stream) {
+  if (!x || !Wp16 || !out || M <= 0 || M > 16 || S <= 0 || K % (16 * S) || (epi && (S != 1 || !bias))) return SFMI_EINVAL;
+  const int NT = (N + 15) / 16;
+  const int kslice = K / S;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(NT, S);
+  if (kslice % (16 * 8) == 0 && kslice >= 512)
+    hipLaunchKernelGGL((skinny16_gemm_kernel<8>), grid, dim3(512), 0, st, x, Wp16, bias, out, M, N, K, kslice, ldo, epi);
+  else if (kslice % (16 * 4) == 0)
+    hipLaunchKernelGGL((skinny16_gemm_kernel<4>), grid, dim3(256), 0, st, x, Wp16, bias, out, M, N, K, kslice, ldo, epi);
+  else if (kslice % (16 * 2) == 0)
+    hipLaunchKernelGGL((skinny16_gemm_kernel<2>), grid, dim3(128), 0, st, x, Wp16, bias, out, M, N, K, kslice, ldo, epi);
+  else
+    hipLaunchKernelGGL((skinny16_gemm_kernel<1>), grid, dim3(64), 0, st, x, Wp16, bias, out, M, N, K, kslice, ldo, epi);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
 // replaces get_embeddings (mingpt.py:256-286) + the AR_N extra index (representers.py:188-196,432-442)
 // (+ LayerNorm ln1 of the first block).  P == 0: one row per sequence at t = len[b]-1; P > 0: prefill rows (b,t<P).
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
@@ -590,7 +707,7 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
                              int S, int B, int D, int H, int Lmax, void* stream) {
   if (!qkv_part || !bqkv || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
   const int HD = D / H;
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, qkv_part, bqkv, Kc, Vc, len, y, S, B, D,
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(B, H), dim3(1024), 0, (hipStream_t)stream, qkv_part, bqkv, Kc, Vc, len, y, S, B, D,
                      Lmax, HD, 1.0f / sqrtf((float)HD));
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;

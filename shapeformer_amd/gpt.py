@@ -35,12 +35,22 @@ def pack_skinny(w: torch.Tensor) -> torch.Tensor:
     return w.view(NT, 32, K // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
 
 
+def pack_skinny16(w: torch.Tensor) -> torch.Tensor:
+    """(N,K) row-major -> [ceil(N/16)][K/16][64][4] (same as sfmi_skinny16_pack_weight)."""
+    N, K = w.shape
+    NT = (N + 15) // 16
+    if NT * 16 != N:
+        w = torch.cat([w, w.new_zeros(NT * 16 - N, K)], 0)
+    return w.view(NT, 16, K // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
 class _Layer:
     pass
 
 
 class CondTupleGPT:
-    S_QKV, S_PROJ, S_FC2, S_HEAD = 4, 8, 8, 2
+    # split-K factors: (32x32 MFMA path for 16 < M <= 64, 16x16 MFMA path for M <= 16)
+    SPLITS = {32: dict(qkv=4, proj=8, fc2=8, head=2), 16: dict(qkv=2, proj=4, fc2=4, head=1)}
 
     def __init__(self, state_dict=None, n_embd=1024, n_head=16, n_layers=(20, 4), block_size=812,
                  vocab_sizes=(4097, 4097), extra_vocab_sizes=(4097,), end_tokens=(4096, 4096), device="cuda:0",
@@ -53,8 +63,6 @@ class CondTupleGPT:
         self.D, self.H, self.n_layers, self.Lmax = n_embd, n_head, tuple(n_layers), block_size
         self.V, self.end = vocab_sizes[0], tuple(end_tokens)
         self.Vpad = (self.V + 31) // 32 * 32
-        self.S_QKV, self.S_PROJ, self.S_HEAD = (self._splits(n_embd, s) for s in (self.S_QKV, self.S_PROJ, self.S_HEAD))
-        self.S_FC2 = self._splits(4 * n_embd, self.S_FC2)
         sd = state_dict if state_dict is not None else self._hash_state_dict()
         self.load_state_dict(sd)
         self._state = None
@@ -88,15 +96,36 @@ class CondTupleGPT:
                 ly.wproj, ly.bproj = g(p + "attn.proj.weight"), g(p + "attn.proj.bias")
                 ly.wfc1, ly.bfc1 = g(p + "mlp.0.weight"), g(p + "mlp.0.bias")
                 ly.wfc2, ly.bfc2 = g(p + "mlp.2.weight"), g(p + "mlp.2.bias")
-                ly.pqkv, ly.pproj, ly.pfc1, ly.pfc2 = (pack_skinny(w) for w in (ly.wqkv, ly.wproj, ly.wfc1, ly.wfc2))
                 ly.stage = s
                 self.layers.append(ly)
         self.head_ln = [(g(f"heads.{s}.0.weight"), g(f"heads.{s}.0.bias")) for s in range(2)]
         self.head_w = [g(f"heads.{s}.1.weight") for s in range(2)]
-        self.head_p = [pack_skinny(w) for w in self.head_w]
+        self._fmt = None
+
+    def _set_format(self, fmt):
+        """Pack the decode weights for the 16x16x4 (M<=16) or 32x32x2 (M<=64) MFMA path (lazily, once)."""
+        if self._fmt == fmt:
+            return
+        pk = pack_skinny16 if fmt == 16 else pack_skinny
+        for ly in self.layers:
+            ly.pqkv, ly.pproj, ly.pfc1, ly.pfc2 = (pk(w) for w in (ly.wqkv, ly.wproj, ly.wfc1, ly.wfc2))
+        self.head_p = [pk(w) for w in self.head_w]
+        sp = self.SPLITS[fmt]
+        unit = 32 if fmt == 32 else 16
+
+        def fix(K, S):   # largest S' <= S with K divisible by unit*S'
+            while S > 1 and K % (unit * S):
+                S //= 2
+            return S
+        self.S_QKV, self.S_PROJ, self.S_HEAD = fix(self.D, sp["qkv"]), fix(self.D, sp["proj"]), fix(self.D, sp["head"])
+        self.S_FC2 = fix(4 * self.D, sp["fc2"])
+        self._fmt = fmt
+        self._state = None
+        self._graph = None
 
     # ------------------------------------------------------------------ state
     def _alloc(self, B, max_steps):
+        self._set_format(16 if B <= 16 else 32)
         key = (B, max_steps)
         if self._state is not None and self._state["key"] == key:
             return self._state
@@ -114,15 +143,9 @@ class CondTupleGPT:
         return st
 
     # ------------------------------------------------------------------ C-ABI wrappers
-    @staticmethod
-    def _splits(K, S):
-        while S > 1 and (K // S) % 32:
-            S //= 2
-        return S
-
     def _skinny(self, x, wp, bias, out, M, N, K, S, ldo, epi):
-        L.check(L.lib().sfmi_skinny_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), M, N, K, S, ldo, epi,
-                                             L.stream_ptr()), "sfmi_skinny_gemm_f32")
+        fn = L.lib().sfmi_skinny16_gemm_f32 if self._fmt == 16 else L.lib().sfmi_skinny_gemm_f32
+        L.check(fn(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), M, N, K, S, ldo, epi, L.stream_ptr()), "sfmi_skinny_gemm_f32")
 
     def _rowprep(self, resid_in, part, bias, S, M, resid_out, xn, ln, Eadd=None, P=0, st=None):
         L.check(L.lib().sfmi_gpt_rowprep_f32(L.ptr(resid_in), L.ptr(part), L.ptr(bias), L.ptr(Eadd),
