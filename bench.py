@@ -70,23 +70,25 @@ def kernel_rooflines(vq, gpt, B, dev):
         out.append(dict(kernel=name, bound=bound, ms=round(ms, 5), achieved=round(ach, 2), peak=peak, unit=unit,
                         frac=round(ach / peak, 4), note=note))
 
-    # decode-step weight streaming GEMMs (dominant by time): bytes = N*K*4 weights + M*K*4 x + S*M*N*4 partials
-    for nm, wp, bias, outb, N, K, S, ldo, epi in (
-            ("skinny_gemm fc1 (1024->4096,+GELU)", ly.pfc1, ly.bfc1, st["h"], 4 * D, D, 1, 4 * D, 1),
-            ("skinny_gemm fc2 (4096->1024)", ly.pfc2, None, st["fc2"], D, 4 * D, gpt.S_FC2, D, 0),
-            ("skinny_gemm qkv (1024->3072)", ly.pqkv, None, st["qkv"], 3 * D, D, gpt.S_QKV, 3 * D, 0),
-            ("skinny_gemm proj (1024->1024)", ly.pproj, None, st["proj"], D, D, gpt.S_PROJ, D, 0)):
-        x = st["h"] if K == 4 * D else st["xn"]
-        # rotate over the 24 layers' weights so the 256 MB Infinity Cache cannot serve them (as in the real step)
-        ws = [getattr(l, {"fc1": "pfc1", "fc2": "pfc2", "qkv": "pqkv", "pro": "pproj"}[nm.split()[1][:3]]) for l in gpt.layers]
-        it = [0]
-
-        def f():
-            w = ws[it[0] % len(ws)]
-            it[0] += 1
-            gpt._skinny(x, w, bias, outb, B, N, K, S, ldo, epi)
-        ms = ev_time(f, 48)
-        add(nm, ms, "hbm", N * K * 4 + B * K * 4 + S * B * N * 4, 1e9, HBM, "GB/s", f"M={B}, split-K {S}")
+    # decode-step weight-streaming GEMMs (dominant by time).  Each is timed as a hipGraph of one launch per
+    # transformer layer (24 different weight matrices back-to-back, exactly as in the real step, so the 256 MB
+    # Infinity Cache cannot serve them); algorithmic bytes = N*K*4 weights + M*K*4 activations + M*N*4 outputs.
+    r = st["resid"]
+    for nm, attr, c1a, c2a, xin, res, outb, N, K, ldo, ln, act in (
+            ("dgemm fc1 (LN+1024->4096+GELU)", "pfc1", "c1fc1", "c2fc1", r, None, st["h"], 4 * D, D, 4 * D, 1, 1),
+            ("dgemm fc2 (4096->1024+resid)", "pfc2", None, "bfc2", st["h"], r, r, D, 4 * D, D, 0, 0),
+            ("dgemm qkv (LN+1024->3072)", "pqkv", "c1qkv", "c2qkv", r, None, st["qkv"], 3 * D, D, 3 * D, 1, 0),
+            ("dgemm proj (1024->1024+resid)", "pproj", None, "bproj", st["y"], r, r, D, D, D, 0, 0)):
+        def body():
+            for l in gpt.layers:
+                gpt._dgemm(xin, getattr(l, attr), getattr(l, c1a) if c1a else None, getattr(l, c2a), res, outb, B, N, K, ldo, ln, act)
+        body()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+        ms = ev_time(g.replay, 10) / len(gpt.layers)
+        add(nm, ms, "hbm", N * K * 4 + B * K * 4 + B * N * 4, 1e9, HBM, "GB/s", f"M={B}, {len(gpt.layers)} layers/graph")
     # SDF query (north-star kernel): MFMA-bound, 31 488 FLOP/pt
     Q = 128
     grid = torch.randn(B, 64, 64, 64, 32, device=dev)
@@ -202,7 +204,7 @@ def main():
         }
         if not a.no_roofline:
             ks = kernel_rooflines(vq, gpt, B, dev)
-            dom = ks[0]  # fc1 skinny GEMM: largest single weight stream of the decode step (see DESIGN.md / profiles/)
+            dom = ks[0]  # fc1 decode GEMM: largest single weight stream of the decode step (see DESIGN.md / profiles/)
             line["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                                 "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"]}
             line["kernels"] = ks

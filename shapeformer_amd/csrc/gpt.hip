@@ -246,6 +246,113 @@ __global__ __launch_bounds__(64 * NW) void skinny16_gemm_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// decode GEMM with fused LayerNorm / bias / GELU / residual  (M <= 64 rows, 16x16x4 f32 MFMA)
+//
+//   plain : out[m][n] = act( sum_k x[m][k] W[n][k] + c2[n] ) (+ resid[m][n])
+//   LN    : LayerNorm commutes with the GEMM:  LN(x) W^T = rstd[m] (x W'^T - mean[m] c1[n]) + c2[n]
+//           with W' = W diag(gamma), c1[n] = sum_k W'[n][k], c2[n] = sum_k beta[k] W[n][k] + bias[n].
+//           Every workgroup streams ALL of x (it owns a 16-column n-tile over the full K), so it derives
+//           mean/rstd of each row on the fly - no separate LayerNorm kernel, no split-K partials, outputs
+//           are final (deterministic: one workgroup owns each output element).
+//   Weights: Wp16 fragment order [N/16][K/16][64][4]; NW waves split K; UN loads per wave in flight.
+// ------------------------------------------------------------------------------------------------
+struct DGemmArgs {
+  const float* x; const float* Wp; const float* c1; const float* c2; const float* resid; float* out;
+  int M, N, K, ldo, ln, act;
+};
+
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[NW][MT][4][64];
+  __shared__ float st1[NW][MT][16], st2[NW][MT][16];
+  constexpr int UN = (MT == 1) ? 8 : (MT == 2 ? 4 : 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
+  const int nt = blockIdx.x;
+  const int kw = a.K / NW;
+  const int k0 = wave * kw;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)nt * (a.K / 16) + k0 / 16) * 64 + lane;
+  const float* xr[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    int m = j * 16 + ml;
+    if (m >= a.M) m = a.M - 1;
+    xr[j] = a.x + (long long)m * a.K + k0 + 4 * q;
+  }
+  f32x4 acc[MT];
+  float s1[MT], s2[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[j] = 0.f; s2[j] = 0.f; }
+  const int steps = kw / 16;
+  for (int s0 = 0; s0 < steps; s0 += UN) {
+    f32x4 w[UN], xb[UN][MT];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int st = (s0 + u < steps) ? s0 + u : steps - 1;
+      w[u] = wp[st * 64];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) xb[u][j] = *reinterpret_cast<const f32x4*>(xr[j] + st * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (s0 + u < steps) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const f32x4 xv = xb[u][j];
+          if (a.ln) {
+            s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
+            s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][e], xv[e], acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][j][r][lane] = acc[j][r];
+    if (a.ln) {
+      float t1 = s1[j], t2 = s2[j];
+      t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+      t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (q == 0) { st1[wave][j][ml] = t1; st2[wave][j][ml] = t2; }
+    }
+  }
+  __syncthreads();
+  // epilogue: wave w finishes m-tiles j = w, w+NW, ...
+  for (int j = wave; j < MT; j += NW) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] += red[w][j][e][lane];
+    const int m = j * 16 + ml;
+    const int n = nt * 16 + 4 * q;
+    if (m < a.M && n < a.N) {
+      if (a.ln) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { t1 += st1[w][j][ml]; t2 += st2[w][j][ml]; }
+        const float mean = t1 / (float)a.K;
+        const float var = fmaxf(t2 / (float)a.K - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + 1e-5f);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(a.c1 + n);
+        r = (r - c1 * mean) * rstd;
+      }
+      if (a.c2) r = r + *reinterpret_cast<const f32x4*>(a.c2 + n);
+      if (a.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
+      }
+      float* o = a.out + (long long)m * a.ldo + n;
+      if (a.resid) r = r + *reinterpret_cast<const f32x4*>(a.resid + (long long)m * a.ldo + n);
+      *reinterpret_cast<f32x4*>(o) = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode attention: grid (B, H), 1024 threads (16 waves); head dim HD <= 64, multiple of 4.
 // KV cache layout is (B, H, Lmax, HD): one (row, head)'s keys are CONTIGUOUS, so a wave-instruction reads
 // 4 keys x 256 B = 1 KiB coalesced; 16 lanes share a key (float4 each), 4 independent loads are in
@@ -423,11 +530,16 @@ __device__ __forceinline__ float sf_uniform(unsigned seed, unsigned idx) {  // =
 }
 
 struct SampleArgs {
-  const float* part;  // (S,M,ldv) logits partials (heads have no bias)
+  const float* part;  // (S,M,ldv) logits (S partial slabs summed in order; heads have no bias)
   int* seq; int* len; const int* Lc;
   float* logp;        // (B,max_steps,2) log-prob of the drawn token under the masked logits, or null
   float* hist;        // (B,max_steps,V) masked logits history for this tuple element, or null
   const int* force;   // (B,max_steps,2) teacher-forced tokens (parity tests), or null
+  // fused tails (decode step): tuple 0 -> resid[b] += E0[pos']   (stage-1 input, mingpt.py:294/309)
+  //                            tuple 1 -> resid[b]  = embedding of the token just completed (mingpt.py:256-286),
+  //                                       i.e. the next step's stage-0 input
+  float* resid; const float *E0, *E1, *Ex, *pos_emb;
+  int D;
   int S, M, V, ldv, Lmax, tuple_i, end0, end1, top_k, greedy_row0, mask_invalid, mask_completion, max_steps, advance;
   float top_p, temperature;
   unsigned seed;
@@ -438,18 +550,20 @@ struct SampleArgs {
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ float lg[4352];
   __shared__ unsigned hist[256];
-  __shared__ float cval_s[SMP_MAXC];
+  __shared__ float cval_s[SMP_MAXC], cexp_s[SMP_MAXC];
   __shared__ int cidx_s[SMP_MAXC];
-  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // big path: [NS] values + [NS] indices
-  // candidate buffer: 512 static entries normally; the whole (padded) vocabulary when top_k is 0 or > 512
-  const bool big = a.top_k <= 0 || a.top_k > SMP_MAXC;
-  const int NS = big ? SMP_BIG : SMP_MAXC;
-  float* cval = big ? dyn_lds : cval_s;
-  int* cidx = big ? reinterpret_cast<int*>(dyn_lds + SMP_BIG) : cidx_s;
   __shared__ float redf[8];
   __shared__ int redi[8];
   __shared__ unsigned s_prefix, s_need;
-  __shared__ int s_cnt, s_choice;
+  __shared__ int s_cnt, s_choice, s_keep;
+  __shared__ float s_tot;
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // big path: [NS] values, [NS] indices, [NS] exps
+  // candidate buffer: 512 static entries normally; the whole (padded) vocabulary when top_k is 0 or > 512
+  const bool big = a.top_k <= 0 || a.top_k > SMP_MAXC;
+  const int NSMAX = big ? SMP_BIG : SMP_MAXC;
+  float* cval = big ? dyn_lds : cval_s;
+  int* cidx = big ? reinterpret_cast<int*>(dyn_lds + SMP_BIG) : cidx_s;
+  float* cexp = big ? dyn_lds + 2 * SMP_BIG : cexp_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = a.len[b], lc = a.Lc[b];
   const int j = L - lc;  // step index of this row
@@ -503,7 +617,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   if (!greedy) {
     // ---- top-k threshold by MSB-first radix select on order-preserving keys of lg/T ----------
     const float invT = 1.0f / a.temperature;
-    int k = a.top_k > 0 ? min(a.top_k, a.V) : a.V;
+    const int k = a.top_k > 0 ? min(a.top_k, a.V) : a.V;
     if (tid == 0) { s_prefix = 0u; s_need = (unsigned)k; }
     __syncthreads();
     for (int pass = 0; pass < 4; ++pass) {
@@ -517,14 +631,21 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        unsigned need = s_need, bin = 255u;
-        for (int q = 255; q >= 0; --q) {
-          if (hist[q] >= need) { bin = (unsigned)q; break; }
-          need -= hist[q];
+      if (wave == 0) {  // descending scan over the 256 bins by one wave (4 bins per lane)
+        const unsigned need = s_need;
+        const int b0 = 255 - 4 * lane;
+        const unsigned h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+        const unsigned tot = (h0 + h1) + (h2 + h3);
+        unsigned incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        const unsigned excl = incl - tot;
+        if (need > excl && need <= incl) {
+          unsigned c = excl; int bin = b0;
+          if (c + h0 < need) { c += h0; bin = b0 - 1; if (c + h1 < need) { c += h1; bin = b0 - 2; if (c + h2 < need) { c += h2; bin = b0 - 3; } } }
+          s_need = need - c;
+          s_prefix = prefix | ((unsigned)bin << shift);
         }
-        s_need = need;
-        s_prefix = prefix | (bin << shift);
       }
       __syncthreads();
     }
@@ -535,15 +656,17 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       const float x = lg[v] * invT;
       if (x > -INFINITY && fkey_u(x) >= kth) {
         const int slot = atomicAdd(&s_cnt, 1);
-        if (slot < NS) { cval[slot] = x; cidx[slot] = v; }
+        if (slot < NSMAX) { cval[slot] = x; cidx[slot] = v; }
       }
     }
     __syncthreads();
-    const int C = min(s_cnt, NS);
+    const int C = min(s_cnt, NSMAX);
+    int NS = 2;
+    while (NS < C) NS <<= 1;
     for (int i = tid; i < NS; i += 256)
       if (i >= C) { cval[i] = -INFINITY; cidx[i] = 0x7fffffff; }
     __syncthreads();
-    // bitonic sort of NS entries (value desc, index asc); each thread owns NS/512 compare-exchange pairs
+    // bitonic sort of NS entries (value desc, index asc)
     for (int sz = 2; sz <= NS; sz <<= 1)
       for (int st = sz >> 1; st > 0; st >>= 1) {
         for (int pr = tid; pr < NS / 2; pr += 256) {
@@ -556,30 +679,38 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         }
         __syncthreads();
       }
+    // exps in parallel; the order-sensitive running sums stay sequential (oracle convention)
+    const float m0 = cval[0];
+    for (int i = tid; i < C; i += 256) cexp[i] = __expf(cval[i] - m0);
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.f;
+      for (int i = 0; i < C; ++i) tot += cexp[i];
+      s_tot = tot;
+    }
+    __syncthreads();
     if (tid == 0) {
       // top-p (common.py:271-284): drop sorted i>=1 where cumsum(softmax)[i-1] > p
-      const float m0 = cval[0];
       int keep = C;
       if (a.top_p > 0.f) {
-        float tot = 0.f;
-        for (int i = 0; i < C; ++i) tot += __expf(cval[i] - m0);
+        const float tot = s_tot;
         float cum = 0.f;
         keep = 1;
         for (int i = 0; i + 1 < C; ++i) {
-          cum += __expf(cval[i] - m0) / tot;
+          cum += cexp[i] / tot;
           if (cum > a.top_p) break;
           keep = i + 2;
         }
       }
       // inverse-CDF draw (oracle/tokens_oracle.py:sample_filtered convention)
       const float u = sf_uniform(a.seed, (unsigned)((j * 2 + a.tuple_i) * (int)gridDim.x + b));
-      float tot = 0.f;
-      for (int i = 0; i < keep; ++i) tot += __expf(cval[i] - m0);
-      const float thr = u * tot;
+      float tot2 = 0.f;
+      for (int i = 0; i < keep; ++i) tot2 += cexp[i];
+      const float thr = u * tot2;
       float cs = 0.f;
       int pick = keep - 1;
       for (int i = 0; i < keep; ++i) {
-        cs += __expf(cval[i] - m0);
+        cs += cexp[i];
         if (cs > thr) { pick = i; break; }
       }
       s_choice = cidx[pick];
@@ -592,6 +723,29 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     a.seq[((long long)b * a.Lmax + L) * 2 + a.tuple_i] = choice;
     if (a.logp && j < a.max_steps) a.logp[((long long)b * a.max_steps + j) * 2 + a.tuple_i] = lg[choice] - lse;
     if (a.advance) a.len[b] = L + 1;
+  }
+  // ---- fused tails --------------------------------------------------------------------------
+  if (a.resid) {
+    const int nq = a.D / 4;
+    f32x4* rr = reinterpret_cast<f32x4*>(a.resid + (long long)b * a.D);
+    if (a.tuple_i == 0) {
+      const f32x4* e0 = reinterpret_cast<const f32x4*>(a.E0 + (long long)choice * a.D);
+      for (int qd = tid; qd < nq; qd += 256) rr[qd] = rr[qd] + e0[qd];
+    } else {
+      const int pos = cur_pos, val = choice, t = L;  // the token at position L is now complete
+      int ext;
+      if (pos == a.end0) ext = a.end0;
+      else {
+        int lo = 0, hi = lc;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (row[2 * mid] > pos) hi = mid; else lo = mid + 1; }
+        ext = row[2 * (lo < lc ? lo : lc - 1)];
+      }
+      const f32x4* e0 = reinterpret_cast<const f32x4*>(a.E0 + (long long)pos * a.D);
+      const f32x4* e1 = reinterpret_cast<const f32x4*>(a.E1 + (long long)val * a.D);
+      const f32x4* ex = reinterpret_cast<const f32x4*>(a.Ex + (long long)ext * a.D);
+      const f32x4* pe = reinterpret_cast<const f32x4*>(a.pos_emb + (long long)(t - lc) * a.D);
+      for (int qd = tid; qd < nq; qd += 256) rr[qd] = ((e0[qd] + e1[qd]) + ex[qd]) + pe[qd];
+    }
   }
 }
 
@@ -673,6 +827,26 @@ int sfmi_skinny16_gemm_f32(const float* x, const float* Wp16, const float* bias,
   return SFMI_OK;
 }
 
+// replaces LayerNorm + nn.Linear (+GELU / +residual) of Block.forward at decode time (mingpt.py:103-111).
+// Wp16: sfmi_skinny16_pack_weight of W (plain) or of W*diag(gamma) (ln=1, with c1/c2 as in the kernel header).
+// c1/c2 need ceil(N/16)*16 readable floats.  resid (if given) is added and shares out's (M,ldo) layout.
+int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
+                         float* out, int M, int N, int K, int ldo, int ln, int act, void* stream) {
+  if (!x || !Wp16 || !out || M <= 0 || M > 64 || K % (K >= 2048 ? 256 : 128) || (ln && !c1)) return SFMI_EINVAL;
+  DGemmArgs a;
+  a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((N + 15) / 16);
+  const int MT = (M + 15) / 16;
+  const bool big = K >= 2048;   // 16 waves for the K = 4096 down-projection, 8 otherwise
+#define DG(MT_, NW_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_>), grid, dim3(64 * NW_), 0, st, a)
+  if (big) { if (MT == 1) DG(1, 16); else if (MT == 2) DG(2, 16); else if (MT == 3) DG(3, 16); else DG(4, 16); }
+  else     { if (MT == 1) DG(1, 8);  else if (MT == 2) DG(2, 8);  else if (MT == 3) DG(3, 8);  else DG(4, 8); }
+#undef DG
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
 // replaces get_embeddings (mingpt.py:256-286) + the AR_N extra index (representers.py:188-196,432-442)
 // (+ LayerNorm ln1 of the first block).  P == 0: one row per sequence at t = len[b]-1; P > 0: prefill rows (b,t<P).
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
@@ -724,18 +898,22 @@ int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int*
 }
 
 // replaces sampling_masker + sample_logits for one tuple element (representers.py:120-155, common.py:260-299,
-// shapeformer.py:91-106); advance != 0 also appends the token (len += 1).
-int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, float* logp, float* hist, const int* force, int S, int B, int V,
-                        int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p, float temperature,
-                        int greedy_row0, int mask_invalid, int mask_completion, int max_steps, unsigned seed, int advance,
-                        void* stream) {
+// shapeformer.py:91-106); advance != 0 also appends the token (len += 1).  Optional fused tail (resid != NULL):
+// tuple 0: resid[b] += E0[pos'] ; tuple 1: resid[b] = embedding of the completed token (next step's input).
+int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, float* logp, float* hist, const int* force,
+                        float* resid, const float* E0, const float* E1, const float* Ex, const float* pos_emb, int D,
+                        int S, int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
+                        float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
+                        unsigned seed, int advance, void* stream) {
   if (!part || !seq || !len || !Lc || V > 4352 || temperature <= 0.f) return SFMI_EINVAL;
+  if (resid && (!E0 || (tuple_i == 1 && (!E1 || !Ex || !pos_emb)) || D % 4)) return SFMI_EINVAL;
   SampleArgs a;
-  a.part = part; a.seq = seq; a.len = len; a.Lc = Lc; a.logp = logp; a.hist = hist; a.force = force; a.S = S; a.M = B; a.V = V; a.ldv = ldv;
+  a.part = part; a.seq = seq; a.len = len; a.Lc = Lc; a.logp = logp; a.hist = hist; a.force = force; a.S = S; a.M = B; a.V = V;
+  a.ldv = ldv; a.resid = resid; a.E0 = E0; a.E1 = E1; a.Ex = Ex; a.pos_emb = pos_emb; a.D = D;
   a.Lmax = Lmax; a.tuple_i = tuple_i; a.end0 = end0; a.end1 = end1; a.top_k = top_k; a.greedy_row0 = greedy_row0;
   a.mask_invalid = mask_invalid; a.mask_completion = mask_completion; a.max_steps = max_steps; a.advance = advance;
   a.top_p = top_p; a.temperature = temperature; a.seed = seed;
-  const size_t dyn = (top_k <= 0 || top_k > SMP_MAXC) ? (size_t)SMP_BIG * 8 : 0;
+  const size_t dyn = (top_k <= 0 || top_k > SMP_MAXC) ? (size_t)SMP_BIG * 12 : 0;
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), dyn, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;

@@ -49,9 +49,6 @@ class _Layer:
 
 
 class CondTupleGPT:
-    # split-K factors: (32x32 MFMA path for 16 < M <= 64, 16x16 MFMA path for M <= 16)
-    SPLITS = {32: dict(qkv=4, proj=8, fc2=8, head=2), 16: dict(qkv=2, proj=4, fc2=4, head=1)}
-
     def __init__(self, state_dict=None, n_embd=1024, n_head=16, n_layers=(20, 4), block_size=812,
                  vocab_sizes=(4097, 4097), extra_vocab_sizes=(4097,), end_tokens=(4096, 4096), device="cuda:0",
                  tuple_n=2, **_ignored):
@@ -100,32 +97,26 @@ class CondTupleGPT:
                 self.layers.append(ly)
         self.head_ln = [(g(f"heads.{s}.0.weight"), g(f"heads.{s}.0.bias")) for s in range(2)]
         self.head_w = [g(f"heads.{s}.1.weight") for s in range(2)]
-        self._fmt = None
-
-    def _set_format(self, fmt):
-        """Pack the decode weights for the 16x16x4 (M<=16) or 32x32x2 (M<=64) MFMA path (lazily, once)."""
-        if self._fmt == fmt:
-            return
-        pk = pack_skinny16 if fmt == 16 else pack_skinny
+        # ---- decode-path weights: LayerNorm folded into the GEMM (csrc/gpt.hip dgemm_kernel) ----------------
+        #   LN(x) W^T + b = rstd (x W'^T - mean c1) + c2,  W' = W diag(gamma), c1 = rowsum(W'), c2 = W beta + b
+        def fold(w, bias, ln):
+            gam, bet = ln
+            wp = w * gam[None, :]
+            c1 = wp.sum(1)
+            c2 = w @ bet + (bias if bias is not None else 0)
+            pad = (-w.shape[0]) % 16
+            if pad:
+                c1, c2 = torch.cat([c1, c1.new_zeros(pad)]), torch.cat([c2, c2.new_zeros(pad)])
+            return pack_skinny16(wp), c1.contiguous(), c2.contiguous()
         for ly in self.layers:
-            ly.pqkv, ly.pproj, ly.pfc1, ly.pfc2 = (pk(w) for w in (ly.wqkv, ly.wproj, ly.wfc1, ly.wfc2))
-        self.head_p = [pk(w) for w in self.head_w]
-        sp = self.SPLITS[fmt]
-        unit = 32 if fmt == 32 else 16
-
-        def fix(K, S):   # largest S' <= S with K divisible by unit*S'
-            while S > 1 and K % (unit * S):
-                S //= 2
-            return S
-        self.S_QKV, self.S_PROJ, self.S_HEAD = fix(self.D, sp["qkv"]), fix(self.D, sp["proj"]), fix(self.D, sp["head"])
-        self.S_FC2 = fix(4 * self.D, sp["fc2"])
-        self._fmt = fmt
-        self._state = None
-        self._graph = None
+            ly.pqkv, ly.c1qkv, ly.c2qkv = fold(ly.wqkv, ly.bqkv, ly.ln1)
+            ly.pfc1, ly.c1fc1, ly.c2fc1 = fold(ly.wfc1, ly.bfc1, ly.ln2)
+            ly.pproj, ly.pfc2 = pack_skinny16(ly.wproj), pack_skinny16(ly.wfc2)
+        self.head_f = [fold(self.head_w[s], None, self.head_ln[s]) for s in range(2)]
+        self.zero_bqkv = torch.zeros(3 * self.D, device=dev)
 
     # ------------------------------------------------------------------ state
     def _alloc(self, B, max_steps):
-        self._set_format(16 if B <= 16 else 32)
         key = (B, max_steps)
         if self._state is not None and self._state["key"] == key:
             return self._state
@@ -134,8 +125,7 @@ class CondTupleGPT:
         st = dict(key=key,
                   seq=torch.zeros(B, self.Lmax + 1, 2, device=dev, dtype=torch.int32),
                   len=torch.zeros(B, device=dev, dtype=torch.int32), Lc=torch.zeros(B, device=dev, dtype=torch.int32),
-                  resid=f(B, D), xn=f(B, D), qkv=f(self.S_QKV, B, 3 * D), y=f(B, D), proj=f(self.S_PROJ, B, D),
-                  h=f(B, 4 * D), fc2=f(self.S_FC2, B, D), logit=f(self.S_HEAD, B, self.Vpad),
+                  resid=f(B, D), qkv=f(B, 3 * D), y=f(B, D), h=f(B, 4 * D), logit=f(B, self.Vpad),
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32))
         self._state = st
@@ -143,9 +133,9 @@ class CondTupleGPT:
         return st
 
     # ------------------------------------------------------------------ C-ABI wrappers
-    def _skinny(self, x, wp, bias, out, M, N, K, S, ldo, epi):
-        fn = L.lib().sfmi_skinny16_gemm_f32 if self._fmt == 16 else L.lib().sfmi_skinny_gemm_f32
-        L.check(fn(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), M, N, K, S, ldo, epi, L.stream_ptr()), "sfmi_skinny_gemm_f32")
+    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act):
+        L.check(L.lib().sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
+                                             ln, act, L.stream_ptr()), "sfmi_decode_gemm_f32")
 
     def _rowprep(self, resid_in, part, bias, S, M, resid_out, xn, ln, Eadd=None, P=0, st=None):
         L.check(L.lib().sfmi_gpt_rowprep_f32(L.ptr(resid_in), L.ptr(part), L.ptr(bias), L.ptr(Eadd),
@@ -157,7 +147,8 @@ class CondTupleGPT:
     def _embed(self, st, B, P, resid, xn, ln):
         L.check(L.lib().sfmi_gpt_embed_f32(L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb),
                                            L.ptr(self.cond_pos_emb), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
-                                           L.ptr(resid), L.ptr(xn), L.ptr(ln[0]), L.ptr(ln[1]), B, P, self.D, self.Lmax + 1,
+                                           L.ptr(resid), L.ptr(xn), L.ptr(ln[0]) if ln else None, L.ptr(ln[1]) if ln else None,
+                                           B, P, self.D, self.Lmax + 1,
                                            self.end[0], L.stream_ptr()), "sfmi_gpt_embed_f32")
 
     def _gemm(self, x, w, bias, resid, y, M, N, K, act=0, og=0, ogs=0):
@@ -189,34 +180,32 @@ class CondTupleGPT:
 
     # ------------------------------------------------------------------ one decode step (graph-capturable)
     def decode_step(self, st, B, sp):
+        """Position t = len[b]-1 of every row through both stages; st["resid"] must hold its embedding on entry
+        (written by the previous step's sampler tail, or by `_embed` before the first step)."""
         D = self.D
         lib = L.lib()
-        self._embed(st, B, 0, st["resid"], st["xn"], self.layers[0].ln1)
+        r = st["resid"]
         for li, ly in enumerate(self.layers):
-            self._skinny(st["xn"], ly.pqkv, None, st["qkv"], B, 3 * D, D, self.S_QKV, 3 * D, 0)
-            L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(ly.bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
-                                                 L.ptr(st["len"]), L.ptr(st["y"]), self.S_QKV, B, D, self.H, self.Lmax + 1,
+            self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0)
+            L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
+                                                 L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
                                                  L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
-            self._skinny(st["y"], ly.pproj, None, st["proj"], B, D, D, self.S_PROJ, D, 0)
-            self._rowprep(st["resid"], st["proj"], ly.bproj, self.S_PROJ, B, st["resid"], st["xn"], ly.ln2)
-            self._skinny(st["xn"], ly.pfc1, ly.bfc1, st["h"], B, 4 * D, D, 1, 4 * D, 1)
-            self._skinny(st["h"], ly.pfc2, None, st["fc2"], B, D, 4 * D, self.S_FC2, D, 0)
-            last_of_stage = li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage
-            ln_next = self.head_ln[ly.stage] if last_of_stage else self.layers[li + 1].ln1
-            self._rowprep(st["resid"], st["fc2"], ly.bfc2, self.S_FC2, B, st["resid"], st["xn"], ln_next)
-            if last_of_stage:
+            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0)
+            self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1)
+            self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0)
+            if li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage:
                 s = ly.stage
-                self._skinny(st["xn"], self.head_p[s], None, st["logit"], B, self.V, D, self.S_HEAD, self.Vpad, 0)
+                hp, hc1, hc2 = self.head_f[s]
+                self._dgemm(r, hp, hc1, hc2, None, st["logit"], B, self.V, D, self.Vpad, 1, 0)
                 hist = sp["hist"][s] if sp.get("hist") is not None else None
                 L.check(lib.sfmi_gpt_sample_f32(L.ptr(st["logit"]), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
-                                                L.ptr(st["logp"]), L.ptr(hist), L.ptr(sp.get("force")), self.S_HEAD, B, self.V, self.Vpad, self.Lmax + 1,
+                                                L.ptr(st["logp"]), L.ptr(hist), L.ptr(sp.get("force")),
+                                                L.ptr(r), L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb), D,
+                                                1, B, self.V, self.Vpad, self.Lmax + 1,
                                                 s, self.end[0], self.end[1], sp["top_k"], sp["top_p"], sp["temperature"],
                                                 int(sp["best_in_first"]), int(sp["mask_invalid"]),
                                                 int(sp["mask_invalid_completion"]), sp["max_steps"], sp["seed"], int(s == 1),
                                                 L.stream_ptr()), "sfmi_gpt_sample_f32")
-                if s == 0:
-                    self._rowprep(st["resid"], None, None, 0, B, st["resid"], st["xn"], self.layers[li + 1].ln1,
-                                  Eadd=self.E[0], st=st)
 
     # ------------------------------------------------------------------ sample_indices
     @torch.no_grad()
@@ -254,13 +243,14 @@ class CondTupleGPT:
         P = Lc_max - 1
         if P > 0:
             self.prefill(st, B, P)
+        self._embed(st, B, 0, st["resid"], None, None)   # embedding of the last condition token (step-0 input)
         done = 0
         if use_graph and steps > 1:
             gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force"))), return_logits)
             if self._graph is None or self._graph[0] != gkey or return_logits:
                 side = torch.cuda.Stream(device=self.dev)
                 side.wait_stream(torch.cuda.current_stream())
-                saved = {k: st[k].clone() for k in ("seq", "len", "logp")}
+                saved = {k: st[k].clone() for k in ("seq", "len", "logp", "resid")}
                 with torch.cuda.stream(side):
                     self.decode_step(st, B, sp)      # warm-up outside capture
                 torch.cuda.current_stream().wait_stream(side)
