@@ -81,7 +81,7 @@ def kernel_rooflines(vq, gpt, B, dev):
             ("dgemm proj (1024->1024+resid)", "pproj", None, "bproj", st["y"], r, r, D, D, D, 0, 0)):
         def body():
             for l in gpt.layers:
-                gpt._dgemm(xin, getattr(l, attr), getattr(l, c1a) if c1a else None, getattr(l, c2a), res, outb, B, N, K, ldo, ln, act)
+                gpt._dgemm(xin, getattr(l, attr), getattr(l, c1a) if c1a else None, getattr(l, c2a), res, outb, B, N, K, ldo, ln, act, 1)
         body()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

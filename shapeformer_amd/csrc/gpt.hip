@@ -258,8 +258,16 @@ __global__ __launch_bounds__(64 * NW) void skinny16_gemm_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------
 struct DGemmArgs {
   const float* x; const float* Wp; const float* c1; const float* c2; const float* resid; float* out;
-  int M, N, K, ldo, ln, act;
+  int M, N, K, ldo /*row stride when out is row-major (out_packed == 0)*/, ln, act, out_packed;
 };
+
+// Decode activations live in MFMA-fragment-packed layout: an (M x N) tensor is stored as
+// [ceil(M/16)][N/16][64 lanes][4] with lane = ((n>>2)&3)*16 + (m&15), j = n&3.  That is simultaneously the
+// 16x16x4 C/D register layout of the producing GEMM (store index == lane) and the B-operand fragment of the
+// consuming GEMM (k == n), so every activation load/store of the decode step is a 1 KiB contiguous wave access.
+__device__ __host__ __forceinline__ long long pk_off(int m, int n, int N) {
+  return ((((long long)(m >> 4) * (N >> 4) + (n >> 4)) * 64 + ((n >> 2) & 3) * 16 + (m & 15)) << 2) + (n & 3);
+}
 
 template <int MT, int NW>
 __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
@@ -271,13 +279,9 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   const int kw = a.K / NW;
   const int k0 = wave * kw;
   const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)nt * (a.K / 16) + k0 / 16) * 64 + lane;
-  const float* xr[MT];
+  const f32x4* xr[MT];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    int m = j * 16 + ml;
-    if (m >= a.M) m = a.M - 1;
-    xr[j] = a.x + (long long)m * a.K + k0 + 4 * q;
-  }
+  for (int j = 0; j < MT; ++j) xr[j] = reinterpret_cast<const f32x4*>(a.x) + ((long long)j * (a.K / 16) + k0 / 16) * 64 + lane;
   f32x4 acc[MT];
   float s1[MT], s2[MT];
 #pragma unroll
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
       const int st = (s0 + u < steps) ? s0 + u : steps - 1;
       w[u] = wp[st * 64];
 #pragma unroll
-      for (int j = 0; j < MT; ++j) xb[u][j] = *reinterpret_cast<const f32x4*>(xr[j] + st * 16);
+      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][st * 64];
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
       for (int e = 0; e < 4; ++e) r[e] += red[w][j][e][lane];
     const int m = j * 16 + ml;
     const int n = nt * 16 + 4 * q;
-    if (m < a.M && n < a.N) {
+    if ((a.out_packed || m < a.M) && n < a.N) {
       if (a.ln) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -345,9 +349,9 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
       }
-      float* o = a.out + (long long)m * a.ldo + n;
-      if (a.resid) r = r + *reinterpret_cast<const f32x4*>(a.resid + (long long)m * a.ldo + n);
-      *reinterpret_cast<f32x4*>(o) = r;
+      const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
+      if (a.resid) r = r + *reinterpret_cast<const f32x4*>(a.resid + off);
+      *reinterpret_cast<f32x4*>(a.out + off) = r;
     }
   }
 }
@@ -359,8 +363,8 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 // flight per lane (unrolled), all 16 waves of the workgroup stream disjoint keys.
 // ------------------------------------------------------------------------------------------------
 #define ATT_WAVES 16
-__global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restrict__ qkv_part /*(S,M,3D) q|k|v*/,
-                                                           const float* __restrict__ bqkv /*(3D)*/, float* __restrict__ Kc,
+__global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restrict__ qkv_part /*packed (M x 3D) q|k|v*/,
+                                                           const float* __restrict__ bqkv /*unused*/, float* __restrict__ Kc,
                                                            float* __restrict__ Vc /*(B,H,Lmax,HD)*/, const int* __restrict__ len,
                                                            float* __restrict__ y /*(M,D)*/, int S, int M, int D, int Lmax,
                                                            int HD, float scale) {
@@ -371,11 +375,10 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
   float* Kb = Kc + ((long long)b * H + h) * Lmax * HD;
   float* Vb = Vc + ((long long)b * H + h) * Lmax * HD;
   if (tid < HD) {
-    float q = bqkv[h * HD + tid], k = bqkv[D + h * HD + tid], v = bqkv[2 * D + h * HD + tid];
-    for (int s = 0; s < S; ++s) {
-      const float* p = qkv_part + ((long long)s * M + b) * 3 * D + h * HD + tid;
-      q += p[0]; k += p[D]; v += p[2 * D];
-    }
+    // qkv is the fragment-packed (M x 3D) output of the fused LN+QKV GEMM (bias already included)
+    const float q = qkv_part[pk_off(b, h * HD + tid, 3 * D)];
+    const float k = qkv_part[pk_off(b, D + h * HD + tid, 3 * D)];
+    const float v = qkv_part[pk_off(b, 2 * D + h * HD + tid, 3 * D)];
     qs[tid] = q * scale; kn[tid] = k; vn[tid] = v;
     Kb[(long long)t * HD + tid] = k;
     Vb[(long long)t * HD + tid] = v;
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
     float o = 0.f, l = 0.f;
 #pragma unroll
     for (int w = 0; w < ATT_WAVES; ++w) { o += yacc[w][tid]; l += red[ATT_WAVES + w]; }
-    y[(long long)b * D + h * HD + tid] = o / l;
+    y[pk_off(b, h * HD + tid, D)] = o / l;   // fragment-packed (M x D)
   }
 }
 
@@ -727,10 +730,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   // ---- fused tails --------------------------------------------------------------------------
   if (a.resid) {
     const int nq = a.D / 4;
-    f32x4* rr = reinterpret_cast<f32x4*>(a.resid + (long long)b * a.D);
     if (a.tuple_i == 0) {
       const f32x4* e0 = reinterpret_cast<const f32x4*>(a.E0 + (long long)choice * a.D);
-      for (int qd = tid; qd < nq; qd += 256) rr[qd] = rr[qd] + e0[qd];
+      for (int qd = tid; qd < nq; qd += 256) {
+        f32x4* rr = reinterpret_cast<f32x4*>(a.resid + pk_off(b, 4 * qd, a.D));
+        *rr = *rr + e0[qd];
+      }
     } else {
       const int pos = cur_pos, val = choice, t = L;  // the token at position L is now complete
       int ext;
@@ -744,9 +749,36 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       const f32x4* e1 = reinterpret_cast<const f32x4*>(a.E1 + (long long)val * a.D);
       const f32x4* ex = reinterpret_cast<const f32x4*>(a.Ex + (long long)ext * a.D);
       const f32x4* pe = reinterpret_cast<const f32x4*>(a.pos_emb + (long long)(t - lc) * a.D);
-      for (int qd = tid; qd < nq; qd += 256) rr[qd] = ((e0[qd] + e1[qd]) + ex[qd]) + pe[qd];
+      for (int qd = tid; qd < nq; qd += 256)
+        *reinterpret_cast<f32x4*>(a.resid + pk_off(b, 4 * qd, a.D)) = ((e0[qd] + e1[qd]) + ex[qd]) + pe[qd];
     }
   }
+}
+
+// embedding of the token at position len[b]-1 (mingpt.py:256-286 + AR_N extra index) -> fragment-packed resid
+__global__ __launch_bounds__(256) void embed_packed_kernel(const float* __restrict__ E0, const float* __restrict__ E1,
+                                                           const float* __restrict__ Ex, const float* __restrict__ pos_emb,
+                                                           const float* __restrict__ cond_pos_emb, const int* __restrict__ seq,
+                                                           const int* __restrict__ len, const int* __restrict__ Lc,
+                                                           float* __restrict__ resid, int D, int Lmax, int end0) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int t = len[b] - 1, lc = Lc[b];
+  const int* row = seq + (long long)b * Lmax * 2;
+  const int pos = row[2 * t], val = row[2 * t + 1];
+  int ext;
+  if (t < lc) ext = pos;
+  else if (pos == end0) ext = end0;
+  else {
+    int lo = 0, hi = lc;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (row[2 * mid] > pos) hi = mid; else lo = mid + 1; }
+    ext = row[2 * (lo < lc ? lo : lc - 1)];
+  }
+  const f32x4* e0 = reinterpret_cast<const f32x4*>(E0 + (long long)pos * D);
+  const f32x4* e1 = reinterpret_cast<const f32x4*>(E1 + (long long)val * D);
+  const f32x4* ex = reinterpret_cast<const f32x4*>(Ex + (long long)ext * D);
+  const f32x4* pe = reinterpret_cast<const f32x4*>(t < lc ? cond_pos_emb + (long long)t * D : pos_emb + (long long)(t - lc) * D);
+  for (int qd = tid; qd < D / 4; qd += 256)
+    *reinterpret_cast<f32x4*>(resid + pk_off(b, 4 * qd, D)) = ((e0[qd] + e1[qd]) + ex[qd]) + pe[qd];
 }
 
 __global__ void set_len_kernel(int* len, const int* src, int B, int delta) {
@@ -830,11 +862,15 @@ int sfmi_skinny16_gemm_f32(const float* x, const float* Wp16, const float* bias,
 // replaces LayerNorm + nn.Linear (+GELU / +residual) of Block.forward at decode time (mingpt.py:103-111).
 // Wp16: sfmi_skinny16_pack_weight of W (plain) or of W*diag(gamma) (ln=1, with c1/c2 as in the kernel header).
 // c1/c2 need ceil(N/16)*16 readable floats.  resid (if given) is added and shares out's (M,ldo) layout.
+// x (and out/resid when out_packed) are fragment-packed [ceil(M/16)][N/16][64][4] (see pk_off); out_packed == 0
+// writes row-major (M,ldo) (used for the logits handed to the sampler).
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
-                         float* out, int M, int N, int K, int ldo, int ln, int act, void* stream) {
+                         float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, void* stream) {
   if (!x || !Wp16 || !out || M <= 0 || M > 64 || K % (K >= 2048 ? 256 : 128) || (ln && !c1)) return SFMI_EINVAL;
+  if (out_packed && N % 16) return SFMI_EINVAL;
   DGemmArgs a;
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
+  a.out_packed = out_packed;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((N + 15) / 16);
   const int MT = (M + 15) / 16;
@@ -915,6 +951,17 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
   a.top_p = top_p; a.temperature = temperature; a.seed = seed;
   const size_t dyn = (top_k <= 0 || top_k > SMP_MAXC) ? (size_t)SMP_BIG * 12 : 0;
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), dyn, (hipStream_t)stream, a);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// decode-path embedding into the fragment-packed residual buffer (input of the first decode step)
+int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
+                              const int* seq, const int* len, const int* Lc, float* resid, int B, int D, int Lmax, int end0,
+                              void* stream) {
+  if (!E0 || !E1 || !Ex || !pos_emb || !cond_pos_emb || !seq || !len || !Lc || !resid || D % 16) return SFMI_EINVAL;
+  hipLaunchKernelGGL(embed_packed_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, E0, E1, Ex, pos_emb, cond_pos_emb, seq, len, Lc,
+                     resid, D, Lmax, end0);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

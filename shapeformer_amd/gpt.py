@@ -122,10 +122,12 @@ class CondTupleGPT:
             return self._state
         dev, D = self.dev, self.D
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        Bp = (B + 15) // 16 * 16   # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off)
         st = dict(key=key,
                   seq=torch.zeros(B, self.Lmax + 1, 2, device=dev, dtype=torch.int32),
                   len=torch.zeros(B, device=dev, dtype=torch.int32), Lc=torch.zeros(B, device=dev, dtype=torch.int32),
-                  resid=f(B, D), qkv=f(B, 3 * D), y=f(B, D), h=f(B, 4 * D), logit=f(B, self.Vpad),
+                  resid=torch.zeros(Bp, D, device=dev), qkv=torch.zeros(Bp, 3 * D, device=dev), y=torch.zeros(Bp, D, device=dev),
+                  h=torch.zeros(Bp, 4 * D, device=dev), logit=f(B, self.Vpad),
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32))
         self._state = st
@@ -133,9 +135,9 @@ class CondTupleGPT:
         return st
 
     # ------------------------------------------------------------------ C-ABI wrappers
-    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act):
+    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act, packed=1):
         L.check(L.lib().sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
-                                             ln, act, L.stream_ptr()), "sfmi_decode_gemm_f32")
+                                             ln, act, packed, L.stream_ptr()), "sfmi_decode_gemm_f32")
 
     def _rowprep(self, resid_in, part, bias, S, M, resid_out, xn, ln, Eadd=None, P=0, st=None):
         L.check(L.lib().sfmi_gpt_rowprep_f32(L.ptr(resid_in), L.ptr(part), L.ptr(bias), L.ptr(Eadd),
@@ -196,7 +198,7 @@ class CondTupleGPT:
             if li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage:
                 s = ly.stage
                 hp, hc1, hc2 = self.head_f[s]
-                self._dgemm(r, hp, hc1, hc2, None, st["logit"], B, self.V, D, self.Vpad, 1, 0)
+                self._dgemm(r, hp, hc1, hc2, None, st["logit"], B, self.V, D, self.Vpad, 1, 0, packed=0)
                 hist = sp["hist"][s] if sp.get("hist") is not None else None
                 L.check(lib.sfmi_gpt_sample_f32(L.ptr(st["logit"]), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
                                                 L.ptr(st["logp"]), L.ptr(hist), L.ptr(sp.get("force")),
@@ -243,7 +245,11 @@ class CondTupleGPT:
         P = Lc_max - 1
         if P > 0:
             self.prefill(st, B, P)
-        self._embed(st, B, 0, st["resid"], None, None)   # embedding of the last condition token (step-0 input)
+        # embedding of the last condition token (step-0 input) into the fragment-packed residual buffer
+        L.check(L.lib().sfmi_gpt_embed_packed_f32(L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb),
+                                                  L.ptr(self.cond_pos_emb), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
+                                                  L.ptr(st["resid"]), B, self.D, self.Lmax + 1, self.end[0], L.stream_ptr()),
+                "sfmi_gpt_embed_packed_f32")
         done = 0
         if use_graph and steps > 1:
             gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force"))), return_logits)
