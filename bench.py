@@ -74,21 +74,21 @@ def kernel_rooflines(vq, gpt, B, dev):
     # transformer layer (24 different weight matrices back-to-back, exactly as in the real step, so the 256 MB
     # Infinity Cache cannot serve them); algorithmic bytes = N*K*4 weights + M*K*4 activations + M*N*4 outputs.
     r = st["resid"]
-    for nm, attr, c1a, c2a, xin, res, outb, N, K, ldo, ln, act in (
-            ("dgemm fc1 (LN+1024->4096+GELU)", "pfc1", "c1fc1", "c2fc1", r, None, st["h"], 4 * D, D, 4 * D, 1, 1),
-            ("dgemm fc2 (4096->1024+resid)", "pfc2", None, "bfc2", st["h"], r, r, D, 4 * D, D, 0, 0),
-            ("dgemm qkv (LN+1024->3072)", "pqkv", "c1qkv", "c2qkv", r, None, st["qkv"], 3 * D, D, 3 * D, 1, 0),
-            ("dgemm proj (1024->1024+resid)", "pproj", None, "bproj", st["y"], r, r, D, D, D, 0, 0)):
+    for nm, attr, c1a, c2a, xin, res, outb, N, K, ldo, ln, act, S in (
+            ("dgemm fc1 (LN+1024->4096+GELU)", "pfc1", "c1fc1", "c2fc1", r, None, st["h"], 4 * D, D, 4 * D, 1, 1, 1),
+            ("dgemm fc2 (4096->1024+resid)", "pfc2", None, "bfc2", st["h"], r, r, D, 4 * D, D, 0, 0, gpt.S_FC2),
+            ("dgemm qkv (LN+1024->3072)", "pqkv", "c1qkv", "c2qkv", r, None, st["qkv"], 3 * D, D, 3 * D, 1, 0, 1),
+            ("dgemm proj (1024->1024+resid)", "pproj", None, "bproj", st["y"], r, r, D, D, D, 0, 0, gpt.S_PROJ)):
         def body():
             for l in gpt.layers:
-                gpt._dgemm(xin, getattr(l, attr), getattr(l, c1a) if c1a else None, getattr(l, c2a), res, outb, B, N, K, ldo, ln, act, 1)
+                gpt._dgemm(xin, getattr(l, attr), getattr(l, c1a) if c1a else None, getattr(l, c2a), res, outb, B, N, K, ldo, ln, act, 1, S)
         body()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             body()
         ms = ev_time(g.replay, 10) / len(gpt.layers)
-        add(nm, ms, "hbm", N * K * 4 + B * K * 4 + B * N * 4, 1e9, HBM, "GB/s", f"M={B}, {len(gpt.layers)} layers/graph")
+        add(nm, ms, "hbm", N * K * 4 + B * K * 4 + B * N * 4, 1e9, HBM, "GB/s", f"M={B}, split-K {S}, {len(gpt.layers)} layers/graph")
     # SDF query (north-star kernel): MFMA-bound, 31 488 FLOP/pt
     Q = 128
     grid = torch.randn(B, 64, 64, 64, 32, device=dev)

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(64 * NW) void skinny16_gemm_kernel(const float* __r
 struct DGemmArgs {
   const float* x; const float* Wp; const float* c1; const float* c2; const float* resid; float* out;
   int M, N, K, ldo /*row stride when out is row-major (out_packed == 0)*/, ln, act, out_packed;
+  float* slab; int* cnt;   // split-K scratch: ceil(M/16)*ceil(N/16)*S*320 floats, ceil(M/16)*ceil(N/16) ints (zeroed once)
 };
 
 // Decode activations live in MFMA-fragment-packed layout: an (M x N) tensor is stored as
@@ -269,23 +270,39 @@ __device__ __host__ __forceinline__ long long pk_off(int m, int n, int N) {
   return ((((long long)(m >> 4) * (N >> 4) + (n >> 4)) * 64 + ((n >> 2) & 3) * 16 + (m & 15)) << 2) + (n & 3);
 }
 
+// 8-byte agent-scope relaxed atomics lower to sc1 (write-through / L1-bypassing) accesses on gfx950: the
+// placement-independent hand-off form for small split-K slabs (no release/acquire fences needed).
+__device__ __forceinline__ void st_sc1(float* p, f32x4 v) {
+  unsigned long long lo = ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]);
+  unsigned long long hi = ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 ld_sc1(const float* p) {
+  unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+               __uint_as_float((unsigned)(hi >> 32))};
+}
+
 template <int MT, int NW>
 __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float red[NW][MT][4][64];
   __shared__ float st1[NW][MT][16], st2[NW][MT][16];
   constexpr int UN = (MT == 1) ? 8 : (MT == 2 ? 4 : 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
-  const int nt = blockIdx.x;
-  const int kw = a.K / NW;
-  const int k0 = wave * kw;
+  const int nt = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+  const int kslice = a.K / S;
+  const int kw = kslice / NW;
+  const int k0 = sp * kslice + wave * kw;
   const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)nt * (a.K / 16) + k0 / 16) * 64 + lane;
   const f32x4* xr[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) xr[j] = reinterpret_cast<const f32x4*>(a.x) + ((long long)j * (a.K / 16) + k0 / 16) * 64 + lane;
-  f32x4 acc[MT];
+  f32x4 acc[MT][2];
   float s1[MT], s2[MT];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < MT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = acc[j][0]; s1[j] = 0.f; s2[j] = 0.f; }
   const int steps = kw / 16;
   for (int s0 = 0; s0 < steps; s0 += UN) {
     f32x4 w[UN], xb[UN][MT];
@@ -307,15 +324,17 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
             s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][e], xv[e], acc[j], 0, 0, 0);
+          for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
+            acc[j][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][e], xv[e], acc[j][e & 1], 0, 0, 0);
         }
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
+    const f32x4 t = acc[j][0] + acc[j][1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][j][r][lane] = acc[j][r];
+    for (int r = 0; r < 4; ++r) red[wave][j][r][lane] = t[r];
     if (a.ln) {
       float t1 = s1[j], t2 = s2[j];
       t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
@@ -331,13 +350,41 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     for (int w = 0; w < NW; ++w)
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] += red[w][j][e][lane];
+    float t1 = 0.f, t2 = 0.f;
+    if (a.ln) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { t1 += st1[w][j][ml]; t2 += st2[w][j][ml]; }
+    }
+    if (S > 1) {
+      // split-K: publish this slice's slab write-through, take a ticket; the last arriver of the (nt, j) tile
+      // sums the S slabs in slice order (deterministic) and runs the epilogue.
+      const long long tile = (long long)j * gridDim.x + nt;
+      float* slab = a.slab + (tile * S + sp) * 320;          // 256 acc floats + 64 stat floats
+      st_sc1(slab + lane * 4, r);
+      if (a.ln && q == 0) {
+        __hip_atomic_store(slab + 256 + ml, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slab + 272 + ml, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int ticket = 0;
+      if (lane == 0) ticket = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __shfl(ticket, 0, 64);
+      if (ticket != S - 1) continue;
+      if (lane == 0) __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+      r = f32x4{0.f, 0.f, 0.f, 0.f}; t1 = 0.f; t2 = 0.f;
+      const float* base = a.slab + tile * S * 320;
+      for (int s = 0; s < S; ++s) {
+        r = r + ld_sc1(base + s * 320 + lane * 4);
+        if (a.ln) {
+          t1 += __hip_atomic_load(base + s * 320 + 256 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t2 += __hip_atomic_load(base + s * 320 + 272 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
     const int m = j * 16 + ml;
     const int n = nt * 16 + 4 * q;
     if ((a.out_packed || m < a.M) && n < a.N) {
       if (a.ln) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { t1 += st1[w][j][ml]; t2 += st2[w][j][ml]; }
         const float mean = t1 / (float)a.K;
         const float var = fmaxf(t2 / (float)a.K - mean * mean, 0.f);
         const float rstd = rsqrtf(var + 1e-5f);
@@ -863,21 +910,27 @@ int sfmi_skinny16_gemm_f32(const float* x, const float* Wp16, const float* bias,
 // Wp16: sfmi_skinny16_pack_weight of W (plain) or of W*diag(gamma) (ln=1, with c1/c2 as in the kernel header).
 // c1/c2 need ceil(N/16)*16 readable floats.  resid (if given) is added and shares out's (M,ldo) layout.
 // x (and out/resid when out_packed) are fragment-packed [ceil(M/16)][N/16][64][4] (see pk_off); out_packed == 0
-// writes row-major (M,ldo) (used for the logits handed to the sampler).
+// writes row-major (M,ldo) (used for the logits handed to the sampler).  S > 1 splits K across S workgroups per
+// n-tile with an in-kernel deterministic last-arriver reduction (slab/cnt scratch, cnt zero-initialised ONCE).
+size_t sfmi_decode_gemm_slab_floats(int M, int N, int S) { return (size_t)((M + 15) / 16) * ((N + 15) / 16) * S * 320; }
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
-                         float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 64 || K % (K >= 2048 ? 256 : 128) || (ln && !c1)) return SFMI_EINVAL;
+                         float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
+                         int* cnt, void* stream) {
+  if (!x || !Wp16 || !out || M <= 0 || M > 64 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
   if (out_packed && N % 16) return SFMI_EINVAL;
+  if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
+  const int kslice = K / S;
+  const int NWv = kslice >= 2048 ? 16 : 8;
+  if (kslice % (16 * NWv)) return SFMI_EINVAL;
   DGemmArgs a;
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
-  a.out_packed = out_packed;
+  a.out_packed = out_packed; a.slab = slab; a.cnt = cnt;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((N + 15) / 16);
+  dim3 grid((N + 15) / 16, S);
   const int MT = (M + 15) / 16;
-  const bool big = K >= 2048;   // 16 waves for the K = 4096 down-projection, 8 otherwise
 #define DG(MT_, NW_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_>), grid, dim3(64 * NW_), 0, st, a)
-  if (big) { if (MT == 1) DG(1, 16); else if (MT == 2) DG(2, 16); else if (MT == 3) DG(3, 16); else DG(4, 16); }
-  else     { if (MT == 1) DG(1, 8);  else if (MT == 2) DG(2, 8);  else if (MT == 3) DG(3, 8);  else DG(4, 8); }
+  if (NWv == 16) { if (MT == 1) DG(1, 16); else if (MT == 2) DG(2, 16); else if (MT == 3) DG(3, 16); else DG(4, 16); }
+  else           { if (MT == 1) DG(1, 8);  else if (MT == 2) DG(2, 8);  else if (MT == 3) DG(3, 8);  else DG(4, 8); }
 #undef DG
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;

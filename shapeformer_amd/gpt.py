@@ -49,6 +49,8 @@ class _Layer:
 
 
 class CondTupleGPT:
+    S_PROJ, S_FC2 = 4, 4   # in-kernel split-K of the N = n_embd GEMMs (64 n-tiles -> 256 workgroups)
+
     def __init__(self, state_dict=None, n_embd=1024, n_head=16, n_layers=(20, 4), block_size=812,
                  vocab_sizes=(4097, 4097), extra_vocab_sizes=(4097,), end_tokens=(4096, 4096), device="cuda:0",
                  tuple_n=2, **_ignored):
@@ -128,6 +130,7 @@ class CondTupleGPT:
                   len=torch.zeros(B, device=dev, dtype=torch.int32), Lc=torch.zeros(B, device=dev, dtype=torch.int32),
                   resid=torch.zeros(Bp, D, device=dev), qkv=torch.zeros(Bp, 3 * D, device=dev), y=torch.zeros(Bp, D, device=dev),
                   h=torch.zeros(Bp, 4 * D, device=dev), logit=f(B, self.Vpad),
+                  slab=f(L.lib().sfmi_decode_gemm_slab_floats(Bp, 4 * D, 4)), cnt=torch.zeros(Bp // 16 * (4 * D // 16 + 1), device=dev, dtype=torch.int32),
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32))
         self._state = st
@@ -135,9 +138,13 @@ class CondTupleGPT:
         return st
 
     # ------------------------------------------------------------------ C-ABI wrappers
-    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act, packed=1):
+    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act, packed=1, S=1):
+        st = self._state
+        while S > 1 and (K // S) % 128:
+            S //= 2
         L.check(L.lib().sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
-                                             ln, act, packed, L.stream_ptr()), "sfmi_decode_gemm_f32")
+                                             ln, act, packed, S, L.ptr(st["slab"]) if S > 1 else None,
+                                             L.ptr(st["cnt"]) if S > 1 else None, L.stream_ptr()), "sfmi_decode_gemm_f32")
 
     def _rowprep(self, resid_in, part, bias, S, M, resid_out, xn, ln, Eadd=None, P=0, st=None):
         L.check(L.lib().sfmi_gpt_rowprep_f32(L.ptr(resid_in), L.ptr(part), L.ptr(bias), L.ptr(Eadd),
@@ -192,9 +199,9 @@ class CondTupleGPT:
             L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
                                                  L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
                                                  L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
-            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0)
+            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=self.S_PROJ)
             self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1)
-            self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0)
+            self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=self.S_FC2)
             if li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage:
                 s = ly.stage
                 hp, hc1, hc2 = self.head_f[s]
