@@ -16,6 +16,7 @@
 //             common.py:260-299) fused per row: radix-select top-k, bitonic sort of the candidates,
 //             top-p cut, counter-hash uniforms (no host RNG, no per-step D2H of (B,4097) logits)
 #include "sfmi_common.h"
+#include <stdlib.h>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -285,11 +286,12 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
                __uint_as_float((unsigned)(hi >> 32))};
 }
 
-template <int MT, int NW>
+// UN = loads in flight per wave per operand; the host picks UN | steps so the unrolled batches carry NO per-element
+// conditions (a runtime select around a load makes hipcc wait vmcnt(0) per element - guide §5 trap 4c).
+template <int MT, int NW, int UN>
 __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float red[NW][MT][4][64];
   __shared__ float st1[NW][MT][16], st2[NW][MT][16];
-  constexpr int UN = (MT == 1) ? 8 : (MT == 2 ? 4 : 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
   const int nt = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
   const int kslice = a.K / S;
@@ -303,30 +305,40 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   float s1[MT], s2[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = acc[j][0]; s1[j] = 0.f; s2[j] = 0.f; }
+  // epilogue operands are fetched NOW (wave j owns m-tile j) so that no dependent global round trip is left
+  // after the weight stream: the memory system is saturated by then and a late load costs ~1.5 us.
+  f32x4 pc1 = {0.f, 0.f, 0.f, 0.f}, pc2 = pc1, pres = pc1;
+  const int n_ep = nt * 16 + 4 * q;
+  const long long off_ep = a.out_packed ? (((long long)wave * (a.N >> 4) + nt) * 64 + lane) * 4
+                                        : (long long)min(wave * 16 + ml, a.M - 1) * a.ldo + n_ep;
+  if (wave < MT && n_ep < a.N) {
+    if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
+    if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
+    if (a.resid) pres = *reinterpret_cast<const f32x4*>(a.resid + off_ep);
+  }
   const int steps = kw / 16;
   for (int s0 = 0; s0 < steps; s0 += UN) {
     f32x4 w[UN], xb[UN][MT];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int st = (s0 + u < steps) ? s0 + u : steps - 1;
-      w[u] = wp[st * 64];
+      w[u] = wp[(s0 + u) * 64];
 #pragma unroll
-      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][st * 64];
+      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][(s0 + u) * 64];
     }
+    // keep ALL loads of the batch ahead of the first MFMA: hipcc otherwise sinks each load next to its use
+    // (2-4 loads in flight) and the kernel becomes HBM-latency-bound instead of bandwidth-bound
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (s0 + u < steps) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          const f32x4 xv = xb[u][j];
-          if (a.ln) {
-            s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
-            s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
-          }
+      for (int j = 0; j < MT; ++j) {
+        const f32x4 xv = xb[u][j];
+        // LayerNorm statistics (a few VALU ops; computed unconditionally, only used when a.ln)
+        s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
+        s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
-            acc[j][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][e], xv[e], acc[j][e & 1], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
+          acc[j][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][e], xv[e], acc[j][e & 1], 0, 0, 0);
       }
     }
   }
@@ -388,16 +400,15 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
         const float mean = t1 / (float)a.K;
         const float var = fmaxf(t2 / (float)a.K - mean * mean, 0.f);
         const float rstd = rsqrtf(var + 1e-5f);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(a.c1 + n);
-        r = (r - c1 * mean) * rstd;
+        r = (r - pc1 * mean) * rstd;
       }
-      if (a.c2) r = r + *reinterpret_cast<const f32x4*>(a.c2 + n);
+      if (a.c2) r = r + pc2;
       if (a.act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
       }
       const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
-      if (a.resid) r = r + *reinterpret_cast<const f32x4*>(a.resid + off);
+      if (a.resid) r = r + pres;
       *reinterpret_cast<f32x4*>(a.out + off) = r;
     }
   }
@@ -928,9 +939,14 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((N + 15) / 16, S);
   const int MT = (M + 15) / 16;
-#define DG(MT_, NW_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_>), grid, dim3(64 * NW_), 0, st, a)
-  if (NWv == 16) { if (MT == 1) DG(1, 16); else if (MT == 2) DG(2, 16); else if (MT == 3) DG(3, 16); else DG(4, 16); }
-  else           { if (MT == 1) DG(1, 8);  else if (MT == 2) DG(2, 8);  else if (MT == 3) DG(3, 8);  else DG(4, 8); }
+  const int steps = kslice / NWv / 16;
+  int un = 8 / MT < 1 ? 1 : (MT == 3 ? 2 : 8 / MT);   // UN*MT <= 8 float4 pairs in flight
+  while (un > 1 && steps % un) un >>= 1;
+#define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
+#define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
+  if (NWv == 16) { if (MT == 1) DGU(1, 16); else if (MT == 2) DGU(2, 16); else if (MT == 3) DGU(3, 16); else DGU(4, 16); }
+  else           { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
+#undef DGU
 #undef DG
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;

@@ -49,7 +49,7 @@ class _Layer:
 
 
 class CondTupleGPT:
-    S_PROJ, S_FC2 = 4, 4   # in-kernel split-K of the N = n_embd GEMMs (64 n-tiles -> 256 workgroups)
+    S_PROJ, S_FC2 = 1, 4   # in-kernel split-K of the N = n_embd GEMMs (64 n-tiles -> 256 workgroups)
 
     def __init__(self, state_dict=None, n_embd=1024, n_head=16, n_layers=(20, 4), block_size=812,
                  vocab_sizes=(4097, 4097), extra_vocab_sizes=(4097,), end_tokens=(4096, 4096), device="cuda:0",
