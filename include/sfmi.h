@@ -1,0 +1,115 @@
+/* libsfmi — C ABI of the MI355X-native ShapeFormer hot path (gfx950, HIP).
+ *
+ * Drop-in boundary.  The reference (QhelDIV/ShapeFormer) is pure Python over PyTorch
+ * operators; it has no FFI of its own, so each entry point below names the reference function / third-party
+ * operator call site it replaces (file:line under shapeformer/ in the reference tree).  A reference-side
+ * ctypes binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - the caller owns every buffer; nothing is allocated or freed here; scratch sizes come from *_bytes/_floats;
+ *   - all pointers are DEVICE pointers unless the function is marked [host];
+ *   - `stream` is a hipStream_t (passed as void*); launches are asynchronous on it, no internal sync;
+ *   - returns 0 on success, a negative SFMI_E* code for bad arguments, or a positive hipError_t;
+ *   - no global mutable state; re-entrant for distinct streams and buffers;
+ *   - layouts: feature grids are channels-last (B,D,H,W,C) f32; token buffers are int32; decode activations of the
+ *     transformer are "fragment-packed" [ceil(M/16)][N/16][64][4] (see sfmi_decode_gemm_f32).
+ */
+#ifndef SFMI_H
+#define SFMI_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFMI_OK 0
+#define SFMI_EINVAL (-1)
+
+int sfmi_version(void);
+
+/* ---- VQDIF encoder, per-point path: enc.py:95-140 (LocalPoolPointnet.forward up to scatter_mean), layers.py:39-48,
+ *      vqdif/common.py:260-321, torch_scatter.scatter_max / scatter_mean call sites enc.py:70-74,103-110 ---------- */
+size_t sfmi_enc_pack_floats(void);
+/* [host] fc_pos (64,3)+(64); 5 blocks {fc_0 (32,64)+(32), fc_1 (32,32)+(32), shortcut (32,64)} stacked; fc_c (32,32)+(32) */
+int sfmi_enc_pack_weights(const float* fc_pos_w, const float* fc_pos_b, const float* fc0_w, const float* fc0_b,
+                          const float* fc1_w, const float* fc1_b, const float* sc_w, const float* fc_c_w,
+                          const float* fc_c_b, float* out);
+size_t sfmi_enc_workspace_bytes(int B, int T);
+/* cloud (B,T,3) in [-1,1] -> per-cell mean grid (B,64,64,64,32) + latent occupancy mask (B,R,R,R) u8 [z][y][x] */
+int sfmi_encode_points_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out,
+                           void* workspace, int B, int T, int R, void* stream);
+
+/* ---- Conv3d / GroupNorm / pooling: updown.py:79-132 (Downsampler, Upsampler), unet3d.py:79-144,195-293,449-474 -- */
+int sfmi_conv_pack_weight(const float* w, int Cout, int Cin, int KS, float* out); /* [host] (Cout,Cin,k,k,k)->[tap][Cout][Cin] */
+/* nn.Conv3d with fused input GroupNorm-apply (in_scale/in_shift (B,Cin) or NULL), nearest-x2 input upsample (up=1),
+ * bias, activation (relu: 0 none, 1 ReLU, 2 GELU-erf).  x (B,Di,Hi,Wi,Cin) -> y (B,Do,Ho,Wo,Cout). */
+int sfmi_conv3d_cl_f32(const float* x, const float* wT, const float* in_scale, const float* in_shift, const float* bias,
+                       float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int KS, int stride, int pad, int up,
+                       int relu, void* stream);
+int sfmi_gn_splits(int V);
+/* nn.GroupNorm statistics -> scale/shift (B,C) with GN(x) == x*scale+shift; partial: B*sfmi_gn_splits(V)*C*2 doubles */
+int sfmi_groupnorm_coeffs_f32(const float* x, const float* gamma, const float* beta, float* scale, float* shift,
+                              double* partial, int B, int V, int C, int groups, float eps, void* stream);
+int sfmi_affine_cl_f32(const float* x, const float* scale, const float* shift, float* y, int B, long long V, int C, void* stream);
+int sfmi_maxpool2_cl_f32(const float* x, float* y, int B, int Do, int Ho, int Wo, int C, void* stream); /* unet3d.py:218-237 */
+int sfmi_upcat_cl_f32(const float* skip, const float* low, float* y, int B, int D, int H, int W, int Cs, int Cu, void* stream); /* unet3d.py:268-293 */
+
+/* ---- Vector quantiser: quantizer.py:19-30 (get_code), :47-51 (distances + argmax) ----------------------------- */
+size_t sfmi_vq_pack_floats(int K, int D);
+int sfmi_vq_pack_codebook(const float* W, int K, int D, float* out); /* [host] embedding.weight (K,D) */
+int sfmi_vq_argmin_f32(const float* x, const float* packed, int* idx_out, float* dmin_out, long long N, int K, int D, void* stream);
+int sfmi_vq_gather_f32(const float* W, const int* idx, float* out, long long N, int D, void* stream);
+
+/* ---- Sparse (pos,code) tokens: models/common.py:20-23 (mode), :84-189 (dense<->sparse), vqdif.py:50-58 ---------- */
+int sfmi_mode_i32(const int* idx, long long n, int K, int rows, int* hist, int* mode_out, void* stream);
+int sfmi_apply_mask_i32(const int* idx, const unsigned char* mask, const int* mode, int* out, long long n, int mode_rows, void* stream);
+int sfmi_dense2sparse_i32(const int* q, const int* mode, int mode_per_row, int* tokens, int* len, int B, int ncell, int Lpad,
+                          int max_length, int end0, int end1, void* stream);
+int sfmi_sparse2dense_i32(const int* tokens, const int* start, const int* len, const int* empty, int empty_per_row, int* dense,
+                          int B, int ncell, int Lpad, int end0, int end1, void* stream);
+
+/* ---- CondTupleGPT: transformer/mingpt.py:46-111 (Block), :256-310 (embeddings, two-stage tuple head),
+ *      shapeformer.py:54-123 (sample_indices), representers.py:120-155,188-196,432-442, models/common.py:260-299 ---- */
+/* prefill (M = B*P rows): plain GEMM y[remap(m)] = act(x W^T + bias) + resid */
+int sfmi_gemm_f32(const float* x, const float* W, const float* bias, const float* resid, float* y, long long M, int N, int K,
+                  int act, long long out_group, long long out_group_stride, void* stream);
+int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
+                       const int* seq, const int* len, const int* Lc, float* resid_out, float* xn, const float* gamma,
+                       const float* beta, int B, int P, int D, int Lmax, int end0, void* stream);
+int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* bias, const float* Eadd, const int* seq,
+                         const int* len, const int* Lc, float* resid_out, float* xn, const float* gamma, const float* beta,
+                         int S, int M, int P, int D, int Lmax, void* stream);
+int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* Lc, float* y, int B, int P, int D, int H,
+                              int Lmax, void* stream);
+/* decode step (M = B <= 64 rows) */
+size_t sfmi_skinny16_pack_floats(int N, int K);
+int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out); /* [host] (N,K) -> [N/16][K/16][64][4] */
+size_t sfmi_decode_gemm_slab_floats(int M, int N, int S);
+int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
+                         int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, void* stream);
+int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
+                              const int* seq, const int* len, const int* Lc, float* resid, int B, int D, int Lmax, int end0,
+                              void* stream);
+int sfmi_gpt_attn_decode_f32(const float* qkv_packed, const float* unused, float* Kc, float* Vc, const int* len, float* y_packed,
+                             int S, int B, int D, int H, int Lmax, void* stream);
+int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, float* logp, float* hist, const int* force,
+                        float* resid, const float* E0, const float* E1, const float* Ex, const float* pos_emb, int D, int S,
+                        int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
+                        float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
+                        unsigned seed, int advance, void* stream);
+int sfmi_set_len_i32(int* len, const int* src, int B, int delta, void* stream);
+
+/* ---- Implicit decoder SDF/occupancy query: dec.py:62-100 (grid_sample + 5-block conditioned MLP), layers.py:39-48 - */
+size_t sfmi_sdf_pack_floats(void);
+int sfmi_sdf_pack_weights(const float* fc_p_w, const float* fc_p_b, const float* fc_c_w, const float* fc_c_b,
+                          const float* fc0_w, const float* fc0_b, const float* fc1_w, const float* fc1_b,
+                          const float* fc_out_w, const float* fc_out_b, float* out); /* [host] */
+int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpack, float* out, int B, long long N, int G,
+                       int apply_sigmoid, void* stream);
+/* structured Q^3 lattice of nputil.makeGrid 'ij' (xgutils/nputil.py:618-654) from a Q-entry f32 axis table */
+int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, const float* wpack, float* out, int B, int G,
+                            int apply_sigmoid, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFMI_H */

@@ -50,12 +50,8 @@ PROTOTYPES = {
     "sfmi_sparse2dense_i32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, c_ptr, i32, i32, i32, i32, i32, c_ptr]),
     # transformer
     "sfmi_gemm_f32": (i32, [c_ptr] * 5 + [i64, i32, i32, i32, i64, i64, c_ptr]),
-    "sfmi_skinny_pack_floats": (sz, [i32, i32]),
-    "sfmi_skinny_pack_weight": (i32, [c_ptr, i32, i32, c_ptr]),
-    "sfmi_skinny_gemm_f32": (i32, [c_ptr] * 4 + [i32] * 6 + [c_ptr]),
     "sfmi_skinny16_pack_floats": (sz, [i32, i32]),
     "sfmi_skinny16_pack_weight": (i32, [c_ptr, i32, i32, c_ptr]),
-    "sfmi_skinny16_gemm_f32": (i32, [c_ptr] * 4 + [i32] * 6 + [c_ptr]),
     "sfmi_gpt_embed_f32": (i32, [c_ptr] * 12 + [i32] * 5 + [c_ptr]),
     "sfmi_gpt_rowprep_f32": (i32, [c_ptr] * 11 + [i32] * 5 + [c_ptr]),
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr]),

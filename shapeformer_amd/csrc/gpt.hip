@@ -5,13 +5,12 @@
 // (valid by SURVEY Appendix A11) made of a handful of weight-streaming kernels that read all
 // per-row state (lengths, tokens) from device memory, so one captured hipGraph replays every step:
 //
-//   rowprep   x = resid + sum_s partial[s] + bias (+ token-embedding add) ; LayerNorm -> xn
-//             (mingpt.py:103-111 residual adds, :256-286 embeddings, LN eps 1e-5)
-//   skinny    out[m][n] = sum_k x[m][k] W[n][k]  for M <= 64 rows on f32 MFMA 32x32x2, weights
-//             pre-packed in MFMA-fragment order (every wave-load = 1 KiB contiguous), split-K across
-//             workgroups -> raw partials (deterministic: the consumer sums them in fixed order)
-//   attn      one workgroup per (row, head): new q/k/v from the QKV partials, KV append, softmax(QK^T/8)V
-//             over the row's own cached length (rows are ragged)            (mingpt.py:73-91)
+//   dgemm     LayerNorm-fused weight-streaming GEMM for M <= 64 rows on f32 MFMA 16x16x4 (mingpt.py:103-111):
+//             weights AND activations in MFMA-fragment order (every wave access = 1 KiB contiguous), final
+//             outputs (bias / GELU / residual in the epilogue), optional in-kernel deterministic split-K
+//   attn      one workgroup per (row, head): KV append, softmax(QK^T/8)V over the row's own cached length
+//             (rows are ragged), head-contiguous (B,H,L,64) cache                 (mingpt.py:73-91)
+//   rowprep   prefill only: embeddings / residual / LayerNorm over (B*P) rows (mingpt.py:256-286)
 //   sample    sampling_masker + filter_sampling_logits + inverse-CDF draw   (representers.py:120-155,
 //             common.py:260-299) fused per row: radix-select top-k, bitonic sort of the candidates,
 //             top-p cut, counter-hash uniforms (no host RNG, no per-step D2H of (B,4097) logits)
@@ -116,133 +115,6 @@ __global__ __launch_bounds__(256) void rowprep_kernel(RowPrepArgs a) {
     if (q >= nq) continue;
     const f32x4 g = reinterpret_cast<const f32x4*>(a.gamma)[q], be = reinterpret_cast<const f32x4*>(a.beta)[q];
     reinterpret_cast<f32x4*>(a.xn + (long long)m * a.D)[q] = (v[it] - mean) * rstd * g + be;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// skinny GEMM: out[m][n] = sum_k x[m][k] * W[n][k],  M <= 32*MT rows
-//   Wp packed [N/32][K/8][64][4];  grid (N/32, S);  NW waves split the WG's k-slice; LDS reduce.
-//   epi 0: raw partial -> out[(s*M + m)*ldo + n] ; 1: + bias, GELU(erf) ; 2: + bias   (1,2 need S == 1)
-// ------------------------------------------------------------------------------------------------
-template <int MT, int NW>
-__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
-                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                              int M, int N, int K, int kslice, int ldo, int epi) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NW][MT*16][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, pl = lane & 31;
-  const int nt = blockIdx.x, sp = blockIdx.y;
-  const int kw = kslice / NW;
-  const int k0 = sp * kslice + wave * kw;
-  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((long long)nt * (K / 8) + k0 / 8) * 64 + lane;
-  const float* xr[MT];
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    int m = j * 32 + pl;
-    if (m >= M) m = M - 1;
-    xr[j] = x + (long long)m * K + k0 + 4 * hi;
-  }
-  f32x16 acc[MT];
-#pragma unroll
-  for (int j = 0; j < MT; ++j)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[j][t] = 0.f;
-  const int steps = kw / 8;
-#pragma unroll 4
-  for (int st = 0; st < steps; ++st) {
-    const f32x4 w = wp[st * 64];
-    f32x4 xb[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) xb[j] = *reinterpret_cast<const f32x4*>(xr[j] + st * 8);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) acc[j] = MFMA(w[q], xb[j][q], acc[j]);
-  }
-  // cross-wave reduction through LDS
-#pragma unroll
-  for (int j = 0; j < MT; ++j)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) lds[((wave * MT + j) * 16 + t) * 64 + lane] = acc[j][t];
-  __syncthreads();
-  for (int item = wave; item < MT * 4; item += NW) {
-    const int j = item >> 2, g = item & 3;
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    for (int w = 0; w < NW; ++w)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] += lds[((w * MT + j) * 16 + 4 * g + e) * 64 + lane];
-    const int m = j * 32 + pl;
-    const int n = nt * 32 + 8 * g + 4 * hi;
-    if (m < M && n < N) {
-      if (epi) {
-        r = r + *reinterpret_cast<const f32x4*>(bias + n);
-        if (epi == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
-        }
-      }
-      *reinterpret_cast<f32x4*>(out + ((long long)sp * M + m) * ldo + n) = r;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// skinny GEMM for M <= 16 rows on v_mfma_f32_16x16x4_f32: n-tile = 16 output columns per workgroup
-// (N/16 x S workgroups -> every CU streams weights even for N = 1024), Wp16 packed [N/16][K/16][64][4]
-// (lane (n=l&15, q=l>>4) holds W[n][16*k16 + 4q + j]); each wave issues UN weight + UN activation
-// float4 loads before its MFMAs so that ~UN KiB per wave are in flight.
-// ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void skinny16_gemm_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
-                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                                int M, int N, int K, int kslice, int ldo, int epi) {
-  __shared__ __attribute__((aligned(16))) float red[NW][4][64];
-  constexpr int UN = 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
-  const int nt = blockIdx.x, sp = blockIdx.y;
-  const int kw = kslice / NW;
-  const int k0 = sp * kslice + wave * kw;
-  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((long long)nt * (K / 16) + k0 / 16) * 64 + lane;
-  const int m = ml < M ? ml : M - 1;
-  const float* xr = x + (long long)m * K + k0 + 4 * q;
-  typedef float f32x4_t __attribute__((ext_vector_type(4)));
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  const int steps = kw / 16;
-  for (int s0 = 0; s0 < steps; s0 += UN) {
-    f32x4 w[UN], xb[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int st = (s0 + u < steps) ? s0 + u : steps - 1;
-      w[u] = wp[st * 64];
-      xb[u] = *reinterpret_cast<const f32x4*>(xr + st * 16);
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      if (s0 + u < steps) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][j], xb[u][j], acc, 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
-  __syncthreads();
-  if (wave == 0) {
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] += red[w][e][lane];
-    const int n = nt * 16 + 4 * q;
-    if (ml < M && n < N) {
-      if (epi) {
-        r = r + *reinterpret_cast<const f32x4*>(bias + n);
-        if (epi == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
-        }
-      }
-      *reinterpret_cast<f32x4*>(out + ((long long)sp * M + ml) * ldo + n) = r;
-    }
   }
 }
 
@@ -846,43 +718,7 @@ __global__ void set_len_kernel(int* len, const int* src, int B, int delta) {
 
 extern "C" {
 
-// host: Linear weight (N,K) row-major -> MFMA-fragment order [ceil(N/32)][K/8][64][4] (rows >= N zero)
-size_t sfmi_skinny_pack_floats(int N, int K) { return (size_t)((N + 31) / 32) * 32 * K; }
-int sfmi_skinny_pack_weight(const float* W, int N, int K, float* out) {
-  if (!W || !out || K % 8) return SFMI_EINVAL;
-  const int NT = (N + 31) / 32;
-  for (int nt = 0; nt < NT; ++nt)
-    for (int k8 = 0; k8 < K / 8; ++k8)
-      for (int l = 0; l < 64; ++l) {
-        const int n = nt * 32 + (l & 31);
-        for (int j = 0; j < 4; ++j) {
-          const int k = k8 * 8 + 4 * (l >> 5) + j;
-          out[(((size_t)nt * (K / 8) + k8) * 64 + l) * 4 + j] = n < N ? W[(size_t)n * K + k] : 0.0f;
-        }
-      }
-  return SFMI_OK;
-}
-
-// replaces nn.Linear at decode time (M <= 64 rows). out: (S,M,ldo) raw partials (epi 0) or final (epi 1/2, S==1).
-int sfmi_skinny_gemm_f32(const float* x, const float* Wp, const float* bias, float* out, int M, int N, int K, int S,
-                         int ldo, int epi, void* stream) {
-  if (!x || !Wp || !out || M <= 0 || M > 64 || S <= 0 || K % (8 * S) || (epi && (S != 1 || !bias))) return SFMI_EINVAL;
-  const int NT = (N + 31) / 32;
-  const int kslice = K / S;
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(NT, S);
-  const int MT = M > 32 ? 2 : 1;
-  const int nw = (MT == 1 && kslice % 64 == 0 && kslice >= 512) ? 8 : 4;
-  if (kslice % (8 * nw)) return SFMI_EINVAL;
-  const size_t lds = (size_t)nw * MT * 16 * 64 * 4;
-  if (MT == 1 && nw == 4) hipLaunchKernelGGL((skinny_gemm_kernel<1, 4>), grid, dim3(256), lds, st, x, Wp, bias, out, M, N, K, kslice, ldo, epi);
-  else if (MT == 1) hipLaunchKernelGGL((skinny_gemm_kernel<1, 8>), grid, dim3(512), lds, st, x, Wp, bias, out, M, N, K, kslice, ldo, epi);
-  else hipLaunchKernelGGL((skinny_gemm_kernel<2, 4>), grid, dim3(256), lds, st, x, Wp, bias, out, M, N, K, kslice, ldo, epi);
-  SFMI_CHECK_LAUNCH();
-  return SFMI_OK;
-}
-
-// M <= 16 variant on the 16x16x4 MFMA; Wp16 = [ceil(N/16)][K/16][64][4] (sfmi_skinny16_pack_weight)
+// host: Linear weight (N,K) row-major -> 16x16x4-MFMA fragment order Wp16 = [ceil(N/16)][K/16][64][4] (rows >= N zero)
 size_t sfmi_skinny16_pack_floats(int N, int K) { return (size_t)((N + 15) / 16) * 16 * K; }
 int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out) {
   if (!W || !out || K % 16) return SFMI_EINVAL;
@@ -898,25 +734,6 @@ int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out) {
       }
   return SFMI_OK;
 }
-int sfmi_skinny16_gemm_f32(const float* x, const float* Wp16, const float* bias, float* out, int M, int N, int K, int S,
-                           int ldo, int epi, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 16 || S <= 0 || K % (16 * S) || (epi && (S != 1 || !bias))) return SFMI_EINVAL;
-  const int NT = (N + 15) / 16;
-  const int kslice = K / S;
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(NT, S);
-  if (kslice % (16 * 8) == 0 && kslice >= 512)
-    hipLaunchKernelGGL((skinny16_gemm_kernel<8>), grid, dim3(512), 0, st, x, Wp16, bias, out, M, N, K, kslice, ldo, epi);
-  else if (kslice % (16 * 4) == 0)
-    hipLaunchKernelGGL((skinny16_gemm_kernel<4>), grid, dim3(256), 0, st, x, Wp16, bias, out, M, N, K, kslice, ldo, epi);
-  else if (kslice % (16 * 2) == 0)
-    hipLaunchKernelGGL((skinny16_gemm_kernel<2>), grid, dim3(128), 0, st, x, Wp16, bias, out, M, N, K, kslice, ldo, epi);
-  else
-    hipLaunchKernelGGL((skinny16_gemm_kernel<1>), grid, dim3(64), 0, st, x, Wp16, bias, out, M, N, K, kslice, ldo, epi);
-  SFMI_CHECK_LAUNCH();
-  return SFMI_OK;
-}
-
 // replaces LayerNorm + nn.Linear (+GELU / +residual) of Block.forward at decode time (mingpt.py:103-111).
 // Wp16: sfmi_skinny16_pack_weight of W (plain) or of W*diag(gamma) (ln=1, with c1/c2 as in the kernel header).
 // c1/c2 need ceil(N/16)*16 readable floats.  resid (if given) is added and shares out's (M,ldo) layout.

@@ -1,0 +1,51 @@
+"""Multi-GPU sharding of the completion hot path: one process per GPU, shapes are independent.
+
+Mirrors the reference's inference sharding (xgutils/plutil.py:123-139 `get_effective_visual_indices`: rank r takes
+items r, r+G, r+2G, ...).  There is NO data-path collective: every rank holds a full weight replica (1.3 GB +
+72 MB) and completes its own shapes; the only exchange is the optional final gather of the (B,L,2) token tensors /
+timing scalars over torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def effective_indices(indices, rank: int, world: int):
+    """plutil.py:123-139: the items rank `rank` of `world` processes."""
+    indices = np.asarray(indices)
+    n = len(indices)
+    cnt = -(-(n - rank) // world) if n > rank else 0
+    return indices[rank + world * np.arange(cnt)]
+
+
+def init_from_env(backend=None):
+    """torch.distributed init from RANK/WORLD_SIZE/MASTER_* (torchrun); returns (rank, world, dist or None)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return 0, 1, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+    return rank, world, dist
+
+
+def gather_ragged_tokens(tokens: torch.Tensor, lengths: torch.Tensor, dist, world: int):
+    """All-gather per-rank (B,Lpad,2) int32 token rows + (B,) lengths -> lists indexed by rank (rank-major order is the
+    inverse of `effective_indices` striding: item i lives at [i % world][i // world])."""
+    if dist is None or world == 1:
+        return [tokens], [lengths]
+    tl = [torch.empty_like(tokens) for _ in range(world)]
+    ll = [torch.empty_like(lengths) for _ in range(world)]
+    dist.all_gather(tl, tokens.contiguous())
+    dist.all_gather(ll, lengths.contiguous())
+    return tl, ll
+
+
+def unshard(per_rank, n_items: int):
+    """Inverse of the striding: per_rank[r][j] is item r + j*world."""
+    world = len(per_rank)
+    return [per_rank[i % world][i // world] for i in range(n_items)]

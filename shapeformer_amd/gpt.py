@@ -26,15 +26,6 @@ def _t(sd, k, dev):
     return v.to(dev, torch.float32).contiguous()
 
 
-def pack_skinny(w: torch.Tensor) -> torch.Tensor:
-    """(N,K) row-major -> MFMA-fragment order [ceil(N/32)][K/8][64][4] (same as sfmi_skinny_pack_weight)."""
-    N, K = w.shape
-    NT = (N + 31) // 32
-    if NT * 32 != N:
-        w = torch.cat([w, w.new_zeros(NT * 32 - N, K)], 0)
-    return w.view(NT, 32, K // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
-
-
 def pack_skinny16(w: torch.Tensor) -> torch.Tensor:
     """(N,K) row-major -> [ceil(N/16)][K/16][64][4] (same as sfmi_skinny16_pack_weight)."""
     N, K = w.shape

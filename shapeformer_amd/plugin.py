@@ -1,0 +1,202 @@
+"""Drop-in boundary B1: the reference's YAML + dotted-class plugin mechanism, bound to the HIP path.
+
+Mirrors xgutils/optutil.py:44-70 (`load_option` with recursive `inherit_from`), xgutils/sysutil.py:46-64
+(`dictUpdate`: replace wholesale unless both sides are mappings of the same type) and :148-156
+(`load_object`, `instantiate_from_opt`: returns None when `class` is missing/None), so the reference's
+YAMLs load UNCHANGED:  every `class: shapeformer....` path the hot path names resolves to the MI355X-native
+class with the same ctor kwargs.  Classes off the hot path (datasets, Lightning
+callbacks' rendering half, trainer) are not provided — resolving them raises with a clear message.
+
+    opt   = get_opt("configs/shapeformer/shapenet_scale.yaml")
+    model = instantiate_from_opt(opt["pl_model_opt"])          # -> ShapeFormerModel on cuda:0
+    out   = model.complete(Xct)                                  # VisShapeFormer.compute_batch equivalent
+"""
+from __future__ import annotations
+
+import collections.abc
+import importlib
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from . import weights as W
+
+
+# --------------------------------------------------------------------------- config loading
+def dictUpdate(d1: dict, d2: dict, recursive=True):
+    """sysutil.py:46-64."""
+    for k, v2 in d2.items():
+        v1 = d1.get(k, None)
+        if type(v1) is type(v2) and isinstance(v2, collections.abc.Mapping) and recursive:
+            d1[k] = dictUpdate(v1, v2)
+        else:
+            d1[k] = v2
+    return d1
+
+
+def load_option(path):
+    """optutil.py:44-70: YAML + recursive `inherit_from` (relative to the including file)."""
+    with open(path, "r") as f:
+        this_opt = yaml.load(f, Loader=yaml.FullLoader)
+    inherit_from = this_opt.get("inherit_from")
+    if inherit_from is not None:
+        full = os.path.abspath(os.path.join(os.path.dirname(path), inherit_from))
+        base = load_option(full if os.path.exists(full) else inherit_from)
+    else:
+        base = dict()
+    return dictUpdate(base, this_opt)
+
+
+def get_opt(src, root_dir="."):
+    """optutil.py:28-37 (meta_info reduced to the directories the hot path reads)."""
+    opt = load_option(src) if isinstance(src, str) else src
+    name = opt.get("expr_name")
+    if name is None:
+        raise ValueError("You should specify expr_name")
+    root = os.path.abspath(root_dir)
+    exp = os.path.join(root, "experiments", name)
+    opt["meta_info"] = dict(experiments_dir=os.path.join(root, "experiments/"), expr_dir=exp,
+                            checkpoints_dir=os.path.join(exp, "checkpoints"), results_dir=os.path.join(exp, "results"))
+    return opt
+
+
+# --------------------------------------------------------------------------- model wrappers (reference ctor kwargs)
+def _device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cuda:0")
+
+
+def load_pl_state_dict(ckpt_path, prefix=""):
+    """Lightning `.ckpt` = torch.save dict with `state_dict` (SURVEY §5 checkpoint row); strips `prefix`."""
+    ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    sd = ck.get("state_dict", ck)
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+class VQDIFModel:
+    """`shapeformer.models.vqdif.vqdif.VQDIF` ctor surface (vqdif.py:22-33) over shapeformer_amd.vqdif.VQDIF."""
+
+    def __init__(self, Xct_as_Xbd=False, encoder_opt=None, decoder_opt=None, quantizer_opt=None, vq_beta=1.0,
+                 optim_opt=None, ckpt_path=None, opt=None, state_dict=None, device=None):
+        from .vqdif import VQDIF
+        ek, dk, qk = encoder_opt["kwargs"], decoder_opt["kwargs"], quantizer_opt["kwargs"]
+        assert encoder_opt["class"].endswith("enc.LocalPoolPointnet") and decoder_opt["class"].endswith("dec.LocalDecoder")
+        assert quantizer_opt["class"].endswith("quantizer.Quantizer")
+        assert ek["hidden_dim"] == 32 and ek["c_dim"] == 32 and ek["grid_resolution"] == 64 and ek["plane_type"] == "grid"
+        steps = ek["downsampler_kwargs"]["downsample_steps"]
+        assert dk["upsampler_kwargs"]["upsampler_steps"] == steps and dk["hidden_size"] == 32 and dk["c_dim"] == 32
+        res = 64 >> steps
+        assert res in (16, 32) and qk["n_embd"] == 32 << steps, "shipped configs: res16 (d=128) / res32 (d=64)"
+        if state_dict is None and ckpt_path and os.path.exists(ckpt_path):
+            state_dict = load_pl_state_dict(ckpt_path)
+        self.hparams = dict(encoder_opt=encoder_opt, decoder_opt=decoder_opt, quantizer_opt=quantizer_opt, vq_beta=vq_beta,
+                            optim_opt=optim_opt)
+        self.core = VQDIF(state_dict, res=res, device=device or _device(), vocab_size=qk["vocab_size"])
+
+    def __getattr__(self, name):  # encode / quantize_cloud / decode / decode_index / forward ...
+        return getattr(self.core, name)
+
+    @classmethod
+    def load_from_checkpoint(cls, ckpt_path, **kw):
+        ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        return cls(**ck["hyper_parameters"], state_dict=ck["state_dict"], **kw)
+
+
+class CondTupleGPTModel:
+    """`...transformer.mingpt.CondTupleGPT` ctor surface (mingpt.py:187-189)."""
+
+    def __new__(cls, vocab_sizes, extra_vocab_sizes, block_size, tuple_n, n_layers=(12,), n_head=8, n_embd=256,
+                embd_pdrop=0., resid_pdrop=0., attn_pdrop=0., state_dict=None, device=None, end_tokens=(4096, 4096), **_):
+        from .gpt import CondTupleGPT
+        return CondTupleGPT(state_dict, n_embd=n_embd, n_head=n_head, n_layers=tuple(n_layers), block_size=block_size,
+                            vocab_sizes=tuple(vocab_sizes), extra_vocab_sizes=tuple(extra_vocab_sizes), tuple_n=tuple_n,
+                            end_tokens=tuple(end_tokens), device=device or _device())
+
+
+class ARNRepresenter:
+    """`...representers.AR_N` ctor surface (representers.py:53-67): owns the frozen VQDIF named by `vqvae_opt`."""
+
+    def __init__(self, voxel_res=16, end_tokens=None, block_size=None, uncond=False, no_val_ind=False, vqvae_opt=None,
+                 random_cind_masking=False, mask_invalid=True, mask_invalid_completion=False, device=None, **_):
+        self.voxel_res, self.end_tokens, self.block_size = voxel_res, tuple(end_tokens), block_size
+        self.mask_invalid, self.mask_invalid_completion = mask_invalid, mask_invalid_completion
+        self.max_length = block_size // 2
+        y = load_option(vqvae_opt["yaml_path"]) if os.path.exists(vqvae_opt.get("yaml_path", "")) else None
+        kw = dict(y["pl_model_opt"]["kwargs"]) if y else default_vqdif_kwargs(voxel_res)
+        ck = vqvae_opt.get("ckpt_path")
+        self.vqvae_model = VQDIFModel(**kw, ckpt_path=ck if ck and os.path.exists(ck) else None, device=device)
+
+
+class ShapeFormerModel:
+    """`shapeformer.models.shapeformer.shapeformer.ShapeFormer` ctor surface (shapeformer.py:17-24) + `sample` /
+    the compute half of VisShapeFormer (`complete`)."""
+
+    def __init__(self, tuple_n=None, block_size=None, end_tokens=None, vocab_sizes=None, extra_vocab_sizes=None,
+                 voxel_res=16, transformer_opt=None, representer_opt=None, optim_opt=None, state_dict=None, device=None):
+        assert "TupleGPT" in transformer_opt["class"]  # shapeformer.py:24
+        from .pipeline import ShapeCompletion
+        dev = device or _device()
+        tsd = {k[len("transformer."):]: v for k, v in state_dict.items() if k.startswith("transformer.")} if state_dict else None
+        self.transformer = CondTupleGPTModel(**transformer_opt["kwargs"], state_dict=tsd, device=dev, end_tokens=end_tokens)
+        self.representer = instantiate_from_opt(dict(representer_opt, kwargs=dict(representer_opt["kwargs"], device=dev)))
+        self.tuple_n, self.block_size, self.end_tokens, self.voxel_res = tuple_n, block_size, tuple(end_tokens), voxel_res
+        self.pipe = ShapeCompletion(self.representer.vqvae_model.core, self.transformer, voxel_res, block_size, end_tokens)
+
+    def sample(self, c_indices, Lc=None, max_steps=512, temperature=1.0, best_in_first=False, top_k=100, top_p=0.8,
+               mask_invalid=True, mask_invalid_completion=False, **kw):
+        """shapeformer.py:125-130 -> dict(samples, log_prob, steps)."""
+        B, Lp, _ = c_indices.shape
+        Lc = Lc if Lc is not None else torch.full((B,), Lp, dtype=torch.int32)
+        return self.transformer.sample(c_indices, Lc, max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature,
+                                       best_in_first=best_in_first, mask_invalid=mask_invalid,
+                                       mask_invalid_completion=mask_invalid_completion, **kw)
+
+    def complete(self, Xct, **kw):
+        kw.setdefault("mask_invalid", self.representer.mask_invalid)
+        kw.setdefault("mask_invalid_completion", self.representer.mask_invalid_completion)
+        return self.pipe.complete(Xct, **kw)
+
+
+def default_vqdif_kwargs(res=16):
+    """kwargs of configs/vqdif/shapenet_res{16,32}.yaml `pl_model_opt` (used when the YAML file is absent)."""
+    steps, d = (2, 128) if res == 16 else (1, 64)
+    P = "shapeformer.models.vqdif."
+    return dict(
+        encoder_opt={"class": P + "enc.LocalPoolPointnet",
+                     "kwargs": dict(hidden_dim=32, plane_type="grid", grid_resolution=64, c_dim=32, downsampler=True,
+                                    downsampler_kwargs=dict(in_channels=32, downsample_steps=steps))},
+        quantizer_opt={"class": P + "quantizer.Quantizer", "kwargs": dict(vocab_size=4096, n_embd=d)},
+        vq_beta=0.001,
+        decoder_opt={"class": P + "dec.LocalDecoder",
+                     "kwargs": dict(sample_mode="bilinear", hidden_size=32, c_dim=32, unet3d=True,
+                                    unet3d_kwargs=dict(num_levels=3, f_maps=d, in_channels=d, out_channels=d), upsampler=True,
+                                    upsampler_kwargs=dict(in_channels=d, upsampler_steps=steps))},
+        optim_opt=dict(lr=1e-4, scheduler="StepLR", step_size=10, gamma=0.9))
+
+
+# --------------------------------------------------------------------------- plugin loader
+REGISTRY = {
+    "shapeformer.models.vqdif.vqdif.VQDIF": VQDIFModel,
+    "shapeformer.models.shapeformer.shapeformer.ShapeFormer": ShapeFormerModel,
+    "shapeformer.models.shapeformer.transformer.mingpt.CondTupleGPT": CondTupleGPTModel,
+    "shapeformer.models.shapeformer.representers.AR_N": ARNRepresenter,
+}
+OUT_OF_SCOPE_PREFIXES = ("shapeformer.datamodule", "shapeformer.data.", "shapeformer.trainer", "xgutils.")
+
+
+def load_object(object_path):
+    """sysutil.py:148-152, with the hot-path classes mapped onto the MI355X-native implementations."""
+    if object_path in REGISTRY:
+        return REGISTRY[object_path]
+    if object_path.startswith(OUT_OF_SCOPE_PREFIXES) or object_path.startswith("shapeformer."):
+        raise NotImplementedError(f"{object_path}: outside the accelerated hot path (SURVEY.md §8); not provided by shapeformer_amd")
+    mod, name = object_path.rsplit(".", 1)
+    return getattr(importlib.import_module(mod), name)
+
+
+def instantiate_from_opt(opt):
+    """sysutil.py:153-156."""
+    if "class" not in opt or opt["class"] is None:
+        return None
+    return load_object(opt["class"])(**opt.get("kwargs", dict()))
