@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     f32x4 w[UN], xb[UN][MT];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      w[u] = wp[(s0 + u) * 64];
+      w[u] = __builtin_nontemporal_load(wp + (s0 + u) * 64);   // weights are streamed once: keep them out of L2's way
 #pragma unroll
       for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][(s0 + u) * 64];
     }
@@ -757,7 +757,7 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   dim3 grid((N + 15) / 16, S);
   const int MT = (M + 15) / 16;
   const int steps = kslice / NWv / 16;
-  int un = 8 / MT < 1 ? 1 : (MT == 3 ? 2 : 8 / MT);   // UN*MT <= 8 float4 pairs in flight
+  int un = MT == 1 ? 8 : 4;   // loads in flight per wave: UN weight + UN*MT activation float4s
   while (un > 1 && steps % un) un >>= 1;
 #define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
 #define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
