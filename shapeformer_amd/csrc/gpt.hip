@@ -189,17 +189,19 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     if (a.resid) pres = *reinterpret_cast<const f32x4*>(a.resid + off_ep);
   }
   const int steps = kw / 16;
-  for (int s0 = 0; s0 < steps; s0 += UN) {
-    f32x4 w[UN], xb[UN][MT];
+  // software pipeline over batches of UN k16-steps: the loads of batch b+1 are issued BEFORE the MFMAs of batch b
+  // (two register sets, statically indexed), and every load of a batch is pinned ahead of the first MFMA that
+  // follows (sched_barrier) - hipcc otherwise sinks loads next to their uses and the kernel turns latency-bound.
+  f32x4 wA[UN], xA[UN][MT], wB[UN], xB[UN][MT];
+  auto load_batch = [&](int s0, f32x4 (&w)[UN], f32x4 (&xb)[UN][MT]) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      w[u] = __builtin_nontemporal_load(wp + (s0 + u) * 64);   // weights are streamed once: keep them out of L2's way
+      w[u] = __builtin_nontemporal_load(wp + (s0 + u) * 64);   // weights are streamed once
 #pragma unroll
       for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][(s0 + u) * 64];
     }
-    // keep ALL loads of the batch ahead of the first MFMA: hipcc otherwise sinks each load next to its use
-    // (2-4 loads in flight) and the kernel becomes HBM-latency-bound instead of bandwidth-bound
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto compute_batch = [&](const f32x4 (&w)[UN], const f32x4 (&xb)[UN][MT]) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
 #pragma unroll
@@ -213,6 +215,16 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
           acc[j][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][e], xv[e], acc[j][e & 1], 0, 0, 0);
       }
     }
+  };
+  load_batch(0, wA, xA);
+  for (int s0 = 0; s0 < steps; s0 += 2 * UN) {
+    if (s0 + UN < steps) load_batch(s0 + UN, wB, xB);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_batch(wA, xA);
+    if (s0 + UN >= steps) break;
+    if (s0 + 2 * UN < steps) load_batch(s0 + 2 * UN, wA, xA);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_batch(wB, xB);
   }
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -757,7 +769,7 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   dim3 grid((N + 15) / 16, S);
   const int MT = (M + 15) / 16;
   const int steps = kslice / NWv / 16;
-  int un = MT == 1 ? 8 : 4;   // loads in flight per wave: UN weight + UN*MT activation float4s
+  int un = MT == 1 ? 8 : (MT == 2 ? 4 : 2);   // per register set; two sets are in flight (software pipeline)
   while (un > 1 && steps % un) un >>= 1;
 #define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
 #define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)

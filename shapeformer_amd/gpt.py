@@ -190,7 +190,7 @@ class CondTupleGPT:
             L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
                                                  L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
                                                  L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
-            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=self.S_PROJ)
+            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=self.S_PROJ if B <= 16 else 4)
             self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1)
             self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=self.S_FC2)
             if li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage:
