@@ -125,11 +125,24 @@ def kernel_rooflines(vq, gpt, B, dev):
     return out
 
 
+def effective_cores():
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota) — the GPU box exposes 256 logical
+    CPUs but caps the container at 16 via cpu.max; oversubscribing torch's pool makes the CPU path 100x slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(points, ar_steps, decode_res):
     """Oracle (CPU restatement pinned to the reference) timed on the host cores, bounded sample (~10-30 s)."""
     from oracle import gpt_oracle as GO, tokens_oracle as TO, vqdif_oracle as VO
     from shapeformer_amd import synthetic, weights as W
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     torch.set_num_threads(cores)
     sdv = VO.to_torch_sd(W.make_state_dict(W.vqdif_spec(16)))
     X = torch.from_numpy(synthetic.make_batch(314, 1, n_partial=points)["Xct"])
