@@ -73,13 +73,14 @@ int sfmi_sparse2dense_i32(const int* tokens, const int* start, const int* len, c
 int sfmi_gemm_f32(const float* x, const float* W, const float* bias, const float* resid, float* y, long long M, int N, int K,
                   int act, long long out_group, long long out_group_stride, void* stream);
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
-                       const int* seq, const int* len, const int* Lc, float* resid_out, float* xn, const float* gamma,
-                       const float* beta, int B, int P, int D, int Lmax, int end0, void* stream);
+                       const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, float* resid_out,
+                       float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax, int end0, void* stream);
 int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* bias, const float* Eadd, const int* seq,
-                         const int* len, const int* Lc, float* resid_out, float* xn, const float* gamma, const float* beta,
-                         int S, int M, int P, int D, int Lmax, void* stream);
-int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* Lc, float* y, int B, int P, int D, int H,
+                         const int* len, const int* Lc, const int* nval, float* resid_out, float* xn, const float* gamma,
+                         const float* beta, int S, int M, int P, int D, int Lmax, void* stream);
+int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                               int Lmax, void* stream);
+int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream); /* shapeformer.py:132-140 */
 /* decode step (M = B <= 64 rows) */
 size_t sfmi_skinny16_pack_floats(int N, int K);
 int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out); /* [host] (N,K) -> [N/16][K/16][64][4] */

@@ -26,6 +26,8 @@ struct RowPrepArgs {
   // EMBED source (mode 0): token tables
   const float *E0, *E1, *Ex, *pos_emb, *cond_pos_emb;
   const int *seq, *len, *Lc;  // (B,Lmax,2), (B), (B)
+  const int* nval;            // prefill rows (b,t) are valid for t < nval[b] (NULL: Lc[b]-1)
+  const int* extra;           // optional explicit extra index (B,Lmax) (NULL: AR_N rule, representers.py:188-196)
   // ACCUM source (mode 1)
   const float* resid_in;   // (M,D)
   const float* part;       // (S,M,D) or null
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void rowprep_kernel(RowPrepArgs a) {
   int t;
   if (a.P) { t = m - b * a.P; } else { t = a.len ? a.len[b] - 1 : 0; }
   const int lc = a.Lc ? a.Lc[b] : 0;
-  if (a.P) { int tmax = lc - 2; if (tmax < 0) tmax = 0; if (t > tmax) t = tmax; }  // padded prefill rows: harmless clamp
+  if (a.P) { int tmax = (a.nval ? a.nval[b] : lc - 1) - 1; if (tmax < 0) tmax = 0; if (t > tmax) t = tmax; }  // padded rows: harmless clamp
   const int nq = a.D / 4;
   f32x4 v[4];
   float s = 0.f;
@@ -53,7 +55,9 @@ __global__ __launch_bounds__(256) void rowprep_kernel(RowPrepArgs a) {
   if (a.mode == 0) {
     const int* tk = a.seq + ((long long)b * a.Lmax + t) * 2;
     pos = tk[0]; val = tk[1];
-    if (t < lc) {
+    if (a.extra) {
+      ext = a.extra[(long long)b * a.Lmax + t];
+    } else if (t < lc) {
       ext = pos;  // representers.py:191 cond token -> own pos
     } else if (pos == a.end0) {
       ext = a.end0;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * 64 + wave * 4 + kk;
       kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) kf[u] = *reinterpret_cast<const f32x4*>(Kb + (long long)i * HD + 4 * c4);
+      if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Kb + (long long)i * HD + 4 * c4));
       else if (i == t && cok) kf[u] = *reinterpret_cast<const f32x4*>(kn + 4 * c4);
     }
 #pragma unroll
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
       const int i = i0 + u * 64 + wave * 4 + kk;
       vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       pr[u] = 0.f;
-      if (i < t && cok) vf[u] = *reinterpret_cast<const f32x4*>(Vb + (long long)i * HD + 4 * c4);
+      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vb + (long long)i * HD + 4 * c4));
       else if (i == t && cok) vf[u] = *reinterpret_cast<const f32x4*>(vn + 4 * c4);
       if (i <= t) pr[u] = __expf(sc[i] - gmax);
     }
@@ -396,12 +400,12 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
 //   into the caches.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
-                                                           float* __restrict__ Vc, const int* __restrict__ Lc,
+                                                           float* __restrict__ Vc, const int* __restrict__ nval,
                                                            float* __restrict__ y /*(B*P,D)*/, int P, int D, int Lmax,
                                                            float scale) {
   __shared__ __attribute__((aligned(16))) float Ks[64][64], Vs[64][64];
   const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x;
-  const int n = min(P, max(Lc[b] - 1, 0));  // valid prefill positions of this row
+  const int n = min(P, max(nval[b], 0));  // valid prefill positions of this row
   const int q0 = qb * 64;
   if (q0 >= n) return;
   const int qi = tid >> 2, c16 = tid & 3;
@@ -723,6 +727,26 @@ __global__ __launch_bounds__(256) void embed_packed_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(resid + pk_off(b, 4 * qd, D)) = ((e0[qd] + e1[qd]) + ex[qd]) + pe[qd];
 }
 
+// per-row cross entropy: loss[m] = logsumexp(logits[m,:V]) - logits[m, target[m]]   (F.cross_entropy, shapeformer.py:136)
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int* __restrict__ target,
+                                                      float* __restrict__ loss, int V, int ld) {
+  __shared__ float red[8];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (long long)m * ld;
+  float mx = -INFINITY;
+  for (int v = tid; v < V; v += 256) mx = fmaxf(mx, row[v]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int v = tid; v < V; v += 256) se += __expf(row[v] - mx);
+  se = wave_sum(se);
+  if (lane == 0) red[4 + wave] = se;
+  __syncthreads();
+  if (tid == 0) loss[m] = mx + __logf((red[4] + red[5]) + (red[6] + red[7])) - row[target[m]];
+}
+
 __global__ void set_len_kernel(int* len, const int* src, int B, int delta) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) len[i] = src[i] + delta;
@@ -784,11 +808,12 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
 // replaces get_embeddings (mingpt.py:256-286) + the AR_N extra index (representers.py:188-196,432-442)
 // (+ LayerNorm ln1 of the first block).  P == 0: one row per sequence at t = len[b]-1; P > 0: prefill rows (b,t<P).
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
-                       const int* seq, const int* len, const int* Lc, float* resid_out, float* xn, const float* gamma,
-                       const float* beta, int B, int P, int D, int Lmax, int end0, void* stream) {
+                       const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, float* resid_out,
+                       float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax, int end0, void* stream) {
   if (!E0 || !E1 || !Ex || !pos_emb || !cond_pos_emb || !seq || !len || !Lc || D % 4 || D > 4096) return SFMI_EINVAL;
   RowPrepArgs a = {};
   a.E0 = E0; a.E1 = E1; a.Ex = Ex; a.pos_emb = pos_emb; a.cond_pos_emb = cond_pos_emb; a.seq = seq; a.len = len; a.Lc = Lc;
+  a.nval = nval; a.extra = extra;
   a.resid_out = resid_out; a.xn = xn; a.gamma = gamma; a.beta = beta; a.mode = 0; a.M = P ? B * P : B; a.D = D; a.Lmax = Lmax;
   a.P = P; a.end0 = end0;
   hipLaunchKernelGGL(rowprep_kernel, dim3(a.M), dim3(256), 0, (hipStream_t)stream, a);
@@ -799,11 +824,11 @@ int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const 
 // replaces the residual adds + LayerNorm of Block.forward (mingpt.py:107-111): x = resid + sum_s part[s] + bias
 // (+ tok_embs[0][next pos], mingpt.py:294) ; resid_out = x ; xn = LN(x)
 int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* bias, const float* Eadd, const int* seq,
-                         const int* len, const int* Lc, float* resid_out, float* xn, const float* gamma, const float* beta,
-                         int S, int M, int P, int D, int Lmax, void* stream) {
+                         const int* len, const int* Lc, const int* nval, float* resid_out, float* xn, const float* gamma,
+                         const float* beta, int S, int M, int P, int D, int Lmax, void* stream) {
   if (!resid_in || D % 4 || D > 4096 || (Eadd && (!seq || !len))) return SFMI_EINVAL;
   RowPrepArgs a = {};
-  a.resid_in = resid_in; a.part = part; a.bias = bias; a.Eadd = Eadd; a.seq = seq; a.len = len; a.Lc = Lc;
+  a.resid_in = resid_in; a.part = part; a.bias = bias; a.Eadd = Eadd; a.seq = seq; a.len = len; a.Lc = Lc; a.nval = nval;
   a.resid_out = resid_out; a.xn = xn; a.gamma = gamma; a.beta = beta; a.mode = 1; a.S = S; a.M = M; a.D = D; a.Lmax = Lmax; a.P = P;
   hipLaunchKernelGGL(rowprep_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
@@ -822,10 +847,10 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
 }
 
 // causal self-attention over the conditioning prefix (positions 0..Lc[b]-2), also fills the KV caches
-int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* Lc, float* y, int B, int P, int D, int H,
+int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                               int Lmax, void* stream) {
-  if (!qkv || !Kc || !Vc || !Lc || !y || D / H != 64 || P <= 0) return SFMI_EINVAL;
-  hipLaunchKernelGGL(attn_prefill_kernel, dim3(B, H, (P + 63) / 64), dim3(256), 0, (hipStream_t)stream, qkv, Kc, Vc, Lc, y, P, D,
+  if (!qkv || !Kc || !Vc || !nval || !y || D / H != 64 || P <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(attn_prefill_kernel, dim3(B, H, (P + 63) / 64), dim3(256), 0, (hipStream_t)stream, qkv, Kc, Vc, nval, y, P, D,
                      Lmax, 0.125f);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
@@ -860,6 +885,14 @@ int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex,
   if (!E0 || !E1 || !Ex || !pos_emb || !cond_pos_emb || !seq || !len || !Lc || !resid || D % 16) return SFMI_EINVAL;
   hipLaunchKernelGGL(embed_packed_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, E0, E1, Ex, pos_emb, cond_pos_emb, seq, len, Lc,
                      resid, D, Lmax, end0);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// replaces F.cross_entropy(reduction='none') over rows (shapeformer.py:132-140)
+int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream) {
+  if (!logits || !target || !loss || M <= 0 || V <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, logits, target, loss, V, ld);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -140,13 +140,15 @@ class CondTupleGPT:
     def _rowprep(self, resid_in, part, bias, S, M, resid_out, xn, ln, Eadd=None, P=0, st=None):
         L.check(L.lib().sfmi_gpt_rowprep_f32(L.ptr(resid_in), L.ptr(part), L.ptr(bias), L.ptr(Eadd),
                                              L.ptr(st["seq"]) if st else None, L.ptr(st["len"]) if st else None,
-                                             L.ptr(st["Lc"]) if st else None, L.ptr(resid_out), L.ptr(xn),
+                                             L.ptr(st["Lc"]) if st else None, L.ptr(st.get("nval")) if st else None,
+                                             L.ptr(resid_out), L.ptr(xn),
                                              L.ptr(ln[0]) if ln else None, L.ptr(ln[1]) if ln else None, S, M, P, self.D,
                                              self.Lmax + 1, L.stream_ptr()), "sfmi_gpt_rowprep_f32")
 
     def _embed(self, st, B, P, resid, xn, ln):
         L.check(L.lib().sfmi_gpt_embed_f32(L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb),
                                            L.ptr(self.cond_pos_emb), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
+                                           L.ptr(st.get("nval")), L.ptr(st.get("extra")),
                                            L.ptr(resid), L.ptr(xn), L.ptr(ln[0]) if ln else None, L.ptr(ln[1]) if ln else None,
                                            B, P, self.D, self.Lmax + 1,
                                            self.end[0], L.stream_ptr()), "sfmi_gpt_embed_f32")
@@ -155,16 +157,33 @@ class CondTupleGPT:
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, og, ogs,
                                       L.stream_ptr()), "sfmi_gemm_f32")
 
-    # ------------------------------------------------------------------ prefill (positions 0..Lc[b]-2)
-    def prefill(self, st, B, P):
+    # ------------------------------------------------------------------ prefill (positions 0..nval[b]-1)
+    def prefill(self, st, B, P, want_logits=False):
+        """Batched forward of rows (b,t), t < P, through both stages (fills the KV caches).  Rows with
+        t >= nval[b] (default Lc[b]-1) are padding.  want_logits: also run both heads on every row and return
+        [(B,P,V), (B,P,V)] — the teacher-forced `CondTupleGPT.forward` (mingpt.py:287-296,311-319)."""
         D, dev = self.D, self.dev
         M = B * P
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         resid, xn, qkv, y, h = f(M, D), f(M, D), f(M, 3 * D), f(M, D), f(M, 4 * D)
+        if st.get("nval") is None:
+            st["nval"] = (st["Lc"] - 1).clamp_(min=0).contiguous()
+        logits = []
+
+        def heads(s):
+            if not want_logits:
+                return
+            if not hasattr(self, "head_w_pad"):   # (V,D) -> rows padded to a multiple of 32 for the GEMM tiles
+                self.head_w_pad = [torch.cat([w, w.new_zeros(self.Vpad - self.V, D)], 0).contiguous() for w in self.head_w]
+            self._rowprep(resid, None, None, 0, M, None, xn, self.head_ln[s])
+            lg = f(M, self.Vpad)
+            self._gemm(xn, self.head_w_pad[s], None, None, lg, M, self.Vpad, D)
+            logits.append(lg.view(B, P, self.Vpad)[:, :, :self.V])
+
         self._embed(st, B, P, resid, xn, self.layers[0].ln1)
         for li, ly in enumerate(self.layers):
             self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
-            L.check(L.lib().sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]), L.ptr(st["Lc"]),
+            L.check(L.lib().sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]), L.ptr(st["nval"]),
                                                       L.ptr(y), B, P, D, self.H, self.Lmax + 1, L.stream_ptr()), "attn_prefill")
             self._gemm(y, ly.wproj, ly.bproj, resid, resid, M, D, D)
             self._rowprep(resid, None, None, 0, M, None, xn, ly.ln2)
@@ -172,11 +191,61 @@ class CondTupleGPT:
             self._gemm(h, ly.wfc2, ly.bfc2, resid, resid, M, D, 4 * D)
             nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
             if nxt is None:
+                heads(ly.stage)
                 break
             if nxt.stage != ly.stage:   # stage boundary: x += tok_embs[0][next pos] (mingpt.py:294)
+                heads(ly.stage)
                 self._rowprep(resid, None, None, 0, M, resid, xn, nxt.ln1, Eadd=self.E[0], P=P, st=st)
             else:
                 self._rowprep(resid, None, None, 0, M, None, xn, nxt.ln1)
+        return logits
+
+    # ------------------------------------------------------------------ teacher-forced forward (mingpt.py:311-319)
+    @torch.no_grad()
+    def forward(self, idx, extra_idx=None, L_cond=1, target_idx=None):
+        """CondTupleGPT.forward: idx (B,L,2), extra_idx (B,L,1) or None (-> AR_N rule), target_idx (B,L,2)
+        -> [logits_pos (B,L,V), logits_val (B,L,V)] (float32, on device)."""
+        idx = torch.as_tensor(idx).to(self.dev, torch.int32)
+        B, Lq, _ = idx.shape
+        assert Lq <= self.Lmax, "Cannot forward, model block size is exhausted."   # mingpt.py:279
+        st = dict(self._alloc(B, 1))
+        st["seq"] = torch.zeros(B, self.Lmax + 1, 2, device=self.dev, dtype=torch.int32)
+        st["seq"][:, :Lq] = idx
+        if target_idx is not None:       # stage-1 input adds tok_embs[0][target pos] = seq[t+1][0]
+            tgt = torch.as_tensor(target_idx).to(self.dev, torch.int32)
+            assert bool((tgt[:, :-1, 0] == idx[:, 1:, 0]).all()), "target_idx must be idx shifted left (shapeformer.py:37-41)"
+            st["seq"][:, Lq, 0] = tgt[:, -1, 0]
+        st["Lc"] = torch.full((B,), int(L_cond), device=self.dev, dtype=torch.int32)
+        st["len"] = torch.full((B,), Lq, device=self.dev, dtype=torch.int32)
+        st["nval"] = torch.full((B,), Lq, device=self.dev, dtype=torch.int32)
+        st["extra"] = None
+        if extra_idx is not None:
+            ex = torch.zeros(B, self.Lmax + 1, device=self.dev, dtype=torch.int32)
+            ex[:, :Lq] = torch.as_tensor(extra_idx).to(self.dev, torch.int32)[..., 0]
+            st["extra"] = ex
+        return self.prefill(st, B, Lq, want_logits=True)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def training_loss(self, c_indices, z_indices, extra_indices=None):
+        """ShapeFormer.forward + shared_step loss (shapeformer.py:26-46,132-140): mean of the two cross entropies over
+        the outputs from index L_c-1 on (end-token padding included).  Forward only (no backward in round 1)."""
+        c = torch.as_tensor(c_indices).to(self.dev, torch.int32)
+        z = torch.as_tensor(z_indices).to(self.dev, torch.int32)
+        cz = torch.cat([c, z], 1)
+        L_c = c.shape[1]
+        ex = None if extra_indices is None else torch.as_tensor(extra_indices)[:, :-1]
+        logits = self.forward(cz[:, :-1], ex, L_c, cz[:, 1:])
+        loss = 0.0
+        for i in range(2):
+            lg = logits[i][:, L_c - 1:, :].contiguous()
+            M = lg.shape[0] * lg.shape[1]
+            tgt = z[..., i].contiguous().view(-1)
+            rows = torch.empty(M, device=self.dev, dtype=torch.float32)
+            L.check(L.lib().sfmi_ce_rows_f32(L.ptr(lg), L.ptr(tgt), L.ptr(rows), M, self.V, self.V, L.stream_ptr()), "sfmi_ce_rows_f32")
+            loss = loss + rows.mean()
+        return loss / 2
 
     # ------------------------------------------------------------------ one decode step (graph-capturable)
     def decode_step(self, st, B, sp):
@@ -241,6 +310,7 @@ class CondTupleGPT:
             sp["force"] = ft.to(self.dev)
             use_graph = False
         P = Lc_max - 1
+        st["nval"], st["extra"] = None, None
         if P > 0:
             self.prefill(st, B, P)
         # embedding of the last condition token (step-0 input) into the fragment-packed residual buffer

@@ -137,3 +137,26 @@ def test_sampler_kernel_vs_oracle_filter(dev):
             want = TO.sample_filtered(f, u[1, 0, b])
             bad += int(want != got[b])
     assert bad == 0
+
+
+def test_teacher_forced_forward_and_loss_vs_reference_vectors(dev):
+    """CondTupleGPT.forward (mingpt.py:311-319) + the training loss (shapeformer.py:132-140), forward only:
+    full 20+4-layer model vs logits produced by the REFERENCE (fixture), tiny model vs the oracle."""
+    from oracle import gpt_oracle as GO
+    from shapeformer_amd.gpt import CondTupleGPT
+    z = np.load(os.path.join(G, "gpt_full_probe.npz"))
+    cz, ex, L_c = torch.from_numpy(z["cz"]), torch.from_numpy(z["extra"]), int(z["L_c"])
+    g = CondTupleGPT(device=dev)
+    for extra in (ex[:, :-1], None):     # explicit extra index, and the built-in AR_N rule (representers.py:188-196)
+        lg = g.forward(cz[:, :-1], extra, L_c, cz[:, 1:])
+        for k, t in enumerate(z["pos_sel"]):
+            assert np.abs(lg[0][0, t].cpu().numpy() - z["logits0"][k]).max() < LOGIT_TOL
+            assert np.abs(lg[1][0, t].cpu().numpy() - z["logits1"][k]).max() < LOGIT_TOL
+    del g
+    sd, sd_t, cfg = _tiny()
+    gt = CondTupleGPT(sd, n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    t = np.load(os.path.join(G, "gpt_tiny.npz"))
+    c, zz, exx = (torch.from_numpy(t[k]) for k in ("c_idx", "z_idx", "extra"))
+    want = GO.training_loss(sd_t, cfg, c, zz, exx).item()
+    got = gt.training_loss(c, zz, exx).item()
+    assert abs(got - want) < 1e-4 * max(1.0, abs(want))
