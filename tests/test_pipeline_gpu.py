@@ -1,0 +1,93 @@
+"""GPU: end-to-end pipeline properties at BASELINE sizes, res32 parity, determinism."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_vqdif32_vs_reference_vectors(dev):
+    from oracle import vqdif_oracle as O
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.vqdif import VQDIF
+    sd = W.make_state_dict(W.vqdif_spec(32))
+    vq = VQDIF(sd, res=32, device=dev)
+    z = np.load(os.path.join(G, "vqdif32_small.npz"))
+    q, mode, enc = vq.quantize_cloud(torch.from_numpy(z["cloud"]))
+    assert np.array_equal(np.packbits(enc["grid_mask"].cpu().numpy()), z["grid_mask"])
+    want = z["quant_ind"].astype(np.int64)
+    bad = int((q.cpu().numpy() != want).sum())
+    assert bad <= 2 and (bad > 0 or int(mode) == int(z["mode"]))   # near-tie policy, 0 observed
+    Q = int(z["Q"])
+    lg = vq.decode_index(torch.from_numpy(want), grid_Q=Q)["logits"].cpu().numpy()[..., 0]
+    np.testing.assert_allclose(lg, z["logits"], atol=2e-4, rtol=1e-4)
+
+
+def test_config2_reconstruct_batch32_properties(dev, vq16_sd, vq16_sd_t):
+    """BASELINE config 2: VQDIF res16 reconstruction, batch 32, T=32768, 64^3 targets.  Size-independent
+    properties at full size + oracle comparison on 2 of the 32 shapes."""
+    from oracle import tokens_oracle as TO, vqdif_oracle as O
+    from shapeformer_amd import synthetic
+    from shapeformer_amd.gpt import CondTupleGPT
+    from shapeformer_amd.pipeline import ShapeCompletion
+    from shapeformer_amd.vqdif import VQDIF
+    from shapeformer_amd import weights as W
+    vq = VQDIF(vq16_sd, res=16, device=dev)
+    pipe = ShapeCompletion(vq, None)
+    Xbd = torch.from_numpy(synthetic.make_batch(1000, 32)["Xbd"])
+    assert Xbd.shape == (32, 32768, 3)
+    r = pipe.reconstruct(Xbd, decode_res=64, max_length=512)
+    q = r["dense"].cpu().numpy()
+    raw, mask = r["quant_ind"].cpu().numpy(), r["grid_mask"].cpu().numpy().astype(bool)
+    tok, ln = (t.cpu().numpy() for t in r["sparse"])
+    # dense -> sparse -> dense is the identity while no row is truncated (common.py:143-147,192-206 round trips)
+    assert ln.max() < 512
+    modes, counts = np.unique(raw, return_counts=True)
+    mode = int(modes[np.argmax(counts)])
+    want = np.where(mask, raw, mode)
+    assert np.array_equal(q, want)
+    for b in range(32):                                   # token rows: ascending positions, end-token terminated
+        n = int(ln[b]) - 1
+        assert np.all(np.diff(tok[b, :n, 0]) > 0) and tuple(tok[b, n]) == (4096, 4096)
+        assert n == int((want[b] != mode).sum())
+    lg = r["logits"].cpu()
+    assert lg.shape == (32, 64 ** 3, 1) and torch.isfinite(lg).all()
+    # oracle on shapes 0 and 31 with the batch's mode imposed (mode is a whole-batch quantity, vqdif.py:53)
+    for b in (0, 31):
+        fea, m = O.encode(vq16_sd_t, Xbd[b:b + 1])
+        ind, _ = O.quantize(vq16_sd_t, fea)
+        assert np.array_equal(m[0].numpy(), mask[b])
+        assert int((ind[0].numpy() != raw[b]).sum()) <= 1
+        ref = O.decode_index(vq16_sd_t, torch.from_numpy(want[b:b + 1]).long(), torch.from_numpy(O.make_grid(64))[None])
+        assert (lg[b] - ref[0]).abs().max().item() < 5e-4
+
+
+def test_completion_is_deterministic_and_matches_oracle_decode(dev, vq16_sd, vq16_sd_t):
+    from oracle import vqdif_oracle as O
+    from shapeformer_amd import synthetic, weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    from shapeformer_amd.pipeline import ShapeCompletion
+    from shapeformer_amd.vqdif import VQDIF
+    vq = VQDIF(vq16_sd, res=16, device=dev)
+    gsd = W.make_state_dict(W.gpt_spec(n_embd=128, n_layers=(2, 1), block_size=500))
+    gpt = CondTupleGPT(gsd, n_embd=128, n_head=2, n_layers=(2, 1), block_size=500, device=dev)
+    pipe = ShapeCompletion(vq, gpt, block_size=500)
+    X = torch.from_numpy(synthetic.make_batch(77, 17, n_partial=4096)["Xct"])   # 17 rows: two m-tiles, ragged Lc
+    a = pipe.complete(X, max_steps=24, decode_res=32, stop_early=False, sigmoid=False, seed=5)
+    seq_a, occ_a, dense_a = a["state"]["seq"].clone(), a["occupancy"].clone(), a["dense"].clone()
+    b = pipe.complete(X, max_steps=24, decode_res=32, stop_early=False, sigmoid=False, seed=5)
+    assert torch.equal(seq_a, b["state"]["seq"]) and torch.equal(occ_a, b["occupancy"])   # bitwise run-to-run
+    c = pipe.complete(X, max_steps=24, decode_res=32, stop_early=False, sigmoid=False, seed=6)
+    assert not torch.equal(seq_a, c["state"]["seq"])                                      # seed matters
+    # sampled positions are strictly increasing until the end token (sampling_masker, representers.py:136-140)
+    Lc = a["Lc"].cpu().numpy()
+    seq = seq_a.cpu().numpy()
+    for r in range(17):
+        pos = seq[r, Lc[r]:Lc[r] + 24, 0]
+        live = pos[pos != 4096]
+        assert np.all(np.diff(live) > 0)
+    ref = O.decode_index(vq16_sd_t, dense_a.cpu().long()[:3], torch.from_numpy(O.make_grid(32))[None].expand(3, -1, -1))[..., 0]
+    assert (occ_a.cpu()[:3] - ref).abs().max().item() < 5e-4
