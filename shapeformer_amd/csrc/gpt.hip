@@ -164,6 +164,12 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
 
 // UN = loads in flight per wave per operand; the host picks UN | steps so the unrolled batches carry NO per-element
 // conditions (a runtime select around a load makes hipcc wait vmcnt(0) per element - guide §5 trap 4c).
+#ifndef XIDX
+#define XIDX(i) (i)
+#endif
+#ifndef DG_MFMA
+#define DG_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+#endif
 template <int MT, int NW, int UN>
 __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float red[NW][MT][4][64];
@@ -196,39 +202,59 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   // software pipeline over batches of UN k16-steps: the loads of batch b+1 are issued BEFORE the MFMAs of batch b
   // (two register sets, statically indexed), and every load of a batch is pinned ahead of the first MFMA that
   // follows (sched_barrier) - hipcc otherwise sinks loads next to their uses and the kernel turns latency-bound.
-  f32x4 wA[UN], xA[UN][MT], wB[UN], xB[UN][MT];
-  auto load_batch = [&](int s0, f32x4 (&w)[UN], f32x4 (&xb)[UN][MT]) {
+  auto mfma_step = [&](const f32x4& wv, const f32x4 (&xs)[MT]) {
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      w[u] = __builtin_nontemporal_load(wp + (s0 + u) * 64);   // weights are streamed once
+    for (int j = 0; j < MT; ++j) {
+      const f32x4 xv = xs[j];
+      // LayerNorm statistics (a few VALU ops; computed unconditionally, only used when a.ln)
+      s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
+      s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
 #pragma unroll
-      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][(s0 + u) * 64];
+      for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
+        acc[j][e & 1] = DG_MFMA(wv[e], xv[e], acc[j][e & 1]);
     }
   };
-  auto compute_batch = [&](const f32x4 (&w)[UN], const f32x4 (&xb)[UN][MT]) {
+  if constexpr (MT == 1) {
+    // M <= 16 (HBM-bound): UN weight + UN activation loads in flight, all pinned ahead of the MFMAs.
+    for (int s0 = 0; s0 < steps; s0 += UN) {
+      f32x4 w[UN], xb[UN][1];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
+      for (int u = 0; u < UN; ++u) {
+        w[u] = __builtin_nontemporal_load(wp + (s0 + u) * 64);   // weights are streamed once
+        xb[u][0] = xr[0][XIDX((s0 + u) * 64)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const f32x4 xv = xb[u][j];
-        // LayerNorm statistics (a few VALU ops; computed unconditionally, only used when a.ln)
-        s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
-        s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
+      for (int u = 0; u < UN; ++u) mfma_step(w[u], xb[u]);
+    }
+  } else {
+    // M > 16 (MFMA-bound): the wave's whole weight slice (<= 8 fragments, HBM latency) is requested up front;
+    // the activation fragments (L2 latency) run through a two-deep register pipeline under the MFMAs.
+    f32x4 w[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
-          acc[j][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][e], xv[e], acc[j][e & 1], 0, 0, 0);
+    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (u < steps ? u : steps - 1) * 64);
+    f32x4 xA[MT], xB[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) xA[j] = xr[j][XIDX(0)];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      if (u < steps) {
+        if (u + 1 < steps) {
+#pragma unroll
+          for (int j = 0; j < MT; ++j) xB[j] = xr[j][XIDX((u + 1) * 64)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(w[u], xA);
+        if (u + 1 < steps) {
+          if (u + 2 < steps) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) xA[j] = xr[j][XIDX((u + 2) * 64)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_step(w[u + 1], xB);
+        }
       }
     }
-  };
-  load_batch(0, wA, xA);
-  for (int s0 = 0; s0 < steps; s0 += 2 * UN) {
-    if (s0 + UN < steps) load_batch(s0 + UN, wB, xB);
-    __builtin_amdgcn_sched_barrier(0);
-    compute_batch(wA, xA);
-    if (s0 + UN >= steps) break;
-    if (s0 + 2 * UN < steps) load_batch(s0 + 2 * UN, wA, xA);
-    __builtin_amdgcn_sched_barrier(0);
-    compute_batch(wB, xB);
   }
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -793,7 +819,8 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   dim3 grid((N + 15) / 16, S);
   const int MT = (M + 15) / 16;
   const int steps = kslice / NWv / 16;
-  int un = MT == 1 ? 8 : (MT == 2 ? 4 : 2);   // per register set; two sets are in flight (software pipeline)
+  int un = MT == 1 ? 8 : 1;   // MT > 1 ignores UN (weights preloaded, activations two-deep pipelined)
+  if (MT > 1 && steps > 8) return SFMI_EINVAL;
   while (un > 1 && steps % un) un >>= 1;
 #define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
 #define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
