@@ -214,47 +214,19 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
         acc[j][e & 1] = DG_MFMA(wv[e], xv[e], acc[j][e & 1]);
     }
   };
-  if constexpr (MT == 1) {
-    // M <= 16 (HBM-bound): UN weight + UN activation loads in flight, all pinned ahead of the MFMAs.
-    for (int s0 = 0; s0 < steps; s0 += UN) {
-      f32x4 w[UN], xb[UN][1];
+  // batches of UN k16-steps: UN weight + UN*MT activation loads in flight, all pinned ahead of the MFMAs
+  // (measured alternatives for MT > 1 — two-deep register pipeline, up-front weight preload — were 4-6 % slower)
+  for (int s0 = 0; s0 < steps; s0 += UN) {
+    f32x4 w[UN], xb[UN][MT];
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        w[u] = __builtin_nontemporal_load(wp + (s0 + u) * 64);   // weights are streamed once
-        xb[u][0] = xr[0][XIDX((s0 + u) * 64)];
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < UN; ++u) {
+      w[u] = __builtin_nontemporal_load(wp + (s0 + u) * 64);   // weights are streamed once
 #pragma unroll
-      for (int u = 0; u < UN; ++u) mfma_step(w[u], xb[u]);
+      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][XIDX((s0 + u) * 64)];
     }
-  } else {
-    // M > 16 (MFMA-bound): the wave's whole weight slice (<= 8 fragments, HBM latency) is requested up front;
-    // the activation fragments (L2 latency) run through a two-deep register pipeline under the MFMAs.
-    f32x4 w[8];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (u < steps ? u : steps - 1) * 64);
-    f32x4 xA[MT], xB[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) xA[j] = xr[j][XIDX(0)];
-#pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      if (u < steps) {
-        if (u + 1 < steps) {
-#pragma unroll
-          for (int j = 0; j < MT; ++j) xB[j] = xr[j][XIDX((u + 1) * 64)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(w[u], xA);
-        if (u + 1 < steps) {
-          if (u + 2 < steps) {
-#pragma unroll
-            for (int j = 0; j < MT; ++j) xA[j] = xr[j][XIDX((u + 2) * 64)];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          mfma_step(w[u + 1], xB);
-        }
-      }
-    }
+    for (int u = 0; u < UN; ++u) mfma_step(w[u], xb[u]);
   }
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -819,8 +791,7 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   dim3 grid((N + 15) / 16, S);
   const int MT = (M + 15) / 16;
   const int steps = kslice / NWv / 16;
-  int un = MT == 1 ? 8 : 1;   // MT > 1 ignores UN (weights preloaded, activations two-deep pipelined)
-  if (MT > 1 && steps > 8) return SFMI_EINVAL;
+  int un = MT == 1 ? 8 : (MT == 2 ? 4 : 2);   // UN weight + UN*MT activation float4 loads in flight per wave
   while (un > 1 && steps % un) un >>= 1;
 #define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
 #define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
