@@ -94,8 +94,14 @@ def kernel_rooflines(vq, gpt, B, dev):
     gm = out[-4:]
     tot_ms = sum(k["ms"] for k in gm)
     tot_b = sum(k["achieved"] * 1e9 * k["ms"] * 1e-3 for k in gm)
-    add("dgemm_kernel (qkv+proj+fc1+fc2 per layer)", tot_ms, "hbm", tot_b, 1e9, HBM, "GB/s",
-        f"M={B}; {tot_b / 1e6:.1f} MB algorithmic per layer; f32 MFMA {2.0 * B * 12.58e6 / (tot_ms * 1e-3) / 1e12:.1f} TFLOP/s")
+    flops = 2.0 * B * 12.58e6   # 4 weight matrices of one block = 12.58 M parameters
+    if 2.0 * B / 4.0 > F32 * 1e3 / HBM:   # arithmetic intensity (FLOP per weight byte) above the machine balance -> MFMA-bound
+        add("dgemm_kernel (qkv+proj+fc1+fc2 per layer)", tot_ms, "mfma", flops, 1e12, F32, "TFLOP/s",
+            f"M={B}: {2.0 * B / 4.0:.0f} FLOP/B > balance {F32 * 1e3 / HBM:.1f}; weights+activations {tot_b / (tot_ms * 1e-3) / 1e9:.0f} GB/s")
+    else:
+        add("dgemm_kernel (qkv+proj+fc1+fc2 per layer)", tot_ms, "hbm", tot_b, 1e9, HBM, "GB/s",
+            f"M={B}; {tot_b / 1e6:.1f} MB algorithmic per layer; f32 MFMA {flops / (tot_ms * 1e-3) / 1e12:.1f} TFLOP/s")
+    out[-1]["launches"] = 4
     # KV-cached decode attention at the mid-run length (Lc + ar_steps/2): bytes = K+V rows of every (row, head)
     lc = st["Lc"].clone()
     saved_len = st["len"].clone()
@@ -123,6 +129,19 @@ def kernel_rooflines(vq, gpt, B, dev):
         f"{B}x128^3 pts; algorithmic HBM {(B * Q ** 3 * 4 + B * 33.55e6) / (ms * 1e-3) / 1e9:.0f} GB/s")
     del grid, o
     return out
+
+
+def pmc_traffic(kernel, B):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic_B64.json: FETCH_SIZE
+    doubled per the gfx950 correction + WRITE_SIZE); only valid for the configuration it was collected on."""
+    f = os.path.join(ROOT, "profiles", "r01_pmc_traffic_B64.json")
+    if B != 64 or not os.path.exists(f):
+        return None
+    key = "dgemm_kernel" if kernel.startswith("dgemm_kernel") else "attn_decode_kernel"
+    for k, v in json.load(open(f))["kernels"].items():
+        if key in k:
+            return v["hbm_bytes_per_launch"]
+    return None
 
 
 def effective_cores():
@@ -245,7 +264,7 @@ def main():
             cands = [k for k in ks if k["kernel"].startswith(("dgemm_kernel", "attn_decode_kernel"))]
             dom = max(cands, key=lambda k: k["ms"])
             line["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                                "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"]}
+                                "frac": dom["frac"], "traffic": pmc_traffic(dom["kernel"], B), "kernel": dom["kernel"]}
             line["kernels"] = ks
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.points, a.ar_steps, a.decode_res)
