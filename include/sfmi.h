@@ -73,8 +73,9 @@ int sfmi_sparse2dense_i32(const int* tokens, const int* start, const int* len, c
 int sfmi_gemm_f32(const float* x, const float* W, const float* bias, const float* resid, float* y, long long M, int N, int K,
                   int act, long long out_group, long long out_group_stride, void* stream);
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
-                       const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, float* resid_out,
-                       float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax, int end0, void* stream);
+                       const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, int* extra_out,
+                       float* resid_out, float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax,
+                       int end0, void* stream);
 int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* bias, const float* Eadd, const int* seq,
                          const int* len, const int* Lc, const int* nval, float* resid_out, float* xn, const float* gamma,
                          const float* beta, int S, int M, int P, int D, int Lmax, void* stream);
@@ -98,6 +99,24 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
                         float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
                         unsigned seed, int advance, void* stream);
 int sfmi_set_len_i32(int* len, const int* src, int B, int delta, void* stream);
+
+/* ---- Training step of the transformer (csrc/train.hip): shapeformer.py:26-46,132-207 (forward/loss/AdamW groups),
+ *      backward of mingpt.py:46-111; GEMM-shaped gradients reuse sfmi_gemm_f32 on transposed operands ------------------- */
+int sfmi_transpose_f32(const float* in, float* out, int R, int C, int ldin, int Rpad, void* stream);
+int sfmi_colsum_f32(const float* x, float* out, int M, int N, int ld, int accumulate, void* stream);          /* bias gradients */
+int sfmi_gelu_f32(const float* x, float* y, long long n, void* stream);                                       /* mingpt.py:103 */
+int sfmi_gelu_bwd_f32(const float* dy, const float* x, float* dx, long long n, void* stream);
+int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* dgamma,
+                           float* dbeta, float* stats, int M, int D, void* stream);
+int sfmi_ce_fwd_bwd_f32(const float* logits, const int* target, float* loss_rows, float* dlogits, int M, int V, int ld, int L,
+                        int t0, float scale, void* stream);                                                    /* shapeformer.py:132-140 */
+int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* lse, float* dqkv, int B, int L, int D, int H,
+                      void* stream);                                                                           /* mingpt.py:73-91 */
+int sfmi_embed_scatter_f32(const float* dx, const int* idx, long long* acc, long long M, int D, void* stream);
+int sfmi_fixed_to_float_f32(const long long* acc, float* out, long long n, int accumulate, void* stream);
+int sfmi_add_f32(const float* a, const float* b, float* out, long long n, void* stream);
+int sfmi_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, void* stream);                                                /* shapeformer.py:198-206 */
 
 /* ---- Implicit decoder SDF/occupancy query: dec.py:62-100 (grid_sample + 5-block conditioned MLP), layers.py:39-48 - */
 size_t sfmi_sdf_pack_floats(void);

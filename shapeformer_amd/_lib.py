@@ -52,7 +52,7 @@ PROTOTYPES = {
     "sfmi_gemm_f32": (i32, [c_ptr] * 5 + [i64, i32, i32, i32, i64, i64, c_ptr]),
     "sfmi_skinny16_pack_floats": (sz, [i32, i32]),
     "sfmi_skinny16_pack_weight": (i32, [c_ptr, i32, i32, c_ptr]),
-    "sfmi_gpt_embed_f32": (i32, [c_ptr] * 14 + [i32] * 5 + [c_ptr]),
+    "sfmi_gpt_embed_f32": (i32, [c_ptr] * 15 + [i32] * 5 + [c_ptr]),
     "sfmi_gpt_rowprep_f32": (i32, [c_ptr] * 12 + [i32] * 5 + [c_ptr]),
     "sfmi_ce_rows_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr]),
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr]),
@@ -62,6 +62,18 @@ PROTOTYPES = {
     "sfmi_decode_gemm_slab_floats": (sz, [i32, i32, i32]),
     "sfmi_gpt_embed_packed_f32": (i32, [c_ptr] * 9 + [i32] * 4 + [c_ptr]),
     "sfmi_set_len_i32": (i32, [c_ptr, c_ptr, i32, i32, c_ptr]),
+    # training step (csrc/train.hip)
+    "sfmi_transpose_f32": (i32, [c_ptr, c_ptr, i32, i32, i32, i32, c_ptr]),
+    "sfmi_colsum_f32": (i32, [c_ptr, c_ptr, i32, i32, i32, i32, c_ptr]),
+    "sfmi_gelu_f32": (i32, [c_ptr, c_ptr, i64, c_ptr]),
+    "sfmi_gelu_bwd_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
+    "sfmi_layernorm_bwd_f32": (i32, [c_ptr] * 8 + [i32, i32, c_ptr]),
+    "sfmi_ce_fwd_bwd_f32": (i32, [c_ptr] * 4 + [i32] * 5 + [C.c_float, c_ptr]),
+    "sfmi_attn_bwd_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [c_ptr]),
+    "sfmi_embed_scatter_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, c_ptr]),
+    "sfmi_fixed_to_float_f32": (i32, [c_ptr, c_ptr, i64, i32, c_ptr]),
+    "sfmi_add_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
+    "sfmi_adamw_f32": (i32, [c_ptr] * 4 + [i64] + [C.c_float] * 5 + [i32, c_ptr]),
 }
 
 

@@ -28,6 +28,7 @@ struct RowPrepArgs {
   const int *seq, *len, *Lc;  // (B,Lmax,2), (B), (B)
   const int* nval;            // prefill rows (b,t) are valid for t < nval[b] (NULL: Lc[b]-1)
   const int* extra;           // optional explicit extra index (B,Lmax) (NULL: AR_N rule, representers.py:188-196)
+  int* extra_out;             // optional: the extra index actually used, (M) ints (needed by the embedding backward)
   // ACCUM source (mode 1)
   const float* resid_in;   // (M,D)
   const float* part;       // (S,M,D) or null
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void rowprep_kernel(RowPrepArgs a) {
       ext = cs[2 * (lo < lc ? lo : lc - 1)];
     }
   }
+  if (a.mode == 0 && a.extra_out && tid == 0) a.extra_out[m] = ext;
   int addrow = -1;
   if (a.mode == 1 && a.Eadd) addrow = a.seq[((long long)b * a.Lmax + t + 1) * 2];
 #pragma unroll
@@ -806,12 +808,13 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
 // replaces get_embeddings (mingpt.py:256-286) + the AR_N extra index (representers.py:188-196,432-442)
 // (+ LayerNorm ln1 of the first block).  P == 0: one row per sequence at t = len[b]-1; P > 0: prefill rows (b,t<P).
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
-                       const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, float* resid_out,
-                       float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax, int end0, void* stream) {
+                       const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, int* extra_out,
+                       float* resid_out, float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax,
+                       int end0, void* stream) {
   if (!E0 || !E1 || !Ex || !pos_emb || !cond_pos_emb || !seq || !len || !Lc || D % 4 || D > 4096) return SFMI_EINVAL;
   RowPrepArgs a = {};
   a.E0 = E0; a.E1 = E1; a.Ex = Ex; a.pos_emb = pos_emb; a.cond_pos_emb = cond_pos_emb; a.seq = seq; a.len = len; a.Lc = Lc;
-  a.nval = nval; a.extra = extra;
+  a.nval = nval; a.extra = extra; a.extra_out = extra_out;
   a.resid_out = resid_out; a.xn = xn; a.gamma = gamma; a.beta = beta; a.mode = 0; a.M = P ? B * P : B; a.D = D; a.Lmax = Lmax;
   a.P = P; a.end0 = end0;
   hipLaunchKernelGGL(rowprep_kernel, dim3(a.M), dim3(256), 0, (hipStream_t)stream, a);

@@ -1,0 +1,444 @@
+// Training-step kernels for CondTupleGPT on gfx950 (backward of the blocks, AdamW) — SURVEY §8 a25.
+//
+// Reference: ShapeFormer.forward / shared_step / configure_optimizers (shapeformer/models/shapeformer/
+// shapeformer.py:26-46,132-207), Block / CausalSelfAttention (transformer/mingpt.py:46-111).  The reference gets its
+// backward from autograd over ~40 ATen ops per block; here the matmul-shaped gradients reuse the f32-MFMA GEMM
+// (sfmi_gemm_f32 on transposed operands) and this file provides everything that is not a GEMM: transposes, column
+// reductions, GELU / LayerNorm / softmax-cross-entropy backward, causal-attention backward (recompute form, no LxL
+// tensor is stored), embedding-gradient scatter, AdamW.  All reductions have a fixed order or use 2^-32 fixed-point
+// integer atomics, so gradients are bit-reproducible run to run.
+#include "sfmi_common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// out[c][r] = in[r][c] ; out has Rpad >= R columns, columns R..Rpad-1 are zero-filled (GEMM K must be a multiple of 16)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
+                                                        int ldin, int Rpad) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? in[(long long)r * ldin + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < Rpad) out[(long long)c * Rpad + r] = tile[tx][i];
+  }
+}
+
+// out[n] = sum_m x[m][n]  (fixed order: each block owns 64 columns, 4 row-lanes, then a 4-way tree)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int ld,
+                                                     int accumulate) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (n < N)
+    for (int m = rl; m < M; m += 4) s += x[(long long)m * ld + n];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[n] = accumulate ? out[n] + t : t;
+  }
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = gelu_f(x[i]);
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = dy[i] * gelu_grad(x[i]);
+}
+
+// LayerNorm backward, row part (one workgroup per row):
+//   xhat = (x-mean)*rstd ; g = dy*gamma ; dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) (+ dres)
+// also stores mean/rstd per row for the column reductions of dgamma/dbeta.
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                          float* __restrict__ dx, float* __restrict__ stats /*(M,2)*/, int D) {
+  __shared__ float red[12];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (long long)m * D;
+  const float* dyr = dy + (long long)m * D;
+  float s = 0.f;
+  for (int c = tid; c < D; c += 256) s += xr[c];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)D;
+  float q = 0.f;
+  for (int c = tid; c < D; c += 256) { const float d = xr[c] - mean; q += d * d; }
+  q = wave_sum(q);
+  if (lane == 0) red[4 + wave] = q;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)D + 1e-5f);
+  float a = 0.f, b = 0.f;
+  for (int c = tid; c < D; c += 256) {
+    const float g = dyr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+    a += g; b += g * xh;
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  __syncthreads();
+  if (lane == 0) { red[wave] = a; red[4 + wave] = b; }
+  __syncthreads();
+  const float ma = ((red[0] + red[1]) + (red[2] + red[3])) / (float)D, mb = ((red[4] + red[5]) + (red[6] + red[7])) / (float)D;
+  for (int c = tid; c < D; c += 256) {
+    const float g = dyr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+    float v = rstd * (g - ma - xh * mb);
+    if (dres) v += dres[(long long)m * D + c];
+    dx[(long long)m * D + c] = v;
+  }
+  if (tid == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+}
+
+// LayerNorm backward, parameter part: dgamma[c] += sum_m dy*xhat ; dbeta[c] += sum_m dy
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ stats, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int M, int D) {
+  __shared__ float rg[4][64], rb[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float g = 0.f, b = 0.f;
+  if (c < D)
+    for (int m = rl; m < M; m += 4) {
+      const float d = dy[(long long)m * D + c];
+      g += d * (x[(long long)m * D + c] - stats[2 * m]) * stats[2 * m + 1];
+      b += d;
+    }
+  rg[rl][threadIdx.x & 63] = g; rb[rl][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    dgamma[c] += (rg[0][threadIdx.x] + rg[1][threadIdx.x]) + (rg[2][threadIdx.x] + rg[3][threadIdx.x]);
+    dbeta[c] += (rb[0][threadIdx.x] + rb[1][threadIdx.x]) + (rb[2][threadIdx.x] + rb[3][threadIdx.x]);
+  }
+}
+
+// softmax cross-entropy: loss_row[m] = lse - logit[target] ; dlogits = (softmax - onehot) * scale for rows with
+// t >= t0 (row m = (b, t), t = m % L), zero otherwise (F.cross_entropy mean over B*L_z rows, shapeformer.py:134-139)
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int* __restrict__ target,
+                                                         float* __restrict__ loss_rows, float* __restrict__ dlogits, int V, int ld,
+                                                         int L, int t0, float scale) {
+  __shared__ float red[8];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (long long)m * ld;
+  float* drow = dlogits + (long long)m * ld;
+  const bool active = (m % L) >= t0;
+  if (!active) {
+    for (int v = tid; v < ld; v += 256) drow[v] = 0.f;
+    if (tid == 0) loss_rows[m] = 0.f;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int v = tid; v < V; v += 256) mx = fmaxf(mx, row[v]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int v = tid; v < V; v += 256) se += __expf(row[v] - mx);
+  se = wave_sum(se);
+  if (lane == 0) red[4 + wave] = se;
+  __syncthreads();
+  const float tot = (red[4] + red[5]) + (red[6] + red[7]);
+  const int tg = target[m];
+  for (int v = tid; v < ld; v += 256) {
+    float g = 0.f;
+    if (v < V) g = (__expf(row[v] - mx) / tot - (v == tg ? 1.f : 0.f)) * scale;
+    drow[v] = g;
+  }
+  if (tid == 0) loss_rows[m] = mx + __logf(tot) - row[tg];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// causal attention backward (recompute form).  qkv (B*L, 3D) rows m=(b,t) [q|k|v], y = attention output (B*L, D),
+// dy = its gradient.  Head dim 64.  lse[b][h][t] = log-sum-exp of the scaled scores of row t (written by the forward).
+//   delta_i = dy_i . y_i ; p_ij = exp(s_ij - lse_i) ; ds_ij = p_ij (dy_i . v_j - delta_i)
+//   dq_i = scale sum_j ds_ij k_j ; dk_j = scale sum_i ds_ij q_i ; dv_j = sum_i p_ij dy_i
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_lse_kernel(const float* __restrict__ qkv, float* __restrict__ lse, int L, int D,
+                                                       float scale) {
+  // grid (B, H, ceil(L/64)); thread (qi = tid>>2, c16 = tid&3)
+  __shared__ __attribute__((aligned(16))) float Ks[64][64];
+  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, H = gridDim.y, tid = threadIdx.x;
+  const int q0 = qb * 64, qi = tid >> 2, c16 = tid & 3, tq = q0 + qi;
+  const bool qok = tq < L;
+  f32x4 qf[4];
+  const float* qp = qkv + ((long long)b * L + (qok ? tq : q0)) * 3 * D + h * 64 + 16 * c16;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) qf[e] = reinterpret_cast<const f32x4*>(qp)[e] * scale;
+  float mrun = -INFINITY, lrun = 0.f;
+  const int kend = min(L, q0 + 64);
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      const int tk = min(k0 + r, L - 1);
+      *reinterpret_cast<f32x4*>(&Ks[r][4 * c]) = *reinterpret_cast<const f32x4*>(qkv + ((long long)b * L + tk) * 3 * D + D + h * 64 + 4 * c);
+    }
+    __syncthreads();
+    const int jn = min(64, kend - k0);
+    for (int j = 0; j < jn; ++j) {
+      const f32x4* kr = reinterpret_cast<const f32x4*>(&Ks[j][16 * c16]);
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const f32x4 kf = kr[e]; d += (qf[e][0] * kf[0] + qf[e][1] * kf[1]) + (qf[e][2] * kf[2] + qf[e][3] * kf[3]); }
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
+      if (k0 + j > tq) continue;
+      const float mnew = fmaxf(mrun, d);
+      lrun = lrun * __expf(mrun - mnew) + __expf(d - mnew);
+      mrun = mnew;
+    }
+  }
+  if (qok && c16 == 0) lse[((long long)b * H + h) * L + tq] = mrun + __logf(lrun);
+}
+
+// dq: grid (B, H, ceil(L/64)) ; thread (qi, c16)
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ y,
+                                                          const float* __restrict__ dy, const float* __restrict__ lse,
+                                                          float* __restrict__ dqkv, int L, int D, float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[64][64], Vs[64][64];
+  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, H = gridDim.y, tid = threadIdx.x;
+  const int q0 = qb * 64, qi = tid >> 2, c16 = tid & 3, tq = q0 + qi;
+  const bool qok = tq < L;
+  const long long mrow = (long long)b * L + (qok ? tq : q0);
+  f32x4 qf[4], dyf[4], acc[4];
+  float delta = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    qf[e] = reinterpret_cast<const f32x4*>(qkv + mrow * 3 * D + h * 64 + 16 * c16)[e] * scale;
+    dyf[e] = reinterpret_cast<const f32x4*>(dy + mrow * D + h * 64 + 16 * c16)[e];
+    const f32x4 yf = reinterpret_cast<const f32x4*>(y + mrow * D + h * 64 + 16 * c16)[e];
+    delta += (dyf[e][0] * yf[0] + dyf[e][1] * yf[1]) + (dyf[e][2] * yf[2] + dyf[e][3] * yf[3]);
+    acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  delta += __shfl_xor(delta, 1, 64); delta += __shfl_xor(delta, 2, 64);
+  const float ls = qok ? lse[((long long)b * H + h) * L + tq] : 0.f;
+  const int kend = min(L, q0 + 64);
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      const int tk = min(k0 + r, L - 1);
+      const float* src = qkv + ((long long)b * L + tk) * 3 * D + h * 64 + 4 * c;
+      *reinterpret_cast<f32x4*>(&Ks[r][4 * c]) = *reinterpret_cast<const f32x4*>(src + D);
+      *reinterpret_cast<f32x4*>(&Vs[r][4 * c]) = *reinterpret_cast<const f32x4*>(src + 2 * D);
+    }
+    __syncthreads();
+    const int jn = min(64, kend - k0);
+    for (int j = 0; j < jn; ++j) {
+      const f32x4* kr = reinterpret_cast<const f32x4*>(&Ks[j][16 * c16]);
+      const f32x4* vr = reinterpret_cast<const f32x4*>(&Vs[j][16 * c16]);
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 kf = kr[e], vf = vr[e];
+        s += (qf[e][0] * kf[0] + qf[e][1] * kf[1]) + (qf[e][2] * kf[2] + qf[e][3] * kf[3]);
+        dp += (dyf[e][0] * vf[0] + dyf[e][1] * vf[1]) + (dyf[e][2] * vf[2] + dyf[e][3] * vf[3]);
+      }
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+      dp += __shfl_xor(dp, 1, 64); dp += __shfl_xor(dp, 2, 64);
+      if (k0 + j > tq) continue;
+      const float ds = __expf(s - ls) * (dp - delta) * scale;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] + kr[e] * ds;
+    }
+  }
+  if (qok) {
+    float* o = dqkv + mrow * 3 * D + h * 64 + 16 * c16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) reinterpret_cast<f32x4*>(o)[e] = acc[e];
+  }
+}
+
+// dk, dv: grid (B, H, ceil(L/64)) ; thread (kj, c16) ; loops over queries i >= first key of the block
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ lse,
+                                                           float* __restrict__ dqkv, int L, int D, float scale) {
+  __shared__ __attribute__((aligned(16))) float Qs[64][64], Gs[64][64];
+  __shared__ float Ls[64], Ds[64];
+  const int b = blockIdx.x, h = blockIdx.y, kb = blockIdx.z, H = gridDim.y, tid = threadIdx.x;
+  const int k0 = kb * 64, kj = tid >> 2, c16 = tid & 3, tk = k0 + kj;
+  const bool kok = tk < L;
+  const long long krow = (long long)b * L + (kok ? tk : k0);
+  f32x4 kf[4], vf[4], dk[4], dv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    kf[e] = reinterpret_cast<const f32x4*>(qkv + krow * 3 * D + D + h * 64 + 16 * c16)[e];
+    vf[e] = reinterpret_cast<const f32x4*>(qkv + krow * 3 * D + 2 * D + h * 64 + 16 * c16)[e];
+    dk[e] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[e] = dk[e];
+  }
+  for (int i0 = k0; i0 < L; i0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      const int ti = min(i0 + r, L - 1);
+      const long long mr = (long long)b * L + ti;
+      *reinterpret_cast<f32x4*>(&Qs[r][4 * c]) = *reinterpret_cast<const f32x4*>(qkv + mr * 3 * D + h * 64 + 4 * c);
+      *reinterpret_cast<f32x4*>(&Gs[r][4 * c]) = *reinterpret_cast<const f32x4*>(dy + mr * D + h * 64 + 4 * c);
+    }
+    if (tid < 64) {
+      const int ti = min(i0 + tid, L - 1);
+      const long long mr = (long long)b * L + ti;
+      Ls[tid] = lse[((long long)b * H + h) * L + ti];
+      float d = 0.f;
+      for (int c = 0; c < 64; ++c) d += dy[mr * D + h * 64 + c] * y[mr * D + h * 64 + c];
+      Ds[tid] = d;
+    }
+    __syncthreads();
+    const int in_ = min(64, L - i0);
+    for (int i = 0; i < in_; ++i) {
+      const f32x4* qr = reinterpret_cast<const f32x4*>(&Qs[i][16 * c16]);
+      const f32x4* gr = reinterpret_cast<const f32x4*>(&Gs[i][16 * c16]);
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 qv = qr[e], gv = gr[e];
+        s += (qv[0] * kf[e][0] + qv[1] * kf[e][1]) + (qv[2] * kf[e][2] + qv[3] * kf[e][3]);
+        dp += (gv[0] * vf[e][0] + gv[1] * vf[e][1]) + (gv[2] * vf[e][2] + gv[3] * vf[e][3]);
+      }
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+      dp += __shfl_xor(dp, 1, 64); dp += __shfl_xor(dp, 2, 64);
+      if (i0 + i < tk) continue;  // causal: query index must be >= key index
+      const float p = __expf(s * scale - Ls[i]);
+      const float ds = p * (dp - Ds[i]) * scale;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dk[e] = dk[e] + qr[e] * ds; dv[e] = dv[e] + gr[e] * p; }
+    }
+  }
+  if (kok) {
+    float* o = dqkv + krow * 3 * D + h * 64 + 16 * c16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { reinterpret_cast<f32x4*>(o + D)[e] = dk[e]; reinterpret_cast<f32x4*>(o + 2 * D)[e] = dv[e]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// embedding gradients: acc[idx[m]][:] += dx[m][:] in 2^-32 fixed point (int64 atomics: associative => deterministic)
+__global__ void embed_scatter_kernel(const float* __restrict__ dx, const int* __restrict__ idx, long long* __restrict__ acc,
+                                     long long M, int D) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * D) return;
+  const long long m = i / D;
+  const int c = (int)(i - m * D);
+  const long long q = __double2ll_rn((double)dx[i] * 4294967296.0);
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc + (long long)idx[m] * D + c), (unsigned long long)q);
+}
+__global__ void fixed_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, long long n, int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = (float)((double)acc[i] * (1.0 / 4294967296.0));
+  out[i] = accumulate ? out[i] + v : v;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+
+// AdamW (torch.optim.AdamW semantics, shapeformer.py:158-207): decoupled weight decay, bias-corrected moments
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+extern "C" {
+
+int sfmi_transpose_f32(const float* in, float* out, int R, int C, int ldin, int Rpad, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0 || Rpad < R) return SFMI_EINVAL;
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (Rpad + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C, ldin, Rpad);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+int sfmi_colsum_f32(const float* x, float* out, int M, int N, int ld, int accumulate, void* stream) {
+  if (!x || !out || M <= 0 || N <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, out, M, N, ld, accumulate);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+int sfmi_gelu_f32(const float* x, float* y, long long n, void* stream) {  // nn.GELU (mingpt.py:103)
+  if (!x || !y || n <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+int sfmi_gelu_bwd_f32(const float* dy, const float* x, float* dx, long long n, void* stream) {
+  if (!dy || !x || !dx || n <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// LayerNorm backward: dx = dLN/dx (+ dres) ; dgamma/dbeta ACCUMULATE.  stats: M*2 floats of scratch.
+int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* dgamma,
+                           float* dbeta, float* stats, int M, int D, void* stream) {
+  if (!dy || !x || !gamma || !dx || !stats || M <= 0 || D <= 0) return SFMI_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3(M), dim3(256), 0, st, dy, x, gamma, dres, dx, stats, D);
+  if (dgamma && dbeta) hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((D + 63) / 64), dim3(256), 0, st, dy, x, stats, dgamma, dbeta, M, D);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// F.cross_entropy forward + backward over rows m=(b,t), active for t >= t0 (shapeformer.py:132-140)
+int sfmi_ce_fwd_bwd_f32(const float* logits, const int* target, float* loss_rows, float* dlogits, int M, int V, int ld, int L,
+                        int t0, float scale, void* stream) {
+  if (!logits || !target || !loss_rows || !dlogits || M <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, target, loss_rows, dlogits, V, ld, L, t0, scale);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// causal self-attention backward (mingpt.py:73-91), head dim 64: dqkv (B*L,3D) from qkv, y, dy.  lse: B*H*L scratch.
+int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* lse, float* dqkv, int B, int L, int D, int H,
+                      void* stream) {
+  if (!qkv || !y || !dy || !lse || !dqkv || D / H != 64) return SFMI_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(B, H, (L + 63) / 64);
+  hipLaunchKernelGGL(attn_lse_kernel, grid, dim3(256), 0, st, qkv, lse, L, D, 0.125f);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, qkv, y, dy, lse, dqkv, L, D, 0.125f);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, qkv, y, dy, lse, dqkv, L, D, 0.125f);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// nn.Embedding backward: acc (rows*D int64, zeroed by the caller) += scatter(dx) ; then sfmi_fixed_to_float_f32
+int sfmi_embed_scatter_f32(const float* dx, const int* idx, long long* acc, long long M, int D, void* stream) {
+  if (!dx || !idx || !acc || M <= 0) return SFMI_EINVAL;
+  const long long n = M * D;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx, idx, acc, M, D);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+int sfmi_fixed_to_float_f32(const long long* acc, float* out, long long n, int accumulate, void* stream) {
+  if (!acc || !out || n <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, out, n, accumulate);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+int sfmi_add_f32(const float* a, const float* b, float* out, long long n, void* stream) {
+  if (!a || !b || !out || n <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// torch.optim.AdamW step on a flat parameter segment (shapeformer.py:158-207 groups: wd on Linear weights only)
+int sfmi_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) return SFMI_EINVAL;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+}  // extern "C"

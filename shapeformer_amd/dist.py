@@ -49,3 +49,12 @@ def unshard(per_rank, n_items: int):
     """Inverse of the striding: per_rank[r][j] is item r + j*world."""
     world = len(per_rank)
     return [per_rank[i % world][i // world] for i in range(n_items)]
+
+
+def allreduce_mean_(flat: torch.Tensor, dist):
+    """DDP gradient synchronisation: ONE collective over the flat gradient buffer, mean over ranks (the reference gets
+    this implicitly from Lightning's `accelerator="ddp"`, trainer.py:22,93).  RCCL on ROCm, gloo in CPU tests."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat)
+        flat.div_(dist.get_world_size())
+    return flat

@@ -90,8 +90,14 @@ class CondTupleGPT:
                 self.layers.append(ly)
         self.head_ln = [(g(f"heads.{s}.0.weight"), g(f"heads.{s}.0.bias")) for s in range(2)]
         self.head_w = [g(f"heads.{s}.1.weight") for s in range(2)]
-        # ---- decode-path weights: LayerNorm folded into the GEMM (csrc/gpt.hip dgemm_kernel) ----------------
-        #   LN(x) W^T + b = rstd (x W'^T - mean c1) + c2,  W' = W diag(gamma), c1 = rowsum(W'), c2 = W beta + b
+        self.zero_bqkv = torch.zeros(3 * self.D, device=dev)
+        self.refresh_decode_weights()
+
+    def refresh_decode_weights(self):
+        """(Re)build the decode-path weights from the raw parameters: LayerNorm folded into the GEMM
+        (csrc/gpt.hip dgemm_kernel):  LN(x) W^T + b = rstd (x W'^T - mean c1) + c2,  W' = W diag(gamma),
+        c1 = rowsum(W'), c2 = W beta + b; all matrices in 16x16x4-MFMA fragment order.  Call after the raw
+        weights change (training)."""
         def fold(w, bias, ln):
             gam, bet = ln
             wp = w * gam[None, :]
@@ -106,7 +112,8 @@ class CondTupleGPT:
             ly.pfc1, ly.c1fc1, ly.c2fc1 = fold(ly.wfc1, ly.bfc1, ly.ln2)
             ly.pproj, ly.pfc2 = pack_skinny16(ly.wproj), pack_skinny16(ly.wfc2)
         self.head_f = [fold(self.head_w[s], None, self.head_ln[s]) for s in range(2)]
-        self.zero_bqkv = torch.zeros(3 * self.D, device=dev)
+        self.head_w_pad = [torch.cat([w, w.new_zeros(self.Vpad - self.V, self.D)], 0).contiguous() for w in self.head_w]
+        self._graph = None
 
     # ------------------------------------------------------------------ state
     def _alloc(self, B, max_steps):
@@ -148,7 +155,7 @@ class CondTupleGPT:
     def _embed(self, st, B, P, resid, xn, ln):
         L.check(L.lib().sfmi_gpt_embed_f32(L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb),
                                            L.ptr(self.cond_pos_emb), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
-                                           L.ptr(st.get("nval")), L.ptr(st.get("extra")),
+                                           L.ptr(st.get("nval")), L.ptr(st.get("extra")), L.ptr(st.get("extra_out")),
                                            L.ptr(resid), L.ptr(xn), L.ptr(ln[0]) if ln else None, L.ptr(ln[1]) if ln else None,
                                            B, P, self.D, self.Lmax + 1,
                                            self.end[0], L.stream_ptr()), "sfmi_gpt_embed_f32")
@@ -173,8 +180,6 @@ class CondTupleGPT:
         def heads(s):
             if not want_logits:
                 return
-            if not hasattr(self, "head_w_pad"):   # (V,D) -> rows padded to a multiple of 32 for the GEMM tiles
-                self.head_w_pad = [torch.cat([w, w.new_zeros(self.Vpad - self.V, D)], 0).contiguous() for w in self.head_w]
             self._rowprep(resid, None, None, 0, M, None, xn, self.head_ln[s])
             lg = f(M, self.Vpad)
             self._gemm(xn, self.head_w_pad[s], None, None, lg, M, self.Vpad, D)

@@ -1,0 +1,263 @@
+"""Training step of the ShapeFormer transformer on MI355X.
+
+Mirrors ShapeFormer.forward / shared_step / configure_optimizers (shapeformer/models/shapeformer/shapeformer.py:26-46,
+132-207): teacher-forced logits over cz[:, :-1], mean of the two cross entropies on the outputs from index L_c-1 on
+(end-token padding included), AdamW(lr, betas (0.9, 0.95)) with weight decay 0.01 on Linear weights only.
+Every arithmetic step is a libsfmi (HIP) call: GEMM-shaped gradients go through the f32-MFMA GEMM on transposed
+operands, the rest through csrc/train.hip.  Gradients live in ONE flat buffer so data-parallel training is a single
+RCCL all-reduce (`torch.distributed`, backend "nccl" on ROCm) per step; the frozen VQDIF is replicated and excluded.
+
+The reference's dropout (p = 0.01, mingpt attn/resid/embd) is not applied: training here is the deterministic
+eval-mode graph (documented deviation; gradients are checked against the oracle's autograd in eval mode).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class GPTTrainer:
+    def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None):
+        self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
+        self.lr, self.betas, self.wd, self.eps, self.dist = lr, betas, weight_decay, eps, dist
+        self.step_count = 0
+        g = gpt
+        # ---- parameter table: (name, tensor, decay?) ; fused QKV is trained as one tensor (equivalent) -----------
+        P = []
+        for li, ly in enumerate(g.layers):
+            p = f"L{li}."
+            P += [(p + "ln1.w", ly.ln1[0], False), (p + "ln1.b", ly.ln1[1], False), (p + "wqkv", ly.wqkv, True),
+                  (p + "bqkv", ly.bqkv, False), (p + "wproj", ly.wproj, True), (p + "bproj", ly.bproj, False),
+                  (p + "ln2.w", ly.ln2[0], False), (p + "ln2.b", ly.ln2[1], False), (p + "wfc1", ly.wfc1, True),
+                  (p + "bfc1", ly.bfc1, False), (p + "wfc2", ly.wfc2, True), (p + "bfc2", ly.bfc2, False)]
+        for s in range(2):
+            P += [(f"head{s}.ln.w", g.head_ln[s][0], False), (f"head{s}.ln.b", g.head_ln[s][1], False),
+                  (f"head{s}.w", g.head_w[s], True)]
+        P += [("E0", g.E[0], False), ("E1", g.E[1], False), ("Ex", g.Ex, False), ("pos_emb", g.pos_emb, False),
+              ("cond_pos_emb", g.cond_pos_emb, False)]
+        self.params = P
+        n = sum(t.numel() for _, t, _ in P)
+        self.flat_grad = torch.zeros(n, device=self.dev)
+        self.grad, self.m, self.v = {}, {}, {}
+        o = 0
+        for name, t, _ in P:
+            self.grad[name] = self.flat_grad[o:o + t.numel()].view(t.shape)
+            o += t.numel()
+        self.flat_m = torch.zeros(n, device=self.dev)
+        self.flat_v = torch.zeros(n, device=self.dev)
+        self._wT = {}
+
+    # ------------------------------------------------------------------ small wrappers
+    def _f(self, *shape):
+        return torch.empty(shape, device=self.dev, dtype=torch.float32)
+
+    def _gemm(self, x, w, bias, resid, y, M, N, K, act=0):
+        L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, 0, 0, L.stream_ptr()), "gemm")
+
+    def _T(self, x, R, C, ld=None, Rpad=None):
+        Rpad = Rpad or _ru(R, 16)
+        out = self._f(C, Rpad)
+        L.check(L.lib().sfmi_transpose_f32(L.ptr(x), L.ptr(out), R, C, ld or C, Rpad, L.stream_ptr()), "transpose")
+        return out
+
+    def _wt(self, name, w):
+        """Transposed weight copy (refreshed after every optimizer step) for dX = dY W as an NT GEMM."""
+        if name not in self._wT:
+            N, K = w.shape
+            self._wT[name] = self._T(w, N, K, Rpad=_ru(N, 16))
+        return self._wT[name]
+
+    def _dW(self, dY, X, M, N, K, gname):
+        """grad[gname] (N,K) += dY^T (N,M) X (M,K)  via NT GEMM on transposed activations (K-dim = M padded to 16)."""
+        Mp = _ru(M, 16)
+        dYT, XT = self._T(dY, M, N, Rpad=Mp), self._T(X, M, K, Rpad=Mp)
+        Np = _ru(N, 1)
+        out = self.grad[gname]
+        assert K % 32 == 0
+        self._gemm(dYT, XT, None, out if self._acc else None, out, N, K, Mp)
+
+    def _colsum(self, x, M, N, gname):
+        L.check(L.lib().sfmi_colsum_f32(L.ptr(x), L.ptr(self.grad[gname]), M, N, N, int(self._acc), L.stream_ptr()), "colsum")
+
+    def _ln_bwd(self, dy, x, gamma, dres, M, gw, gb):
+        dx = self._f(M, self.D)
+        stats = self._f(M, 2)
+        L.check(L.lib().sfmi_layernorm_bwd_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(self.grad[gw]),
+                                               L.ptr(self.grad[gb]), L.ptr(stats), M, self.D, L.stream_ptr()), "ln_bwd")
+        return dx
+
+    def _scatter(self, dx, idx, table, M, accumulate=True):
+        rows = self.grad[table].shape[0]
+        acc = torch.zeros(rows * self.D, device=self.dev, dtype=torch.int64)
+        L.check(L.lib().sfmi_embed_scatter_f32(L.ptr(dx), L.ptr(idx), L.ptr(acc), M, self.D, L.stream_ptr()), "scatter")
+        L.check(L.lib().sfmi_fixed_to_float_f32(L.ptr(acc), L.ptr(self.grad[table]), rows * self.D, int(accumulate), L.stream_ptr()), "fix2f")
+
+    # ------------------------------------------------------------------ forward + backward
+    @torch.no_grad()
+    def loss_and_grad(self, c_indices, z_indices, accumulate=False):
+        """-> loss (0-dim tensor).  Gradients of every parameter are left in self.grad[name] (flat buffer)."""
+        g, D, dev, lib = self.g, self.D, self.dev, L.lib()
+        self._acc = accumulate
+        if not accumulate:
+            self.flat_grad.zero_()
+        c = torch.as_tensor(c_indices).to(dev, torch.int32)
+        z = torch.as_tensor(z_indices).to(dev, torch.int32)
+        cz = torch.cat([c, z], 1).contiguous()
+        B, Lc, Lz = c.shape[0], c.shape[1], z.shape[1]
+        Lq = Lc + Lz - 1
+        M = B * Lq
+        assert Lq <= g.Lmax
+        st = dict(seq=torch.zeros(B, g.Lmax + 1, 2, device=dev, dtype=torch.int32),
+                  Lc=torch.full((B,), Lc, device=dev, dtype=torch.int32), len=torch.full((B,), Lq, device=dev, dtype=torch.int32),
+                  nval=torch.full((B,), Lq, device=dev, dtype=torch.int32), extra=None,
+                  extra_out=torch.zeros(M, device=dev, dtype=torch.int32))
+        st["seq"][:, :Lq + 1] = cz
+        kv = self._f(2, B, g.Lmax + 1, D)   # prefill attention also fills a KV cache; scratch here
+        # ---- forward, keeping what the backward needs --------------------------------------------------------
+        saved = []
+        resid = self._f(M, D)
+        xn = self._f(M, D)
+        g._embed(st, B, Lq, resid, xn, g.layers[0].ln1)
+        x0 = resid
+        head_in = {}
+        for li, ly in enumerate(g.layers):
+            s = dict(x_in=resid, xn1=xn)
+            qkv = self._f(M, 3 * D)
+            self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
+            y = self._f(M, D)
+            L.check(lib.sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
+                                                  g.H, g.Lmax + 1, L.stream_ptr()), "attn")
+            r1 = self._f(M, D)
+            self._gemm(y, ly.wproj, ly.bproj, resid, r1, M, D, D)
+            xn2 = self._f(M, D)
+            g._rowprep(r1, None, None, 0, M, None, xn2, ly.ln2)
+            hpre = self._f(M, 4 * D)
+            self._gemm(xn2, ly.wfc1, ly.bfc1, None, hpre, M, 4 * D, D)
+            h = self._f(M, 4 * D)
+            L.check(lib.sfmi_gelu_f32(L.ptr(hpre), L.ptr(h), M * 4 * D, L.stream_ptr()), "gelu")
+            r2 = self._f(M, D)
+            self._gemm(h, ly.wfc2, ly.bfc2, r1, r2, M, D, 4 * D)
+            s.update(qkv=qkv, y=y, r1=r1, xn2=xn2, hpre=hpre, h=h)
+            saved.append(s)
+            resid = r2
+            last = li + 1 == len(g.layers) or g.layers[li + 1].stage != ly.stage
+            if last:
+                head_in[ly.stage] = resid
+            if li + 1 < len(g.layers):
+                nxt = g.layers[li + 1]
+                xn = self._f(M, D)
+                if nxt.stage != ly.stage:
+                    r3 = self._f(M, D)
+                    g._rowprep(resid, None, None, 0, M, r3, xn, nxt.ln1, Eadd=g.E[0], P=Lq, st=st)
+                    resid = r3
+                else:
+                    g._rowprep(resid, None, None, 0, M, None, xn, nxt.ln1)
+        # ---- heads, loss, dlogits ---------------------------------------------------------------------------------
+        tgt = cz[:, 1:, :].contiguous()     # targets of every input position (only t >= Lc-1 are active)
+        loss = torch.zeros((), device=dev)
+        d_head = {}
+        scale = 1.0 / (2.0 * B * Lz)
+        for s in range(2):
+            xnh = self._f(M, D)
+            g._rowprep(head_in[s], None, None, 0, M, None, xnh, g.head_ln[s])
+            lg = self._f(M, g.Vpad)
+            self._gemm(xnh, g.head_w_pad[s], None, None, lg, M, g.Vpad, D)
+            rows, dlg = self._f(M), self._f(M, g.Vpad)
+            t_s = tgt[..., s].contiguous().view(-1)
+            L.check(lib.sfmi_ce_fwd_bwd_f32(L.ptr(lg), L.ptr(t_s), L.ptr(rows), L.ptr(dlg), M, g.V, g.Vpad, Lq, Lc - 1, scale,
+                                            L.stream_ptr()), "ce")
+            loss = loss + rows.sum() * scale     # scalar for logging only
+            # head backward: dW_h = dlg^T xnh ; dxnh = dlg W_h ; LN backward
+            Mp = _ru(M, 16)
+            dlgT, xnhT = self._T(dlg, M, g.Vpad, Rpad=Mp), self._T(xnh, M, D, Rpad=Mp)
+            gh = self.grad[f"head{s}.w"]                                  # rows >= V of dlg^T are zero: write (V,D) directly
+            self._gemm(dlgT, xnhT, None, gh if accumulate else None, gh, g.V, D, Mp)
+            whT = self._T(g.head_w_pad[s], g.Vpad, D, Rpad=g.Vpad)      # (D, Vpad)
+            dxnh = self._f(M, D)
+            self._gemm(dlg, whT, None, None, dxnh, M, D, g.Vpad)
+            d_head[s] = self._ln_bwd(dxnh, head_in[s], g.head_ln[s][0], None, M, f"head{s}.ln.w", f"head{s}.ln.b")
+        # ---- backward through the blocks -----------------------------------------------------------------------------
+        dr = d_head[1]
+        lse = self._f(B, g.H, Lq)
+        for li in range(len(g.layers) - 1, -1, -1):
+            ly, s, p = g.layers[li], saved[li], f"L{li}."
+            if li + 1 < len(g.layers) and g.layers[li + 1].stage != ly.stage:
+                # stage boundary (mingpt.py:294): x1 = h20 + E0[target pos]  ->  dE0 += scatter(dr) ; dh20 = dr + head-0 path
+                self._scatter(dr, tgt[..., 0].contiguous().view(-1), "E0", M, accumulate=True)
+                dsum = self._f(M, D)
+                L.check(lib.sfmi_add_f32(L.ptr(dr), L.ptr(d_head[0]), L.ptr(dsum), M * D, L.stream_ptr()), "add")
+                dr = dsum
+            # fc2
+            self._colsum(dr, M, D, p + "bfc2")
+            self._dW(dr, s["h"], M, D, 4 * D, p + "wfc2")
+            dh = self._f(M, 4 * D)
+            self._gemm(dr, self._wt(p + "wfc2", ly.wfc2), None, None, dh, M, 4 * D, D)
+            dhpre = self._f(M, 4 * D)
+            L.check(lib.sfmi_gelu_bwd_f32(L.ptr(dh), L.ptr(s["hpre"]), L.ptr(dhpre), M * 4 * D, L.stream_ptr()), "gelu_bwd")
+            # fc1
+            self._colsum(dhpre, M, 4 * D, p + "bfc1")
+            self._dW(dhpre, s["xn2"], M, 4 * D, D, p + "wfc1")
+            dxn2 = self._f(M, D)
+            self._gemm(dhpre, self._wt(p + "wfc1", ly.wfc1), None, None, dxn2, M, D, 4 * D)
+            dr1 = self._ln_bwd(dxn2, s["r1"], ly.ln2[0], dr, M, p + "ln2.w", p + "ln2.b")
+            # proj
+            self._colsum(dr1, M, D, p + "bproj")
+            self._dW(dr1, s["y"], M, D, D, p + "wproj")
+            dy = self._f(M, D)
+            self._gemm(dr1, self._wt(p + "wproj", ly.wproj), None, None, dy, M, D, D)
+            # attention
+            dqkv = self._f(M, 3 * D)
+            L.check(lib.sfmi_attn_bwd_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(lse), L.ptr(dqkv), B, Lq, D, g.H,
+                                          L.stream_ptr()), "attn_bwd")
+            # qkv
+            self._colsum(dqkv, M, 3 * D, p + "bqkv")
+            self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv")
+            dxn1 = self._f(M, D)
+            self._gemm(dqkv, self._wt(p + "wqkv", ly.wqkv), None, None, dxn1, M, D, 3 * D)
+            dr = self._ln_bwd(dxn1, s["x_in"], ly.ln1[0], dr1, M, p + "ln1.w", p + "ln1.b")
+            saved[li] = None
+        # ---- embeddings (mingpt.py:256-286): E0[pos] + E1[val] + Ex[extra] + positional --------------------------------
+        idx = cz[:, :Lq, :]
+        self._scatter(dr, idx[..., 0].contiguous().view(-1), "E0", M)
+        self._scatter(dr, idx[..., 1].contiguous().view(-1), "E1", M, accumulate=accumulate)
+        self._scatter(dr, st["extra_out"], "Ex", M, accumulate=accumulate)   # AR_N index as used by the forward
+        # positional tables: row t of every batch item -> cond_pos_emb[t] (t < Lc) / pos_emb[t - Lc]  (sum over batch)
+        gc, gp = self.grad["cond_pos_emb"], self.grad["pos_emb"]
+        L.check(lib.sfmi_colsum_f32(L.ptr(dr), L.ptr(gc), B, Lc * D, Lq * D, int(accumulate), L.stream_ptr()), "colsum")
+        if Lq > Lc:
+            L.check(lib.sfmi_colsum_f32(dr.data_ptr() + Lc * D * 4, L.ptr(gp), B, (Lq - Lc) * D, Lq * D, int(accumulate),
+                                        L.stream_ptr()), "colsum")
+        return loss
+
+    # ------------------------------------------------------------------ optimizer / data parallel
+    @torch.no_grad()
+    def all_reduce_grads(self):
+        """DDP gradient synchronisation: ONE collective over the flat gradient buffer (mean over ranks)."""
+        from .dist import allreduce_mean_
+        allreduce_mean_(self.flat_grad, self.dist)
+
+    @torch.no_grad()
+    def optimizer_step(self):
+        """torch.optim.AdamW over the two reference groups (shapeformer.py:198-206)."""
+        self.step_count += 1
+        o = 0
+        for name, t, decay in self.params:
+            n = t.numel()
+            L.check(L.lib().sfmi_adamw_f32(L.ptr(t), L.ptr(self.flat_grad[o:o + n]), L.ptr(self.flat_m[o:o + n]),
+                                           L.ptr(self.flat_v[o:o + n]), n, self.lr, self.betas[0], self.betas[1], self.eps,
+                                           self.wd if decay else 0.0, self.step_count, L.stream_ptr()), "adamw")
+            o += n
+        self._wT.clear()                 # transposed copies are stale now
+        self.g.refresh_decode_weights()  # LN-folded / fragment-packed decode weights follow the raw weights
+
+    @torch.no_grad()
+    def training_step(self, c_indices, z_indices):
+        loss = self.loss_and_grad(c_indices, z_indices)
+        self.all_reduce_grads()
+        self.optimizer_step()
+        return loss

@@ -122,6 +122,9 @@ tl, ll = D.gather_ragged_tokens(tok, ln, dist, world)
 flat = D.unshard([[ (t[j], l[j]) for j in range(4)] for t, l in zip(tl, ll)], len(items))
 ok = all(int(l) == i + 1 and bool((t[: i + 1] == i).all()) for i, (t, l) in enumerate(flat))
 t = torch.tensor([float(rank + 1)]); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+g = torch.arange(6, dtype=torch.float32) * (rank + 1)          # flat "gradient" buffer of the trainer
+D.allreduce_mean_(g, dist)
+ok = ok and torch.allclose(g, torch.arange(6, dtype=torch.float32) * (1 + world) / 2)
 print("OK" if ok and t.item() == world else "FAIL", flush=True)
 dist.barrier(); dist.destroy_process_group()
 """

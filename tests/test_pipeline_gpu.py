@@ -91,3 +91,34 @@ def test_completion_is_deterministic_and_matches_oracle_decode(dev, vq16_sd, vq1
         assert np.all(np.diff(live) > 0)
     ref = O.decode_index(vq16_sd_t, dense_a.cpu().long()[:3], torch.from_numpy(O.make_grid(32))[None].expand(3, -1, -1))[..., 0]
     assert (occ_a.cpu()[:3] - ref).abs().max().item() < 5e-4
+
+
+def test_config4_res32_256cubed_stress(dev):
+    """BASELINE config 4: VQDIF res32 + 256^3 SDF query grid, batch 8 (134 M query points).  Properties: finite,
+    lattice mode == point mode on a sample of lattice points (bit-equal), sigmoid output in [0,1]."""
+    import time
+    from oracle import vqdif_oracle as O
+    from shapeformer_amd import ops, synthetic, weights as W
+    from shapeformer_amd.vqdif import VQDIF
+    vq = VQDIF(W.make_state_dict(W.vqdif_spec(32)), res=32, device=dev)
+    Xbd = torch.from_numpy(synthetic.make_batch(50, 8)["Xbd"])
+    q, mode, enc = vq.quantize_cloud(Xbd)
+    assert q.shape == (8, 32, 32, 32)
+    Q = 256
+    torch.cuda.synchronize(); t0 = time.time()
+    lg = vq.decode_index(q, grid_Q=Q)["logits"]
+    torch.cuda.synchronize(); dt = time.time() - t0
+    assert lg.shape == (8, Q ** 3, 1) and bool(torch.isfinite(lg).all())
+    print(f"config4: res32 decode_index 8 x 256^3 in {dt * 1e3:.1f} ms ({8 * Q ** 3 / dt / 1e9:.2f} Gpt/s incl. UNet+upsampler)")
+    g = torch.Generator().manual_seed(0)
+    sel = torch.randint(0, Q ** 3, (4096,), generator=g)
+    ax = np.linspace(-1.0, 1.0, Q).astype(np.float32)
+    ix, iy, iz = sel // (Q * Q), (sel // Q) % Q, sel % Q
+    pts = torch.from_numpy(np.stack([ax[ix], ax[iy], ax[iz]], -1))[None].expand(8, -1, -1).contiguous()
+    grid = vq.decoder_grid_cl(vq.get_code_cl(q))
+    pm = ops.sdf_query(pts.to(dev), grid, vq.sdf_w)
+    assert torch.equal(pm[:, :, 0], lg[:, sel.to(dev), 0])
+    # oracle on shape 0 at the sampled points
+    sd_t = O.to_torch_sd(W.make_state_dict(W.vqdif_spec(32)))
+    ref = O.decode_index(sd_t, q[:1].cpu(), pts[:1])
+    assert (pm[:1].cpu() - ref).abs().max().item() < 5e-4
