@@ -91,7 +91,12 @@ def test_adamw_step_matches_torch_optim_and_training_reduces_loss(dev):
     for name, keys in m.items():
         want = torch.cat([sdt[k].detach().reshape(-1, sdt[k].shape[-1]) if sdt[k].dim() > 1 else sdt[k].detach() for k in keys], 0)
         got = dict((n, t) for n, t, _ in tr.params)[name].cpu().reshape(want.shape)
-        assert (got - want).abs().max().item() < 2e-5, name     # one AdamW step of size lr=1e-3
+        gref = torch.cat([og[k].reshape(-1, og[k].shape[-1]) if og[k].dim() > 1 else og[k] for k in keys], 0)
+        # Adam normalises by |g|: where the true gradient is zero (e.g. the key bias, softmax is shift invariant) the
+        # update direction is the sign of round-off noise -> compare only elements with a resolvable gradient
+        sig = gref.abs() > 1e-3 * max(gref.abs().max().item(), 1e-12)
+        assert ((got - want).abs() * sig).max().item() < 2e-5, name     # one AdamW step of size lr=1e-3
+        assert (got - want).abs().max().item() < 2.1e-3, name           # noise elements move by at most 2*lr
     losses = [l0] + [tr.training_step(c, z).item() for _ in range(5)]
     assert losses[-1] < losses[0] - 0.05, losses                # the step actually trains
     # decode-path weights follow the raw weights: sampling after training uses the updated model
