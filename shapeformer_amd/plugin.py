@@ -152,6 +152,39 @@ class ShapeFormerModel:
                                        best_in_first=best_in_first, mask_invalid=mask_invalid,
                                        mask_invalid_completion=mask_invalid_completion, **kw)
 
+    # ---- training (shapeformer.py:26-46,132-207) ------------------------------------------------------------------
+    def get_indices(self, Xct, Xbd, stage="train"):
+        """ShapeRepresenter.get_indices (representers.py:79-103): frozen VQDIF tokens of the partial and the complete
+        cloud (uniform (B,L,2) rows, end-token padded, whole-batch empty code as the reference does for a batch);
+        train stage: random subset of the condition tokens, keeping the terminating end token (:93-99, numpy RNG)."""
+        from . import tokens as T
+        vq = self.representer.vqvae_model.core
+        out = []
+        for cloud in (Xct, Xbd):
+            q, mode, *_ = vq.quantize_cloud_dev(cloud, per_shape_mode=False)
+            tok, _ = T.batch_dense2sparse(q, max_length=self.representer.max_length, end_tokens=self.end_tokens)
+            out.append(tok)
+        c, z = out
+        if stage == "train" and c.shape[1] >= 1:
+            import numpy as np
+            max_num = c.shape[1] - 1
+            sel = np.sort(np.random.choice(max_num, np.random.randint(0, max_num + 1), replace=False))
+            c = torch.cat([c[:, sel, :], c[:, -1:, :]], 1)
+        return c, z
+
+    def make_trainer(self, optim_opt=None, dist=None):
+        from .train import GPTTrainer
+        lr = (optim_opt or {}).get("lr", 1e-5)
+        self.trainer = GPTTrainer(self.transformer, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, dist=dist)
+        return self.trainer
+
+    def training_step(self, batch, batch_idx=0):
+        """ShapeFormer.training_step (shapeformer.py:142-146): loss of one batch dict {Xct, Xbd} + optimizer step."""
+        if not hasattr(self, "trainer"):
+            self.make_trainer()
+        c, z = self.get_indices(batch["Xct"], batch["Xbd"], stage="train")
+        return self.trainer.training_step(c, z)
+
     def complete(self, Xct, **kw):
         kw.setdefault("mask_invalid", self.representer.mask_invalid)
         kw.setdefault("mask_invalid_completion", self.representer.mask_invalid_completion)
