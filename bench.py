@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--ar-steps", type=int, default=512)
     ap.add_argument("--decode-res", type=int, default=128)
     ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--micro", type=int, default=None, help="micro-batches of the AR loop (default: 2 when batch >= 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -56,7 +57,7 @@ def ev_time(fn, n, warm=2):
     return e0.elapsed_time(e1) / n
 
 
-def kernel_rooflines(vq, gpt, B, dev):
+def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
     """Per-kernel live timings (HIP events) at the bench shapes + algorithmic bytes/flops."""
     from shapeformer_amd import ops
     from shapeformer_amd import _lib as L_
@@ -103,10 +104,10 @@ def kernel_rooflines(vq, gpt, B, dev):
             f"M={B}; {tot_b / 1e6:.1f} MB algorithmic per layer; f32 MFMA {flops / (tot_ms * 1e-3) / 1e12:.1f} TFLOP/s")
     out[-1]["launches"] = 4
     # KV-cached decode attention at the mid-run length (Lc + ar_steps/2): bytes = K+V rows of every (row, head)
-    lc = st["Lc"].clone()
     saved_len = st["len"].clone()
-    st["len"].copy_(lc + 256)
-    Lavg = float((lc + 256).float().mean().item())
+    st["len"].fill_(int(round(lc_mean)) + 256)      # every row at the mid-run cached length
+    st["Kc"].zero_(); st["Vc"].zero_()
+    Lavg = float(int(round(lc_mean)) + 256)
 
     def abody():
         for li in range(len(gpt.layers)):
@@ -221,7 +222,7 @@ def main():
     Xct = torch.from_numpy(synthetic.make_batch(314 + rank * B, B, n_partial=a.points)["Xct"]).to(dev)
 
     def step(i):
-        return pipe.complete(Xct, max_steps=a.ar_steps, decode_res=a.decode_res, seed=i, stop_early=False, sigmoid=True)
+        return pipe.complete(Xct, max_steps=a.ar_steps, decode_res=a.decode_res, seed=i, stop_early=False, sigmoid=True, n_micro=a.micro)
 
     def barrier():
         torch.cuda.synchronize()
@@ -259,7 +260,7 @@ def main():
             "sanity": sanity,
         }
         if not a.no_roofline:
-            ks = kernel_rooflines(vq, gpt, B, dev)
+            ks = kernel_rooflines(vq, gpt, B, dev, lc_mean=sanity["Lc_mean"])
             # dominant kernel symbol of the decode step (>90 % of the run): the one with the larger per-layer time
             cands = [k for k in ks if k["kernel"].startswith(("dgemm_kernel", "attn_decode_kernel"))]
             dom = max(cands, key=lambda k: k["ms"])

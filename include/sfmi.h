@@ -97,7 +97,7 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
                         float* resid, const float* E0, const float* E1, const float* Ex, const float* pos_emb, int D, int S,
                         int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
                         float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
-                        unsigned seed, int advance, void* stream);
+                        unsigned seed, int advance, int row_offset, int rows_total, void* stream);
 int sfmi_set_len_i32(int* len, const int* src, int B, int delta, void* stream);
 
 /* ---- Training step of the transformer (csrc/train.hip): shapeformer.py:26-46,132-207 (forward/loss/AdamW groups),

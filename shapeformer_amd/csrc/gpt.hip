@@ -492,6 +492,7 @@ struct SampleArgs {
   int S, M, V, ldv, Lmax, tuple_i, end0, end1, top_k, greedy_row0, mask_invalid, mask_completion, max_steps, advance;
   float top_p, temperature;
   unsigned seed;
+  int row_offset, rows_total;   // micro-batching: global row = row_offset + blockIdx.x of rows_total (uniform stream, greedy row 0)
 };
 
 #define SMP_MAXC 512
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   const float lse = gmax + __logf((redf[4] + redf[5]) + (redf[6] + redf[7]));
 
   int choice = gidx;
-  const bool greedy = (a.greedy_row0 && b == 0) || a.top_k == 1 || a.force != nullptr;
+  const bool greedy = (a.greedy_row0 && a.row_offset + b == 0) || a.top_k == 1 || a.force != nullptr;
   if (!greedy) {
     // ---- top-k threshold by MSB-first radix select on order-preserving keys of lg/T ----------
     const float invT = 1.0f / a.temperature;
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         }
       }
       // inverse-CDF draw (oracle/tokens_oracle.py:sample_filtered convention)
-      const float u = sf_uniform(a.seed, (unsigned)((j * 2 + a.tuple_i) * (int)gridDim.x + b));
+      const float u = sf_uniform(a.seed, (unsigned)((j * 2 + a.tuple_i) * a.rows_total + a.row_offset + b));
       float tot2 = 0.f;
       for (int i = 0; i < keep; ++i) tot2 += cexp[i];
       const float thr = u * tot2;
@@ -864,15 +865,15 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
                         float* resid, const float* E0, const float* E1, const float* Ex, const float* pos_emb, int D,
                         int S, int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
                         float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
-                        unsigned seed, int advance, void* stream) {
-  if (!part || !seq || !len || !Lc || V > 4352 || temperature <= 0.f) return SFMI_EINVAL;
+                        unsigned seed, int advance, int row_offset, int rows_total, void* stream) {
+  if (!part || !seq || !len || !Lc || V > 4352 || temperature <= 0.f || rows_total < B + row_offset) return SFMI_EINVAL;
   if (resid && (!E0 || (tuple_i == 1 && (!E1 || !Ex || !pos_emb)) || D % 4)) return SFMI_EINVAL;
   SampleArgs a;
   a.part = part; a.seq = seq; a.len = len; a.Lc = Lc; a.logp = logp; a.hist = hist; a.force = force; a.S = S; a.M = B; a.V = V;
   a.ldv = ldv; a.resid = resid; a.E0 = E0; a.E1 = E1; a.Ex = Ex; a.pos_emb = pos_emb; a.D = D;
   a.Lmax = Lmax; a.tuple_i = tuple_i; a.end0 = end0; a.end1 = end1; a.top_k = top_k; a.greedy_row0 = greedy_row0;
   a.mask_invalid = mask_invalid; a.mask_completion = mask_completion; a.max_steps = max_steps; a.advance = advance;
-  a.top_p = top_p; a.temperature = temperature; a.seed = seed;
+  a.top_p = top_p; a.temperature = temperature; a.seed = seed; a.row_offset = row_offset; a.rows_total = rows_total;
   const size_t dyn = (top_k <= 0 || top_k > SMP_MAXC) ? (size_t)SMP_BIG * 12 : 0;
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), dyn, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();

@@ -56,7 +56,7 @@ class CondTupleGPT:
         sd = state_dict if state_dict is not None else self._hash_state_dict()
         self.load_state_dict(sd)
         self._state = None
-        self._graph = None
+        self._states, self._graphs = {}, {}
 
     def get_block_size(self):
         return self.Lmax
@@ -113,13 +113,17 @@ class CondTupleGPT:
             ly.pproj, ly.pfc2 = pack_skinny16(ly.wproj), pack_skinny16(ly.wfc2)
         self.head_f = [fold(self.head_w[s], None, self.head_ln[s]) for s in range(2)]
         self.head_w_pad = [torch.cat([w, w.new_zeros(self.Vpad - self.V, self.D)], 0).contiguous() for w in self.head_w]
-        self._graph = None
+        self._graphs = {}
 
     # ------------------------------------------------------------------ state
-    def _alloc(self, B, max_steps):
+    def _alloc(self, B, max_steps, slot=0):
         key = (B, max_steps)
-        if self._state is not None and self._state["key"] == key:
-            return self._state
+        if not hasattr(self, "_states"):
+            self._states, self._graphs = {}, {}
+        cur = self._states.get(slot)
+        if cur is not None and cur["key"] == key:
+            self._state = cur
+            return cur
         dev, D = self.dev, self.D
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         Bp = (B + 15) // 16 * 16   # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off)
@@ -132,12 +136,13 @@ class CondTupleGPT:
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32))
         self._state = st
-        self._graph = None
+        self._states[slot] = st
+        self._graphs.pop(slot, None)
         return st
 
     # ------------------------------------------------------------------ C-ABI wrappers
-    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act, packed=1, S=1):
-        st = self._state
+    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act, packed=1, S=1, st=None):
+        st = st or self._state
         while S > 1 and (K // S) % 128:
             S //= 2
         L.check(L.lib().sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
@@ -260,17 +265,17 @@ class CondTupleGPT:
         lib = L.lib()
         r = st["resid"]
         for li, ly in enumerate(self.layers):
-            self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0)
+            self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, st=st)
             L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
                                                  L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
                                                  L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
-            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=self.S_PROJ if B <= 16 else 4)
-            self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1)
-            self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=self.S_FC2)
+            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=self.S_PROJ if B <= 16 else 4, st=st)
+            self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, st=st)
+            self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=self.S_FC2, st=st)
             if li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage:
                 s = ly.stage
                 hp, hc1, hc2 = self.head_f[s]
-                self._dgemm(r, hp, hc1, hc2, None, st["logit"], B, self.V, D, self.Vpad, 1, 0, packed=0)
+                self._dgemm(r, hp, hc1, hc2, None, st["logit"], B, self.V, D, self.Vpad, 1, 0, packed=0, st=st)
                 hist = sp["hist"][s] if sp.get("hist") is not None else None
                 L.check(lib.sfmi_gpt_sample_f32(L.ptr(st["logit"]), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
                                                 L.ptr(st["logp"]), L.ptr(hist), L.ptr(sp.get("force")),
@@ -279,25 +284,19 @@ class CondTupleGPT:
                                                 s, self.end[0], self.end[1], sp["top_k"], sp["top_p"], sp["temperature"],
                                                 int(sp["best_in_first"]), int(sp["mask_invalid"]),
                                                 int(sp["mask_invalid_completion"]), sp["max_steps"], sp["seed"], int(s == 1),
-                                                L.stream_ptr()), "sfmi_gpt_sample_f32")
+                                                sp.get("row_offset", 0), sp.get("rows_total", B), L.stream_ptr()), "sfmi_gpt_sample_f32")
 
     # ------------------------------------------------------------------ sample_indices
-    @torch.no_grad()
-    def sample(self, c_tokens, Lc, max_steps=512, top_k=100, top_p=0.4, temperature=1.0, best_in_first=True,
-               mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True, use_graph=True,
-               return_logits=False, check_every=32, force_tokens=None, to_host=True):
-        """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32.
-
-        Returns dict(samples (B,steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
-        Mirrors ShapeFormer.sample_indices (shapeformer.py:54-123); torch.multinomial is replaced by an
-        inverse-CDF draw on counter-hash uniforms (oracle/gpt_oracle.py:uniforms)."""
+    def _prepare(self, c_tokens, Lc, max_steps, sp_kw, slot=0, row_offset=0, rows_total=None, return_logits=False,
+                 force_tokens=None, use_graph=True):
+        """State + prefill + step-0 embedding + (cached) hipGraph of one decode step for one (micro-)batch."""
         B = c_tokens.shape[0]
         if B > 64:
-            raise L.SfmiError("decode kernels support up to 64 rows per call")
+            raise L.SfmiError("decode kernels support up to 64 rows per (micro-)batch")
         Lc_host = Lc.cpu().tolist()
         Lc_max = max(Lc_host)
         steps = min(max_steps, self.Lmax - Lc_max)   # never exceed block_size (DESIGN.md: stop, don't crop)
-        st = self._alloc(B, max_steps)
+        st = self._alloc(B, max_steps, slot)
         st["seq"].zero_()
         st["seq"][:, :c_tokens.shape[1]] = c_tokens.to(self.dev, torch.int32)
         st["Lc"].copy_(Lc.to(self.dev, torch.int32))
@@ -306,9 +305,8 @@ class CondTupleGPT:
         hist = None
         if return_logits:
             hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
-        sp = dict(top_k=int(top_k), top_p=float(top_p), temperature=float(temperature), best_in_first=best_in_first,
-                  mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion, max_steps=int(max_steps),
-                  seed=W._fnv1a32(f"sample-uniforms-{seed}"), hist=hist)
+        sp = dict(sp_kw, max_steps=int(max_steps), hist=hist, row_offset=int(row_offset),
+                  rows_total=int(rows_total if rows_total is not None else B))
         if force_tokens is not None:   # (B,max_steps,2) teacher forcing for stepwise parity tests
             ft = torch.zeros(B, max_steps, 2, dtype=torch.int32)
             ft[:, :force_tokens.shape[1]] = torch.as_tensor(force_tokens).to(torch.int32)
@@ -323,10 +321,11 @@ class CondTupleGPT:
                                                   L.ptr(self.cond_pos_emb), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
                                                   L.ptr(st["resid"]), B, self.D, self.Lmax + 1, self.end[0], L.stream_ptr()),
                 "sfmi_gpt_embed_packed_f32")
-        done = 0
+        graph = None
         if use_graph and steps > 1:
             gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force"))), return_logits)
-            if self._graph is None or self._graph[0] != gkey or return_logits:
+            cached = self._graphs.get(slot)
+            if cached is None or cached[0] != gkey or return_logits:
                 side = torch.cuda.Stream(device=self.dev)
                 side.wait_stream(torch.cuda.current_stream())
                 saved = {k: st[k].clone() for k in ("seq", "len", "logp", "resid")}
@@ -336,13 +335,36 @@ class CondTupleGPT:
                 torch.cuda.synchronize()
                 for k, v in saved.items():
                     st[k].copy_(v)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
                     self.decode_step(st, B, sp)
                 for k, v in saved.items():           # capture does not execute, but keep state pristine
                     st[k].copy_(v)
-                self._graph = (gkey, g)
-            g = self._graph[1]
+                self._graphs[slot] = (gkey, graph)
+            graph = self._graphs[slot][1]
+        return dict(st=st, sp=sp, B=B, steps=steps, graph=graph, hist=hist, Lc_host=Lc_host)
+
+    @staticmethod
+    def _sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed):
+        return dict(top_k=int(top_k), top_p=float(top_p), temperature=float(temperature), best_in_first=best_in_first,
+                    mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion,
+                    seed=W._fnv1a32(f"sample-uniforms-{seed}"))
+
+    @torch.no_grad()
+    def sample(self, c_tokens, Lc, max_steps=512, top_k=100, top_p=0.4, temperature=1.0, best_in_first=True,
+               mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True, use_graph=True,
+               return_logits=False, check_every=32, force_tokens=None, to_host=True):
+        """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32.
+
+        Returns dict(samples (B,steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
+        Mirrors ShapeFormer.sample_indices (shapeformer.py:54-123); torch.multinomial is replaced by an
+        inverse-CDF draw on counter-hash uniforms (oracle/gpt_oracle.py:uniforms)."""
+        sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
+        ctx = self._prepare(c_tokens, Lc, max_steps, sp_kw, return_logits=return_logits, force_tokens=force_tokens,
+                            use_graph=use_graph)
+        st, sp, B, steps, g, hist, Lc_host = (ctx[k] for k in ("st", "sp", "B", "steps", "graph", "hist", "Lc_host"))
+        done = 0
+        if g is not None:
             while done < steps:
                 n = min(check_every, steps - done) if stop_early else steps - done
                 for _ in range(n):
@@ -368,6 +390,48 @@ class CondTupleGPT:
         if return_logits:
             res["logits_history"] = [h[:, :nsteps].cpu() for h in hist]
         return res
+
+    @torch.no_grad()
+    def sample_microbatched(self, c_tokens, Lc, n_micro=2, max_steps=512, top_k=100, top_p=0.4, temperature=1.0,
+                            best_in_first=True, mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True,
+                            check_every=32):
+        """Same result as `sample(..., to_host=False)` (identical tokens: the uniform stream and the greedy row are
+        indexed by GLOBAL row), but the rows are split into `n_micro` independent micro-batches whose decode steps are
+        separate hipGraphs replayed on separate HIP streams: one micro-batch's HBM-bound attention overlaps the other's
+        MFMA-bound GEMMs (each chain is serial, the hardware interleaves the two)."""
+        B = c_tokens.shape[0]
+        bounds = [round(i * B / n_micro) for i in range(n_micro + 1)]
+        groups = [(bounds[i], bounds[i + 1]) for i in range(n_micro) if bounds[i + 1] > bounds[i]]
+        sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
+        ctxs = []
+        for i, (lo, hi) in enumerate(groups):
+            ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B))
+        steps = min(c["steps"] for c in ctxs)
+        if not hasattr(self, "_mb_streams") or len(self._mb_streams) < len(ctxs):
+            self._mb_streams = [torch.cuda.Stream(device=self.dev) for _ in ctxs]
+        cur = torch.cuda.current_stream()
+        for s in self._mb_streams[:len(ctxs)]:
+            s.wait_stream(cur)
+        done = 0
+        while done < steps:
+            n = min(check_every, steps - done) if stop_early else steps - done
+            for _ in range(n):
+                for c, s in zip(ctxs, self._mb_streams):
+                    with torch.cuda.stream(s):
+                        if c["graph"] is not None:
+                            c["graph"].replay()
+                        else:
+                            self.decode_step(c["st"], c["B"], c["sp"])
+            done += n
+            if stop_early:
+                for s in self._mb_streams[:len(ctxs)]:
+                    cur.wait_stream(s)
+                if all(self._all_ended(c["st"], c["B"]) for c in ctxs):
+                    break
+        for s in self._mb_streams[:len(ctxs)]:
+            cur.wait_stream(s)
+        merged = {k: torch.cat([c["st"][k] for c in ctxs], 0) for k in ("seq", "len", "Lc", "logp")}
+        return dict(state=merged, steps=done)
 
     def _all_ended(self, st, B):
         seq, ln = st["seq"], st["len"].long()

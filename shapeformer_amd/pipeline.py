@@ -29,13 +29,19 @@ class ShapeCompletion:
 
     @torch.no_grad()
     def complete(self, Xct, max_steps=512, decode_res=128, top_k=100, top_p=0.4, temperature=1.0, seed=0,
-                 best_in_first=False, stop_early=True, sigmoid=True, mask_invalid=True, mask_invalid_completion=True):
+                 best_in_first=False, stop_early=True, sigmoid=True, mask_invalid=True, mask_invalid_completion=True,
+                 n_micro=None):
         """One (pos,val) sequence per input cloud -> dict(samples tokens, dense code grid, occupancy (B,Q^3))."""
         enc = self.encode_cloud(Xct)
         g = self.gpt
-        res = g.sample(enc["c_tokens"], enc["Lc"], max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature,
-                       best_in_first=best_in_first, mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion,
-                       seed=seed, stop_early=stop_early, to_host=False)
+        B = Xct.shape[0]
+        n_micro = n_micro if n_micro is not None else (2 if B >= 32 else 1)   # 2 interleaved hipGraph chains (gpt.py)
+        kw = dict(max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature, best_in_first=best_in_first,
+                  mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion, seed=seed, stop_early=stop_early)
+        if n_micro > 1:
+            res = g.sample_microbatched(enc["c_tokens"], enc["Lc"], n_micro=n_micro, **kw)
+        else:
+            res = g.sample(enc["c_tokens"], enc["Lc"], to_host=False, **kw)
         st = res["state"]
         dense = T.sparse2dense_dev(st["seq"], st["len"], enc["empty_index"], self.R, self.end, start=st["Lc"])
         out = self.vq.decode_index(dense, grid_Q=decode_res, sigmoid=sigmoid)

@@ -126,7 +126,7 @@ def test_sampler_kernel_vs_oracle_filter(dev):
         seed = W._fnv1a32("sample-uniforms-9")
         L.check(L.lib().sfmi_gpt_sample_f32(L.ptr(dpart), L.ptr(dseq), L.ptr(dlen), L.ptr(dLc), None, L.ptr(hist), None,
                                             None, None, None, None, None, 0, 1, B,
-                                            V, Vpad, Lmax, 0, 4096, 4096, k, p, T, 0, 1, 1, 4, seed, 0, L.stream_ptr()), "sample")
+                                            V, Vpad, Lmax, 0, 4096, 4096, k, p, T, 0, 1, 1, 4, seed, 0, 0, B, L.stream_ptr()), "sample")
         got = dseq.cpu().numpy()[:, 5, 0]
         u = W.hash_unit("sample-uniforms-9", 4 * 2 * B).reshape(4, 2, B)
         idx = np.concatenate([seq[:, :5], np.zeros((B, 1, 2), np.int32)], 1)
@@ -160,3 +160,21 @@ def test_teacher_forced_forward_and_loss_vs_reference_vectors(dev):
     want = GO.training_loss(sd_t, cfg, c, zz, exx).item()
     got = gt.training_loss(c, zz, exx).item()
     assert abs(got - want) < 1e-4 * max(1.0, abs(want))
+
+
+def test_microbatched_two_stream_decode_is_bit_identical(dev):
+    """sample_microbatched (two hipGraph chains on two HIP streams) must give exactly the tokens of the single-batch
+    run: uniforms and the greedy row are indexed by global row."""
+    from shapeformer_amd.gpt import CondTupleGPT
+    sd, sd_t, cfg = _tiny()
+    g = CondTupleGPT(sd, n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    c3, Lc3 = _cond_rows()
+    c = np.concatenate([c3, c3[::-1]], 0)
+    Lc = np.concatenate([Lc3, Lc3[::-1]], 0)
+    ct, Lt = torch.from_numpy(c).to(dev, torch.int32), torch.from_numpy(Lc).to(dev)
+    a = g.sample(ct, Lt, max_steps=20, seed=11, stop_early=False, to_host=False)
+    seq_a, len_a, lp_a = a["state"]["seq"].clone(), a["state"]["len"].clone(), a["state"]["logp"].clone()
+    for nm in (2, 3):
+        b = g.sample_microbatched(ct, Lt, n_micro=nm, max_steps=20, seed=11, stop_early=False)
+        assert torch.equal(seq_a, b["state"]["seq"]) and torch.equal(len_a, b["state"]["len"])
+        assert torch.equal(lp_a, b["state"]["logp"])
