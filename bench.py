@@ -33,11 +33,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="shapes per GPU per step (max 64 rows per decode step)")
+    ap.add_argument("--batch", type=int, default=192, help="shapes per GPU per step (decoded as ceil(B/64) interleaved micro-batches of <= 64 rows)")
     ap.add_argument("--ar-steps", type=int, default=512)
     ap.add_argument("--decode-res", type=int, default=128)
     ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--micro", type=int, default=None, help="micro-batches of the AR loop (default: 2 when batch >= 32)")
+    ap.add_argument("--micro", type=int, default=None, help="micro-batches of the AR loop (default: ceil(B/64); 2 for 32..64 rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -255,17 +255,20 @@ def main():
             "config": {"workload": (f"shape completion, {B} shapes/GPU/step: VQDIF-16 encode of {a.points}-pt partial cloud -> "
                                     f"tokens -> CondTupleGPT 20+4 layers d1024 prefill + {a.ar_steps} KV-cached decode steps "
                                     f"(top_k 100, top_p 0.4, early exit off) -> UNet3D+Upsampler -> {a.decode_res}^3 SDF query"),
-                       "batch_per_gpu": B, "ar_steps": a.ar_steps, "decode_res": a.decode_res, "parallelism": f"shard{world}",
+                       "batch_per_gpu": B, "micro_batches": a.micro or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1)), "ar_steps": a.ar_steps, "decode_res": a.decode_res, "parallelism": f"shard{world}",
                        "weights": "hash-generated (no checkpoints ship)"},
             "sanity": sanity,
         }
         if not a.no_roofline:
-            ks = kernel_rooflines(vq, gpt, B, dev, lc_mean=sanity["Lc_mean"])
+            nm = a.micro or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
+            Bk = -(-B // nm)     # rows per decode launch (micro-batch)
+            ks = kernel_rooflines(vq, gpt, Bk, dev, lc_mean=sanity["Lc_mean"])
             # dominant kernel symbol of the decode step (>90 % of the run): the one with the larger per-layer time
             cands = [k for k in ks if k["kernel"].startswith(("dgemm_kernel", "attn_decode_kernel"))]
             dom = max(cands, key=lambda k: k["ms"])
             line["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                                "frac": dom["frac"], "traffic": pmc_traffic(dom["kernel"], B), "kernel": dom["kernel"]}
+                                "frac": dom["frac"], "traffic": pmc_traffic(dom["kernel"], Bk), "kernel": dom["kernel"],
+                                "rows_per_launch": Bk}
             line["kernels"] = ks
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.points, a.ar_steps, a.decode_res)

@@ -35,7 +35,8 @@ class ShapeCompletion:
         enc = self.encode_cloud(Xct)
         g = self.gpt
         B = Xct.shape[0]
-        n_micro = n_micro if n_micro is not None else (2 if B >= 32 else 1)   # 2 interleaved hipGraph chains (gpt.py)
+        # interleaved hipGraph chains (gpt.py:sample_microbatched): <= 64 rows each; 2 chains already for 32..64 rows
+        n_micro = n_micro if n_micro is not None else (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
         kw = dict(max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature, best_in_first=best_in_first,
                   mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion, seed=seed, stop_early=stop_early)
         if n_micro > 1:
