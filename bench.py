@@ -219,7 +219,14 @@ def main():
     gpt = CondTupleGPT(device=dev)
     pipe = ShapeCompletion(vq, gpt)
     B = a.batch
-    Xct = torch.from_numpy(synthetic.make_batch(314 + rank * B, B, n_partial=a.points)["Xct"]).to(dev)
+    # synthetic partial clouds; keep only shapes whose condition length leaves room for ALL ar_steps inside the
+    # 812-token block (the unit of work is exactly 512 sampled tuples), decided before the timed region
+    cand = torch.from_numpy(synthetic.make_batch(314 + rank * 4 * B, B + max(8, B // 8), n_partial=a.points)["Xct"]).to(dev)
+    lcs = torch.cat([pipe.encode_cloud(cand[i:i + 64])["Lc"].clone() for i in range(0, cand.shape[0], 64)])
+    keep = torch.nonzero(lcs <= gpt.Lmax - a.ar_steps).flatten()[:B]
+    assert keep.numel() == B, "not enough synthetic shapes with a short enough condition"
+    Xct = cand[keep].contiguous()
+    del cand
 
     def step(i):
         return pipe.complete(Xct, max_steps=a.ar_steps, decode_res=a.decode_res, seed=i, stop_early=False, sigmoid=True, n_micro=a.micro)
@@ -242,6 +249,7 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    assert int(r["steps"]) == a.ar_steps, f"only {r['steps']} of {a.ar_steps} AR steps were run"
     occ = r["occupancy"]
     sanity = dict(ar_steps_done=int(r["steps"]), occ_mean=round(float(occ.mean().item()), 4),
                   Lc_mean=round(float(r["Lc"].float().mean().item()), 1))
