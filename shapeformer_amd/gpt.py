@@ -174,6 +174,17 @@ class CondTupleGPT:
         """Batched forward of rows (b,t), t < P, through both stages (fills the KV caches).  Rows with
         t >= nval[b] (default Lc[b]-1) are padding.  want_logits: also run both heads on every row and return
         [(B,P,V), (B,P,V)] — the teacher-forced `CondTupleGPT.forward` (mingpt.py:287-296,311-319)."""
+        gen = self._prefill_gen(st, B, P, want_logits, interactive=False)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as e:
+            return e.value
+
+    def _prefill_gen(self, st, B, P, want_logits, interactive):
+        """Generator form of `prefill`: with interactive=True it yields the stage-0 logits, expects the chosen
+        positions (B,P) via .send() (they become seq[:, 1:P+1, 0], the tok_embs[0] add of mingpt.py:309), then yields the
+        stage-1 logits — the protocol of CondTupleGPT.sample_next_tuple (mingpt.py:297-310)."""
         D, dev = self.D, self.dev
         M = B * P
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
@@ -202,9 +213,15 @@ class CondTupleGPT:
             nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
             if nxt is None:
                 heads(ly.stage)
+                if interactive:
+                    yield logits[-1]
                 break
             if nxt.stage != ly.stage:   # stage boundary: x += tok_embs[0][next pos] (mingpt.py:294)
                 heads(ly.stage)
+                if interactive:
+                    tgt = yield logits[-1]
+                    if tgt is not None:
+                        st["seq"][:, 1:P + 1, 0] = torch.as_tensor(tgt).to(self.dev, torch.int32)
                 self._rowprep(resid, None, None, 0, M, resid, xn, nxt.ln1, Eadd=self.E[0], P=P, st=st)
             else:
                 self._rowprep(resid, None, None, 0, M, None, xn, nxt.ln1)
@@ -236,6 +253,34 @@ class CondTupleGPT:
         return self.prefill(st, B, Lq, want_logits=True)
 
     __call__ = forward
+
+    def _forward_state(self, idx, extra_idx, L_cond):
+        idx = torch.as_tensor(idx).to(self.dev, torch.int32)
+        B, Lq, _ = idx.shape
+        assert Lq <= self.Lmax, "Cannot forward, model block size is exhausted."   # mingpt.py:279
+        st = dict(self._alloc(B, 1))
+        st["seq"] = torch.zeros(B, self.Lmax + 1, 2, device=self.dev, dtype=torch.int32)
+        st["seq"][:, :Lq] = idx
+        st["Lc"] = torch.full((B,), int(L_cond), device=self.dev, dtype=torch.int32)
+        st["len"] = torch.full((B,), Lq, device=self.dev, dtype=torch.int32)
+        st["nval"] = torch.full((B,), Lq, device=self.dev, dtype=torch.int32)
+        st["extra"] = None
+        if extra_idx is not None:
+            ex = torch.zeros(B, self.Lmax + 1, device=self.dev, dtype=torch.int32)
+            ex[:, :Lq] = torch.as_tensor(extra_idx).to(self.dev, torch.int32)[..., 0]
+            st["extra"] = ex
+        return st, B, Lq
+
+    @torch.no_grad()
+    def sample_next_tuple(self, idx, extra_idx=None, L_cond=1):
+        """Compat generator with the reference protocol (mingpt.py:297-310): `g = m.sample_next_tuple(idx, extra, L_c)`;
+        `logits_pos = next(g)` (B,L,V); `logits_val = g.send(target_pos)` with target_pos (B,L) = idx positions shifted
+        left + the newly chosen one.  It recomputes the whole prefix like the reference does (use `sample()` for the
+        KV-cached device loop); provided so ShapeFormer.sample_indices (shapeformer.py:54-123) can run unchanged."""
+        st, B, Lq = self._forward_state(idx, extra_idx, L_cond)
+        gen = self._prefill_gen(st, B, Lq, True, interactive=True)
+        target = yield next(gen)
+        yield gen.send(target)
 
     @torch.no_grad()
     def training_loss(self, c_indices, z_indices, extra_indices=None):

@@ -178,3 +178,23 @@ def test_microbatched_two_stream_decode_is_bit_identical(dev):
         b = g.sample_microbatched(ct, Lt, n_micro=nm, max_steps=20, seed=11, stop_early=False)
         assert torch.equal(seq_a, b["state"]["seq"]) and torch.equal(len_a, b["state"]["len"])
         assert torch.equal(lp_a, b["state"]["logp"])
+
+
+def test_sample_next_tuple_generator_protocol(dev):
+    """mingpt.py:297-310 protocol: next(gen) -> position logits, gen.send(target_pos) -> value logits; must equal the
+    teacher-forced forward on the same inputs."""
+    from shapeformer_amd.gpt import CondTupleGPT
+    sd, sd_t, cfg = _tiny()
+    g = CondTupleGPT(sd, n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    t = np.load(os.path.join(G, "gpt_tiny.npz"))
+    c, z, ex = (torch.from_numpy(t[k]) for k in ("c_idx", "z_idx", "extra"))
+    cz = torch.cat([c, z], 1)
+    L_c = c.shape[1]
+    idx, tgt = cz[:, :-1], cz[:, 1:]
+    want = g.forward(idx, ex[:, :-1], L_c, tgt)
+    w0, w1 = want[0].clone(), want[1].clone()
+    gen = g.sample_next_tuple(idx, extra_idx=ex[:, :-1], L_cond=L_c)
+    l0 = next(gen)
+    assert torch.equal(l0, w0)
+    l1 = gen.send(tgt[..., 0])
+    assert torch.equal(l1, w1)
