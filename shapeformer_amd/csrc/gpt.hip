@@ -303,6 +303,168 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// wide decode GEMM: 64 < M <= 192 rows in ONE launch (MT = 8 or 12 row tiles), same math / layouts as dgemm_kernel.
+//   - each wave owns TWO adjacent 16-column n-tiles, so an activation fragment feeds 8 MFMAs instead of 4:
+//     per-CU L1 traffic drops from 40 B/clk (MT=4, one n-tile: above the ~25 B/clk the L1 sustains) to
+//     (MT+2)/(2 MT) KB per 128 MFMA-clk per wave = 18.7 B/clk at MT = 12, and the weights are streamed ONCE
+//     for all rows instead of once per 64-row chain;
+//   - one accumulator chain per tile (2 MT independent tiles already cover the MFMA dependent-issue latency);
+//   - NW = 8 waves split K; the cross-wave reduction runs in MT/4 passes over a 64 KB LDS buffer, pass p
+//     finishing row tiles 4p..4p+3: wave w owns (row tile 4p + (w>>1), column w&1).
+// grid (ceil(ceil(N/16)/2), S).  Buffers x/out/resid (packed) must hold MT*16 rows.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int UW>
+__global__ __launch_bounds__(512) void dgemm_wide_kernel(DGemmArgs a) {
+  constexpr int NW = 8, PJ = 4;
+  static_assert(MT % PJ == 0, "row tiles are finished four per pass");
+  __shared__ __attribute__((aligned(16))) float red[NW][PJ][2][4][64];
+  __shared__ float st1[NW][MT][16], st2[NW][MT][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
+  const int np = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+  const int ntiles = (a.N + 15) >> 4;
+  const int ntA = 2 * np, ntB = min(2 * np + 1, ntiles - 1);   // odd tile count: column B clamps, its store is masked
+  const int kslice = a.K / S, kw = kslice / NW, k0 = sp * kslice + wave * kw;
+  const long long kt = a.K / 16;
+  const f32x4* wpA = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)ntA * kt + k0 / 16) * 64 + lane;
+  const f32x4* wpB = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)ntB * kt + k0 / 16) * 64 + lane;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(a.x) + (long long)(k0 / 16) * 64 + lane;
+  const long long xs = kt * 64;   // f32x4 stride between row tiles
+  f32x4 acc[MT][2];
+  float s1[MT], s2[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = acc[j][0]; s1[j] = 0.f; s2[j] = 0.f; }
+  // epilogue operands of this wave's (row tile, column) slots, fetched ahead of the weight stream
+  const int ce = wave & 1, jje = wave >> 1;
+  const int nte = 2 * np + ce;
+  const bool col_ok = nte < ntiles;
+  const int n_ep = nte * 16 + 4 * q;
+  f32x4 pc1 = {0.f, 0.f, 0.f, 0.f}, pc2 = pc1, pres[MT / PJ];
+#pragma unroll
+  for (int p = 0; p < MT / PJ; ++p) pres[p] = pc1;
+  if (col_ok && n_ep < a.N) {
+    if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
+    if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
+    if (a.resid) {
+#pragma unroll
+      for (int p = 0; p < MT / PJ; ++p) {
+        const int j = p * PJ + jje;
+        const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nte) * 64 + lane) * 4
+                                           : (long long)min(j * 16 + ml, a.M - 1) * a.ldo + n_ep;
+        pres[p] = *reinterpret_cast<const f32x4*>(a.resid + off);
+      }
+    }
+  }
+  const int steps = kw / 16;
+  // weights are prefetched UW k16-steps ahead (HBM latency); activations come from L2 and are loaded per step
+  f32x4 wA[UW], wB[UW];
+#pragma unroll
+  for (int u = 0; u < UW; ++u) {
+    wA[u] = __builtin_nontemporal_load(wpA + min(u, steps - 1) * 64);
+    wB[u] = __builtin_nontemporal_load(wpB + min(u, steps - 1) * 64);
+  }
+  for (int s0 = 0; s0 < steps; s0 += UW) {
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+      const int s = s0 + u;
+      f32x4 xb[MT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) xb[j] = xr[j * xs + (long long)s * 64];
+      const f32x4 wa = wA[u], wb = wB[u];
+      const int sn = min(s + UW, steps - 1);
+      wA[u] = __builtin_nontemporal_load(wpA + sn * 64);
+      wB[u] = __builtin_nontemporal_load(wpB + sn * 64);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const f32x4 xv = xb[j];
+        s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
+        s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[j][0] = DG_MFMA(wa[e], xv[e], acc[j][0]);
+          acc[j][1] = DG_MFMA(wb[e], xv[e], acc[j][1]);
+        }
+      }
+    }
+  }
+  if (a.ln) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float t1 = s1[j], t2 = s2[j];
+      t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+      t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (q == 0) { st1[wave][j][ml] = t1; st2[wave][j][ml] = t2; }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < MT / PJ; ++p) {
+    if (p) __syncthreads();   // red is reused
+#pragma unroll
+    for (int jj = 0; jj < PJ; ++jj)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][jj][c][r][lane] = acc[p * PJ + jj][c][r];
+    __syncthreads();
+    const int j = p * PJ + jje;
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] += red[w][jje][ce][e][lane];
+    float t1 = 0.f, t2 = 0.f;
+    if (a.ln) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { t1 += st1[w][j][ml]; t2 += st2[w][j][ml]; }
+    }
+    bool fin = col_ok;
+    if (S > 1 && col_ok) {
+      const long long tile = (long long)j * ntiles + nte;
+      float* slab = a.slab + (tile * S + sp) * 320;
+      st_sc1(slab + lane * 4, r);
+      if (a.ln && q == 0) {
+        __hip_atomic_store(slab + 256 + ml, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slab + 272 + ml, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int ticket = 0;
+      if (lane == 0) ticket = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __shfl(ticket, 0, 64);
+      fin = ticket == S - 1;
+      if (fin) {
+        if (lane == 0) __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        r = f32x4{0.f, 0.f, 0.f, 0.f}; t1 = 0.f; t2 = 0.f;
+        const float* base = a.slab + tile * S * 320;
+        for (int s = 0; s < S; ++s) {
+          r = r + ld_sc1(base + s * 320 + lane * 4);
+          if (a.ln) {
+            t1 += __hip_atomic_load(base + s * 320 + 256 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t2 += __hip_atomic_load(base + s * 320 + 272 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+    const int m = j * 16 + ml;
+    if (fin && (a.out_packed || m < a.M) && n_ep < a.N) {
+      if (a.ln) {
+        const float mean = t1 / (float)a.K;
+        const float var = fmaxf(t2 / (float)a.K - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + 1e-5f);
+        r = (r - pc1 * mean) * rstd;
+      }
+      if (a.c2) r = r + pc2;
+      if (a.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
+      }
+      const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nte) * 64 + lane) * 4 : (long long)m * a.ldo + n_ep;
+      if (a.resid) r = r + pres[p];
+      *reinterpret_cast<f32x4*>(a.out + off) = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode attention: grid (B, H), 1024 threads (16 waves); head dim HD <= 64, multiple of 4.
 // KV cache layout is (B, H, Lmax, HD): one (row, head)'s keys are CONTIGUOUS, so a wave-instruction reads
 // 4 keys x 256 B = 1 KiB coalesced; 16 lanes share a key (float4 each), 4 independent loads are in
@@ -777,14 +939,38 @@ int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out) {
 // x (and out/resid when out_packed) are fragment-packed [ceil(M/16)][N/16][64][4] (see pk_off); out_packed == 0
 // writes row-major (M,ldo) (used for the logits handed to the sampler).  S > 1 splits K across S workgroups per
 // n-tile with an in-kernel deterministic last-arriver reduction (slab/cnt scratch, cnt zero-initialised ONCE).
-size_t sfmi_decode_gemm_slab_floats(int M, int N, int S) { return (size_t)((M + 15) / 16) * ((N + 15) / 16) * S * 320; }
-int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
-                         float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
-                         int* cnt, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 64 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
+size_t sfmi_decode_gemm_slab_floats(int M, int N, int S) { return (size_t)((M + 63) / 64 * 4) * ((N + 15) / 16) * S * 320; }
+// the same GEMM through dgemm_wide_kernel (one launch for up to 192 rows; sfmi_decode_gemm_f32 routes M > 64 here)
+int sfmi_decode_gemm_wide_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
+                              float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
+                              int* cnt, void* stream) {
+  if (!x || !Wp16 || !out || M <= 0 || M > 192 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
   if (out_packed && N % 16) return SFMI_EINVAL;
   if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
   const int kslice = K / S;
+  if (kslice % (16 * 8)) return SFMI_EINVAL;
+  DGemmArgs a;
+  a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
+  a.out_packed = out_packed; a.slab = slab; a.cnt = cnt;
+  const int ntiles = (N + 15) / 16;
+  dim3 grid((ntiles + 1) / 2, S);
+  const int steps = kslice / 8 / 16;
+  hipStream_t st = (hipStream_t)stream;
+#define DW(MT_) do { if (steps % 2 == 0) hipLaunchKernelGGL((dgemm_wide_kernel<MT_, 2>), grid, dim3(512), 0, st, a); \
+                     else hipLaunchKernelGGL((dgemm_wide_kernel<MT_, 1>), grid, dim3(512), 0, st, a); } while (0)
+  if (M <= 64) DW(4); else if (M <= 128) DW(8); else hipLaunchKernelGGL((dgemm_wide_kernel<12, 1>), grid, dim3(512), 0, st, a);
+#undef DW
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
+                         float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
+                         int* cnt, void* stream) {
+  if (!x || !Wp16 || !out || M <= 0 || M > 192 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
+  if (out_packed && N % 16) return SFMI_EINVAL;
+  if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
+  const int kslice = K / S;
+  if (M > 64) return sfmi_decode_gemm_wide_f32(x, Wp16, c1, c2, resid, out, M, N, K, ldo, ln, act, out_packed, S, slab, cnt, stream);
   const int NWv = kslice >= 2048 ? 16 : 8;
   if (kslice % (16 * NWv)) return SFMI_EINVAL;
   DGemmArgs a;

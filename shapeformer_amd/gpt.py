@@ -126,13 +126,15 @@ class CondTupleGPT:
             return cur
         dev, D = self.dev, self.D
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
-        Bp = (B + 15) // 16 * 16   # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off)
+        # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off); the wide GEMM (B > 64) works on
+        # groups of four row tiles
+        Bp = (B + 15) // 16 * 16 if B <= 64 else (B + 63) // 64 * 64
         st = dict(key=key,
                   seq=torch.zeros(B, self.Lmax + 1, 2, device=dev, dtype=torch.int32),
                   len=torch.zeros(B, device=dev, dtype=torch.int32), Lc=torch.zeros(B, device=dev, dtype=torch.int32),
                   resid=torch.zeros(Bp, D, device=dev), qkv=torch.zeros(Bp, 3 * D, device=dev), y=torch.zeros(Bp, D, device=dev),
                   h=torch.zeros(Bp, 4 * D, device=dev), logit=f(B, self.Vpad),
-                  slab=f(L.lib().sfmi_decode_gemm_slab_floats(Bp, 4 * D, 4)), cnt=torch.zeros(Bp // 16 * (4 * D // 16 + 1), device=dev, dtype=torch.int32),
+                  slab=f(L.lib().sfmi_decode_gemm_slab_floats(Bp, 4 * D, 4)), cnt=torch.zeros(Bp // 16 * (max(4 * D, self.Vpad) // 16 + 1), device=dev, dtype=torch.int32),
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32))
         self._state = st
