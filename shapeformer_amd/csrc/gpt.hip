@@ -273,12 +273,20 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
       if (lane == 0) __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
       r = f32x4{0.f, 0.f, 0.f, 0.f}; t1 = 0.f; t2 = 0.f;
       const float* base = a.slab + tile * S * 320;
-      for (int s = 0; s < S; ++s) {
-        r = r + ld_sc1(base + s * 320 + lane * 4);
-        if (a.ln) {
-          t1 += __hip_atomic_load(base + s * 320 + 256 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          t2 += __hip_atomic_load(base + s * 320 + 272 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int s = 0; s < S; s += 4) {   // four slices in flight per round trip, summed in slice order
+        f32x4 tv[4];
+        float u1[4], u2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* b = base + min(s + u, S - 1) * 320;
+          tv[u] = ld_sc1(b + lane * 4);
+          u1[u] = __hip_atomic_load(b + 256 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          u2[u] = __hip_atomic_load(b + 272 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (s + u < S) { r = r + tv[u]; t1 += u1[u]; t2 += u2[u]; }
       }
     }
     const int m = j * 16 + ml;
@@ -303,163 +311,205 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// wide decode GEMM: 64 < M <= 192 rows in ONE launch (MT = 8 or 12 row tiles), same math / layouts as dgemm_kernel.
-//   - each wave owns TWO adjacent 16-column n-tiles, so an activation fragment feeds 8 MFMAs instead of 4:
-//     per-CU L1 traffic drops from 40 B/clk (MT=4, one n-tile: above the ~25 B/clk the L1 sustains) to
-//     (MT+2)/(2 MT) KB per 128 MFMA-clk per wave = 18.7 B/clk at MT = 12, and the weights are streamed ONCE
-//     for all rows instead of once per 64-row chain;
+// wide decode GEMM: 64 < M <= 256 rows in ONE launch (MT = 8, 12 or 16 row tiles), same math / layouts as dgemm_kernel.
+//   - each wave owns TWO adjacent 16-column n-tiles over all MT row tiles, so an activation fragment feeds 8 MFMAs
+//     instead of 4 (per-CU L1 traffic (MT+2)/(2 MT) KB per 128 MFMA-clk per wave, 18.7 B/clk at MT = 12 against
+//     40 B/clk for the 64-row kernel and ~25 B/clk the L1 sustains), and the weights are streamed ONCE for all rows;
+//   - 4 waves (one per SIMD, up to 512 VGPRs each) split K; explicit two-buffer pipeline: activations one k16-step
+//     ahead, weights two steps ahead, issued in that order so the in-order vmcnt wait on the activations never
+//     waits for the younger weight loads;
 //   - one accumulator chain per tile (2 MT independent tiles already cover the MFMA dependent-issue latency);
-//   - NW = 8 waves split K; the cross-wave reduction runs in MT/4 passes over a 64 KB LDS buffer, pass p
-//     finishing row tiles 4p..4p+3: wave w owns (row tile 4p + (w>>1), column w&1).
-// grid (ceil(ceil(N/16)/2), S).  Buffers x/out/resid (packed) must hold MT*16 rows.
+//   - ONE reduction pass through LDS (MT*8 KB), then wave w finishes row tiles [w MT/4, (w+1) MT/4) x both columns;
+//     split-K (S > 1): one ticket per (column pair, wave) covers those MT/2 tiles - a single atomic round trip.
+// grid (ceil(ceil(N/16)/2), S).  Packed x/out/resid must hold MT*16 rows; K/S must be a multiple of 128.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int UW>
-__global__ __launch_bounds__(512) void dgemm_wide_kernel(DGemmArgs a) {
-  constexpr int NW = 8, PJ = 4;
-  static_assert(MT % PJ == 0, "row tiles are finished four per pass");
-  __shared__ __attribute__((aligned(16))) float red[NW][PJ][2][4][64];
-  __shared__ float st1[NW][MT][16], st2[NW][MT][16];
+template <int MT>
+__global__ __launch_bounds__(256) void dgemm_wide_kernel(DGemmArgs a) {
+  constexpr int NW = 4, JW = MT / NW;   // JW row tiles finished per wave
+  static_assert(MT % NW == 0, "row tiles are dealt to the four waves");
+  extern __shared__ __attribute__((aligned(16))) float wide_lds[];
+  f32x4 (*red)[MT * 2][64] = reinterpret_cast<f32x4 (*)[MT * 2][64]>(wide_lds);           // [NW][MT*2][64]
+  float (*st1)[MT][16] = reinterpret_cast<float (*)[MT][16]>(wide_lds + NW * MT * 2 * 256);   // [NW][MT][16]
+  float (*st2)[MT][16] = st1 + NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
   const int np = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
   const int ntiles = (a.N + 15) >> 4;
   const int ntA = 2 * np, ntB = min(2 * np + 1, ntiles - 1);   // odd tile count: column B clamps, its store is masked
+  const bool okB = 2 * np + 1 < ntiles;
   const int kslice = a.K / S, kw = kslice / NW, k0 = sp * kslice + wave * kw;
   const long long kt = a.K / 16;
   const f32x4* wpA = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)ntA * kt + k0 / 16) * 64 + lane;
   const f32x4* wpB = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)ntB * kt + k0 / 16) * 64 + lane;
   const f32x4* xr = reinterpret_cast<const f32x4*>(a.x) + (long long)(k0 / 16) * 64 + lane;
   const long long xs = kt * 64;   // f32x4 stride between row tiles
+  const int steps = kw / 16;      // even (host check)
   f32x4 acc[MT][2];
   float s1[MT], s2[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = acc[j][0]; s1[j] = 0.f; s2[j] = 0.f; }
-  // epilogue operands of this wave's (row tile, column) slots, fetched ahead of the weight stream
-  const int ce = wave & 1, jje = wave >> 1;
-  const int nte = 2 * np + ce;
-  const bool col_ok = nte < ntiles;
-  const int n_ep = nte * 16 + 4 * q;
-  f32x4 pc1 = {0.f, 0.f, 0.f, 0.f}, pc2 = pc1, pres[MT / PJ];
+  f32x4 xa[MT], xb[MT];
+  f32x4 wA0 = __builtin_nontemporal_load(wpA), wB0 = __builtin_nontemporal_load(wpB);
 #pragma unroll
-  for (int p = 0; p < MT / PJ; ++p) pres[p] = pc1;
-  if (col_ok && n_ep < a.N) {
-    if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
-    if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
-    if (a.resid) {
+  for (int j = 0; j < MT; ++j) xa[j] = xr[j * xs];
+  f32x4 wA1 = __builtin_nontemporal_load(wpA + 64), wB1 = __builtin_nontemporal_load(wpB + 64);
+  // epilogue operands of this wave's tiles, fetched ahead of the weight stream
+  const int nA = ntA * 16 + 4 * q, nB = (2 * np + 1) * 16 + 4 * q;
+  f32x4 pc1A = {0.f, 0.f, 0.f, 0.f}, pc1B = pc1A, pc2A = pc1A, pc2B = pc1A, pres[JW][2];
 #pragma unroll
-      for (int p = 0; p < MT / PJ; ++p) {
-        const int j = p * PJ + jje;
-        const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nte) * 64 + lane) * 4
-                                           : (long long)min(j * 16 + ml, a.M - 1) * a.ldo + n_ep;
-        pres[p] = *reinterpret_cast<const f32x4*>(a.resid + off);
-      }
-    }
-  }
-  const int steps = kw / 16;
-  // weights are prefetched UW k16-steps ahead (HBM latency); activations come from L2 and are loaded per step
-  f32x4 wA[UW], wB[UW];
+  for (int jj = 0; jj < JW; ++jj) { pres[jj][0] = pc1A; pres[jj][1] = pc1A; }
+  if (a.ln) { if (nA < a.N) pc1A = *reinterpret_cast<const f32x4*>(a.c1 + nA); if (okB && nB < a.N) pc1B = *reinterpret_cast<const f32x4*>(a.c1 + nB); }
+  if (a.c2) { if (nA < a.N) pc2A = *reinterpret_cast<const f32x4*>(a.c2 + nA); if (okB && nB < a.N) pc2B = *reinterpret_cast<const f32x4*>(a.c2 + nB); }
+  if (a.resid) {
 #pragma unroll
-  for (int u = 0; u < UW; ++u) {
-    wA[u] = __builtin_nontemporal_load(wpA + min(u, steps - 1) * 64);
-    wB[u] = __builtin_nontemporal_load(wpB + min(u, steps - 1) * 64);
-  }
-  for (int s0 = 0; s0 < steps; s0 += UW) {
+    for (int jj = 0; jj < JW; ++jj) {
+      const int j = wave * JW + jj;
 #pragma unroll
-    for (int u = 0; u < UW; ++u) {
-      const int s = s0 + u;
-      f32x4 xb[MT];
-#pragma unroll
-      for (int j = 0; j < MT; ++j) xb[j] = xr[j * xs + (long long)s * 64];
-      const f32x4 wa = wA[u], wb = wB[u];
-      const int sn = min(s + UW, steps - 1);
-      wA[u] = __builtin_nontemporal_load(wpA + sn * 64);
-      wB[u] = __builtin_nontemporal_load(wpB + sn * 64);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const f32x4 xv = xb[j];
-        s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
-        s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[j][0] = DG_MFMA(wa[e], xv[e], acc[j][0]);
-          acc[j][1] = DG_MFMA(wb[e], xv[e], acc[j][1]);
+      for (int c = 0; c < 2; ++c) {
+        const int nt = 2 * np + c, n = nt * 16 + 4 * q;
+        if (nt < ntiles && n < a.N) {
+          const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nt) * 64 + lane) * 4
+                                             : (long long)min(j * 16 + ml, a.M - 1) * a.ldo + n;
+          pres[jj][c] = *reinterpret_cast<const f32x4*>(a.resid + off);
         }
       }
     }
   }
-  if (a.ln) {
+  auto mfma_block = [&](const f32x4 (&xv_)[MT], const f32x4& wa, const f32x4& wb) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
+      const f32x4 xv = xv_[j];
+      s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
+      s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[j][0] = DG_MFMA(wa[e], xv[e], acc[j][0]);
+        acc[j][1] = DG_MFMA(wb[e], xv[e], acc[j][1]);
+      }
+    }
+  };
+  for (int s = 0; s < steps; s += 2) {
+    const int s2n = min(s + 2, steps - 1), s3n = min(s + 3, steps - 1);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) xb[j] = xr[j * xs + XIDX((long long)(s + 1) * 64)];
+    const f32x4 wA2 = __builtin_nontemporal_load(wpA + s2n * 64), wB2 = __builtin_nontemporal_load(wpB + s2n * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(xa, wA0, wB0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) xa[j] = xr[j * xs + XIDX((long long)s2n * 64)];
+    const f32x4 wA3 = __builtin_nontemporal_load(wpA + s3n * 64), wB3 = __builtin_nontemporal_load(wpB + s3n * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(xb, wA1, wB1);
+    __builtin_amdgcn_sched_barrier(0);
+    wA0 = wA2; wB0 = wB2; wA1 = wA3; wB1 = wB3;
+  }
+#ifdef WIDE_SKIP_EPI   // ablation (tools/ubench/run_wide.sh): main loop only
+  { f32x4 t = acc[0][0]; float u = s1[0] + s2[0];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) { t = t + acc[j][0] + acc[j][1]; u += s1[j] + s2[j]; }
+    if (t[0] + t[1] + t[2] + t[3] + u == 1.2345f) a.out[0] = 1.f;
+    return; }
+#endif
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    red[wave][j * 2][lane] = acc[j][0];
+    red[wave][j * 2 + 1][lane] = acc[j][1];
+    if (a.ln) {
       float t1 = s1[j], t2 = s2[j];
       t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
       t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
       if (q == 0) { st1[wave][j][ml] = t1; st2[wave][j][ml] = t2; }
     }
   }
+  __syncthreads();
+  f32x4 r[JW][2];
+  float t1[JW], t2[JW];
 #pragma unroll
-  for (int p = 0; p < MT / PJ; ++p) {
-    if (p) __syncthreads();   // red is reused
+  for (int jj = 0; jj < JW; ++jj) {
+    const int j = wave * JW + jj;
 #pragma unroll
-    for (int jj = 0; jj < PJ; ++jj)
+    for (int c = 0; c < 2; ++c) {
+      r[jj][c] = red[0][j * 2 + c][lane];
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][jj][c][r][lane] = acc[p * PJ + jj][c][r];
-    __syncthreads();
-    const int j = p * PJ + jje;
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] += red[w][jje][ce][e][lane];
-    float t1 = 0.f, t2 = 0.f;
+      for (int w = 1; w < NW; ++w) r[jj][c] = r[jj][c] + red[w][j * 2 + c][lane];
+    }
+    t1[jj] = 0.f; t2[jj] = 0.f;
     if (a.ln) {
 #pragma unroll
-      for (int w = 0; w < NW; ++w) { t1 += st1[w][j][ml]; t2 += st2[w][j][ml]; }
+      for (int w = 0; w < NW; ++w) { t1[jj] += st1[w][j][ml]; t2[jj] += st2[w][j][ml]; }
     }
-    bool fin = col_ok;
-    if (S > 1 && col_ok) {
-      const long long tile = (long long)j * ntiles + nte;
-      float* slab = a.slab + (tile * S + sp) * 320;
-      st_sc1(slab + lane * 4, r);
-      if (a.ln && q == 0) {
-        __hip_atomic_store(slab + 256 + ml, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slab + 272 + ml, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int ticket = 0;
-      if (lane == 0) ticket = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ticket = __shfl(ticket, 0, 64);
-      fin = ticket == S - 1;
-      if (fin) {
-        if (lane == 0) __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-        r = f32x4{0.f, 0.f, 0.f, 0.f}; t1 = 0.f; t2 = 0.f;
-        const float* base = a.slab + tile * S * 320;
-        for (int s = 0; s < S; ++s) {
-          r = r + ld_sc1(base + s * 320 + lane * 4);
-          if (a.ln) {
-            t1 += __hip_atomic_load(base + s * 320 + 256 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t2 += __hip_atomic_load(base + s * 320 + 272 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+  }
+  if (S > 1) {
+    // publish this slice's tiles write-through, ONE ticket for the wave's JW x 2 tiles; the last arriver sums the
+    // S slabs in slice order (deterministic) and runs the epilogue
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+      const int j = wave * JW + jj;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c && !okB) continue;
+        float* slab = a.slab + (((long long)j * ntiles + 2 * np + c) * S + sp) * 320;
+        st_sc1(slab + lane * 4, r[jj][c]);
+        if (a.ln && c == 0 && q == 0) {
+          __hip_atomic_store(slab + 256 + ml, t1[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slab + 272 + ml, t2[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
-    const int m = j * 16 + ml;
-    if (fin && (a.out_packed || m < a.M) && n_ep < a.N) {
-      if (a.ln) {
-        const float mean = t1 / (float)a.K;
-        const float var = fmaxf(t2 / (float)a.K - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + 1e-5f);
-        r = (r - pc1 * mean) * rstd;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* cnt = a.cnt + np * NW + wave;
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0, 64);
+    if (ticket != S - 1) return;
+    if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) { r[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f}; r[jj][1] = r[jj][0]; t1[jj] = 0.f; t2[jj] = 0.f; }
+    const int cB = okB ? 1 : 0;
+    for (int s = 0; s < S; ++s) {   // all of a slice's tile loads are in flight together (no per-tile round trip)
+      f32x4 tv[JW][2];
+      float u1[JW], u2[JW];
+#pragma unroll
+      for (int jj = 0; jj < JW; ++jj) {
+        const long long tileA = (long long)(wave * JW + jj) * ntiles + 2 * np;
+        const float* bA = a.slab + (tileA * S + s) * 320;
+        const float* bB = a.slab + ((tileA + cB) * S + s) * 320;
+        tv[jj][0] = ld_sc1(bA + lane * 4);
+        tv[jj][1] = ld_sc1(bB + lane * 4);
+        u1[jj] = __hip_atomic_load(bA + 256 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u2[jj] = __hip_atomic_load(bA + 272 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (a.c2) r = r + pc2;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jj = 0; jj < JW; ++jj) {
+        r[jj][0] = r[jj][0] + tv[jj][0]; r[jj][1] = r[jj][1] + tv[jj][1];
+        t1[jj] += u1[jj]; t2[jj] += u2[jj];
+      }
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    const int j = wave * JW + jj, m = j * 16 + ml;
+    float mean = 0.f, rstd = 1.f;
+    if (a.ln) {
+      mean = t1[jj] / (float)a.K;
+      const float var = fmaxf(t2[jj] / (float)a.K - mean * mean, 0.f);
+      rstd = rsqrtf(var + 1e-5f);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int nt = 2 * np + c, n = nt * 16 + 4 * q;
+      if (nt >= ntiles || n >= a.N || !(a.out_packed || m < a.M)) continue;
+      f32x4 v = r[jj][c];
+      if (a.ln) v = (v - (c ? pc1B : pc1A) * mean) * rstd;
+      if (a.c2) v = v + (c ? pc2B : pc2A);
       if (a.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
       }
-      const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nte) * 64 + lane) * 4 : (long long)m * a.ldo + n_ep;
-      if (a.resid) r = r + pres[p];
-      *reinterpret_cast<f32x4*>(a.out + off) = r;
+      const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
+      if (a.resid) v = v + pres[jj][c];
+      *reinterpret_cast<f32x4*>(a.out + off) = v;
     }
   }
 }
@@ -944,21 +994,26 @@ size_t sfmi_decode_gemm_slab_floats(int M, int N, int S) { return (size_t)((M + 
 int sfmi_decode_gemm_wide_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
                               float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
                               int* cnt, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 192 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
+  if (!x || !Wp16 || !out || M <= 0 || M > 256 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
   if (out_packed && N % 16) return SFMI_EINVAL;
   if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
-  const int kslice = K / S;
-  if (kslice % (16 * 8)) return SFMI_EINVAL;
+  if ((K / S) % 128) return SFMI_EINVAL;
   DGemmArgs a;
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
   a.out_packed = out_packed; a.slab = slab; a.cnt = cnt;
   const int ntiles = (N + 15) / 16;
   dim3 grid((ntiles + 1) / 2, S);
-  const int steps = kslice / 8 / 16;
   hipStream_t st = (hipStream_t)stream;
-#define DW(MT_) do { if (steps % 2 == 0) hipLaunchKernelGGL((dgemm_wide_kernel<MT_, 2>), grid, dim3(512), 0, st, a); \
-                     else hipLaunchKernelGGL((dgemm_wide_kernel<MT_, 1>), grid, dim3(512), 0, st, a); } while (0)
-  if (M <= 64) DW(4); else if (M <= 128) DW(8); else hipLaunchKernelGGL((dgemm_wide_kernel<12, 1>), grid, dim3(512), 0, st, a);
+  static bool attr_set = false;   // idempotent, race-free: raises the dynamic LDS limit of the three instantiations
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dgemm_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (8192 + 512));
+    (void)hipFuncSetAttribute((const void*)dgemm_wide_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (8192 + 512));
+    (void)hipFuncSetAttribute((const void*)dgemm_wide_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * (8192 + 512));
+    (void)hipFuncSetAttribute((const void*)dgemm_wide_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (8192 + 512));
+    attr_set = true;
+  }
+#define DW(MT_) hipLaunchKernelGGL((dgemm_wide_kernel<MT_>), grid, dim3(256), MT_ * (8192 + 512), st, a)
+  if (M <= 64) DW(4); else if (M <= 128) DW(8); else if (M <= 192) DW(12); else DW(16);
 #undef DW
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
@@ -966,7 +1021,7 @@ int sfmi_decode_gemm_wide_f32(const float* x, const float* Wp16, const float* c1
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
                          float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
                          int* cnt, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 192 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
+  if (!x || !Wp16 || !out || M <= 0 || M > 256 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
   if (out_packed && N % 16) return SFMI_EINVAL;
   if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
   const int kslice = K / S;

@@ -311,18 +311,20 @@ class CondTupleGPT:
         D = self.D
         lib = L.lib()
         r = st["resid"]
+        # in-kernel split-K per GEMM: 64-row kernel (B <= 64) / wide kernel (one launch for up to 256 rows)
+        Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if B > 64 else (1, self.S_PROJ if B <= 16 else 4, 1, self.S_FC2, 1)
         for li, ly in enumerate(self.layers):
-            self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, st=st)
+            self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
             L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
                                                  L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
                                                  L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
-            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=self.S_PROJ if B <= 16 else 4, st=st)
-            self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, st=st)
-            self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=self.S_FC2, st=st)
+            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st)
+            self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st)
+            self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=Sfc2, st=st)
             if li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage:
                 s = ly.stage
                 hp, hc1, hc2 = self.head_f[s]
-                self._dgemm(r, hp, hc1, hc2, None, st["logit"], B, self.V, D, self.Vpad, 1, 0, packed=0, st=st)
+                self._dgemm(r, hp, hc1, hc2, None, st["logit"], B, self.V, D, self.Vpad, 1, 0, packed=0, S=Shead, st=st)
                 hist = sp["hist"][s] if sp.get("hist") is not None else None
                 L.check(lib.sfmi_gpt_sample_f32(L.ptr(st["logit"]), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
                                                 L.ptr(st["logp"]), L.ptr(hist), L.ptr(sp.get("force")),
@@ -338,8 +340,8 @@ class CondTupleGPT:
                  force_tokens=None, use_graph=True):
         """State + prefill + step-0 embedding + (cached) hipGraph of one decode step for one (micro-)batch."""
         B = c_tokens.shape[0]
-        if B > 64:
-            raise L.SfmiError("decode kernels support up to 64 rows per (micro-)batch")
+        if B > 256:
+            raise L.SfmiError("decode kernels support up to 256 rows per (micro-)batch")
         Lc_host = Lc.cpu().tolist()
         Lc_max = max(Lc_host)
         steps = min(max_steps, self.Lmax - Lc_max)   # never exceed block_size (DESIGN.md: stop, don't crop)

@@ -23,17 +23,17 @@ def unpack(p, M, N):
     return p.view(Mp // 16, N // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(Mp, N)[:M]
 
 
-for B in [int(b) for b in os.environ.get("B", "64,128,192").split(",")]:
+for B in [int(b) for b in os.environ.get("B", "64,192,256").split(",")]:
     st = gpt._alloc(B, 8)
     Bp = st["resid"].shape[0]
     fn = lib.sfmi_decode_gemm_wide_f32 if (B > 64 or os.environ.get("WIDE")) else lib.sfmi_decode_gemm_f32
     ly = gpt.layers[0]
     torch.manual_seed(0)
     for nm, wp, c1, c2, N, K, ln, act, use_res, Ss in (
-            ("qkv", "pqkv", "c1qkv", "c2qkv", 3 * D, D, 1, 0, False, (1, 2, 4)),
+            ("qkv", "pqkv", "c1qkv", "c2qkv", 3 * D, D, 1, 0, False, (1, 2)),
             ("proj", "pproj", None, "bproj", D, D, 0, 0, True, (2, 4, 8)),
-            ("fc1", "pfc1", "c1fc1", "c2fc1", 4 * D, D, 1, 1, False, (1, 2, 4)),
-            ("fc2", "pfc2", None, "bfc2", D, 4 * D, 0, 0, True, (4, 8, 16))):
+            ("fc1", "pfc1", "c1fc1", "c2fc1", 4 * D, D, 1, 1, False, (1, 2)),
+            ("fc2", "pfc2", None, "bfc2", D, 4 * D, 0, 0, True, (4, 8))):
         x = torch.randn(B, K, device=dev)
         xp = pack(x, Bp)
         res = torch.randn(B, N, device=dev) if use_res else None
