@@ -58,3 +58,48 @@ def allreduce_mean_(flat: torch.Tensor, dist):
         dist.all_reduce(flat)
         flat.div_(dist.get_world_size())
     return flat
+
+
+class GradBuckets:
+    """Bucketed gradient all-reduce overlapped with the backward pass (DDP training).
+
+    The trainer's gradients live in ONE flat buffer laid out layer by layer; a bucket is a contiguous [lo, hi) slice of
+    it.  `ready(name)` is called by the backward pass the moment the last gradient of that bucket has been enqueued on
+    the compute stream and launches an asynchronous all-reduce of the slice (RCCL runs it on its own stream, ordered
+    after the work already enqueued on the caller's stream), so the collective of layer l rides under the backward
+    kernels of layers l-1, l-2, ...  `finish()` waits for every pending collective and applies the 1/world mean.
+    Bucket = one transformer block (12.6 M floats = 50 MB): 26 collectives per step instead of 400 per-tensor ones,
+    each large enough to run the ring at xGMI link rate.  gloo (CPU tests) takes the same path with SUM + scale.
+    """
+
+    def __init__(self, flat: torch.Tensor, ranges: dict, dist):
+        self.flat, self.ranges, self.dist = flat, dict(ranges), dist
+        self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+        self.pending, self.done = [], set()
+        self.avg = False
+        if self.world > 1:
+            self.avg = dist.get_backend() == "nccl"     # RCCL averages in the collective; gloo has no AVG
+
+    def ready(self, name):
+        if self.world == 1 or name in self.done:
+            return
+        lo, hi = self.ranges[name]
+        op = self.dist.ReduceOp.AVG if self.avg else self.dist.ReduceOp.SUM
+        self.pending.append((name, self.dist.all_reduce(self.flat[lo:hi], op=op, async_op=True)))
+        self.done.add(name)
+
+    def finish(self):
+        """Launch whatever was never marked ready, wait for everything, return the bucket names in launch order."""
+        if self.world == 1:
+            return []
+        for name in self.ranges:
+            self.ready(name)
+        order = []
+        for name, work in self.pending:
+            work.wait()
+            order.append(name)
+            if not self.avg:
+                lo, hi = self.ranges[name]
+                self.flat[lo:hi].div_(self.world)
+        self.pending, self.done = [], set()
+        return order

@@ -51,6 +51,20 @@ class GPTTrainer:
         self.flat_m = torch.zeros(n, device=self.dev)
         self.flat_v = torch.zeros(n, device=self.dev)
         self._wT = {}
+        # gradient buckets for the overlapped all-reduce: one per block, one for both heads, one for the embeddings
+        # (flat order = backward-completion order reversed: blocks 0..n-1, heads, embeddings)
+        off, o = {}, 0
+        for name, t, _ in P:
+            off[name] = (o, o + t.numel())
+            o += t.numel()
+        rng = {}
+        for li in range(len(g.layers)):
+            rng[f"L{li}"] = (off[f"L{li}.ln1.w"][0], off[f"L{li}.bfc2"][1])
+        rng["heads"] = (off["head0.ln.w"][0], off["head1.w"][1])
+        rng["emb"] = (off["E0"][0], off["cond_pos_emb"][1])
+        from .dist import GradBuckets
+        self.buckets = GradBuckets(self.flat_grad, rng, dist)
+        self._sync = False
 
     # ------------------------------------------------------------------ small wrappers
     def _f(self, *shape):
@@ -99,10 +113,16 @@ class GPTTrainer:
 
     # ------------------------------------------------------------------ forward + backward
     @torch.no_grad()
-    def loss_and_grad(self, c_indices, z_indices, accumulate=False):
-        """-> loss (0-dim tensor).  Gradients of every parameter are left in self.grad[name] (flat buffer)."""
+    def _ready(self, name):
+        if self._sync:
+            self.buckets.ready(name)
+
+    def loss_and_grad(self, c_indices, z_indices, accumulate=False, sync=False):
+        """-> loss (0-dim tensor).  Gradients of every parameter are left in self.grad[name] (flat buffer).
+        sync=True (last micro-step of a data-parallel step): each block's gradient bucket is all-reduced as soon as it
+        is final, under the backward kernels of the remaining blocks (dist.GradBuckets); finish with all_reduce_grads()."""
         g, D, dev, lib = self.g, self.D, self.dev, L.lib()
-        self._acc = accumulate
+        self._acc, self._sync = accumulate, sync
         if not accumulate:
             self.flat_grad.zero_()
         c = torch.as_tensor(c_indices).to(dev, torch.int32)
@@ -181,6 +201,7 @@ class GPTTrainer:
             dxnh = self._f(M, D)
             self._gemm(dlg, whT, None, None, dxnh, M, D, g.Vpad)
             d_head[s] = self._ln_bwd(dxnh, head_in[s], g.head_ln[s][0], None, M, f"head{s}.ln.w", f"head{s}.ln.b")
+        self._ready("heads")
         # ---- backward through the blocks -----------------------------------------------------------------------------
         dr = d_head[1]
         lse = self._f(B, g.H, Lq)
@@ -221,6 +242,7 @@ class GPTTrainer:
             self._gemm(dqkv, self._wt(p + "wqkv", ly.wqkv), None, None, dxn1, M, D, 3 * D)
             dr = self._ln_bwd(dxn1, s["x_in"], ly.ln1[0], dr1, M, p + "ln1.w", p + "ln1.b")
             saved[li] = None
+            self._ready(f"L{li}")     # this block's 50 MB of gradients are final: all-reduce under the next blocks' backward
         # ---- embeddings (mingpt.py:256-286): E0[pos] + E1[val] + Ex[extra] + positional --------------------------------
         idx = cz[:, :Lq, :]
         self._scatter(dr, idx[..., 0].contiguous().view(-1), "E0", M)
@@ -232,14 +254,15 @@ class GPTTrainer:
         if Lq > Lc:
             L.check(lib.sfmi_colsum_f32(dr.data_ptr() + Lc * D * 4, L.ptr(gp), B, (Lq - Lc) * D, Lq * D, int(accumulate),
                                         L.stream_ptr()), "colsum")
+        self._ready("emb")
         return loss
 
     # ------------------------------------------------------------------ optimizer / data parallel
     @torch.no_grad()
     def all_reduce_grads(self):
-        """DDP gradient synchronisation: ONE collective over the flat gradient buffer (mean over ranks)."""
-        from .dist import allreduce_mean_
-        allreduce_mean_(self.flat_grad, self.dist)
+        """DDP gradient synchronisation (mean over ranks): waits for the per-block collectives that `loss_and_grad(...,
+        sync=True)` launched under the backward pass, and launches any bucket that was not (e.g. sync=False)."""
+        return self.buckets.finish()
 
     @torch.no_grad()
     def optimizer_step(self):
@@ -257,7 +280,7 @@ class GPTTrainer:
 
     @torch.no_grad()
     def training_step(self, c_indices, z_indices):
-        loss = self.loss_and_grad(c_indices, z_indices)
+        loss = self.loss_and_grad(c_indices, z_indices, sync=True)
         self.all_reduce_grads()
         self.optimizer_step()
         return loss

@@ -125,6 +125,15 @@ t = torch.tensor([float(rank + 1)]); dist.all_reduce(t, op=dist.ReduceOp.MAX)
 g = torch.arange(6, dtype=torch.float32) * (rank + 1)          # flat "gradient" buffer of the trainer
 D.allreduce_mean_(g, dist)
 ok = ok and torch.allclose(g, torch.arange(6, dtype=torch.float32) * (1 + world) / 2)
+# bucketed, overlapped gradient all-reduce of the trainer (dist.GradBuckets): buckets become ready in backward order
+flat = torch.arange(40, dtype=torch.float32) * (rank + 1)
+bk = D.GradBuckets(flat, {"L0": (0, 12), "L1": (12, 24), "heads": (24, 30), "emb": (30, 40)}, dist)
+for name in ("heads", "L1", "L0"):
+    bk.ready(name)
+order = bk.finish()                                              # "emb" was never marked: finish() launches it
+ok = ok and order == ["heads", "L1", "L0", "emb"] and torch.allclose(flat, torch.arange(40, dtype=torch.float32) * (1 + world) / 2)
+flat.mul_(rank + 1); bk.ready("L0"); bk.finish()                 # reusable for the next step
+ok = ok and torch.allclose(flat, torch.arange(40, dtype=torch.float32) * (1 + world) / 2 * (1 + world) / 2)
 print("OK" if ok and t.item() == world else "FAIL", flush=True)
 dist.barrier(); dist.destroy_process_group()
 """
