@@ -132,6 +132,16 @@ int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpac
 int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, const float* wpack, float* out, int B, int G,
                             int apply_sigmoid, void* stream);
 
+/* ---- Iso-surface extraction: xgutils/geoutil.py:175-233 array2mesh -> mcubes.marching_cubes
+ *      (PyMCubes, third party) at thresh .5 over the decoded occupancy grid; call sites shapeformer.py:355-356 (vis_ind),
+ *      xgutils/vis/npfvis.py:88-98 (plot_3d_recon).  Two passes so the caller can size the outputs. ------------------- */
+size_t sfmi_mc_workspace_bytes(int B, int Q);
+/* occ (B,Q,Q,Q) f32; offsets (device, 2*(B+1) ints): exclusive vertex offsets [B+1] then triangle offsets [B+1] */
+int sfmi_mc_count_f32(const float* occ, float iso, int B, int Q, void* workspace, int* offsets, void* stream);
+/* verts (V,3) f32 = index/(Q-1)*(hi-lo)+lo (array2mesh's mapping onto the bbox of coords); faces (T,3) int32, local per shape */
+int sfmi_mc_emit_f32(const float* occ, float iso, int B, int Q, const void* workspace, const int* offsets, float lo0, float lo1,
+                     float lo2, float hi0, float hi1, float hi2, float* verts, int* faces, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

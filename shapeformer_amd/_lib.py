@@ -15,12 +15,15 @@ _lib = None
 
 c_f32p = C.c_void_p
 c_ptr = C.c_void_p
-i32, i64, sz = C.c_int, C.c_longlong, C.c_size_t
+i32, i64, sz, f32 = C.c_int, C.c_longlong, C.c_size_t, C.c_float
 
 # name -> (restype, argtypes)   -- mirrors include/sfmi.h
 PROTOTYPES = {
     "sfmi_version": (i32, []),
     # SDF query
+    "sfmi_mc_workspace_bytes": (sz, [i32, i32]),
+    "sfmi_mc_count_f32": (i32, [c_ptr, f32, i32, i32, c_ptr, c_ptr, c_ptr]),
+    "sfmi_mc_emit_f32": (i32, [c_ptr, f32, i32, i32, c_ptr, c_ptr] + [f32] * 6 + [c_ptr, c_ptr, c_ptr]),
     "sfmi_sdf_pack_floats": (sz, []),
     "sfmi_sdf_pack_weights": (i32, [c_ptr] * 11),
     "sfmi_sdf_query_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, i64, i32, i32, c_ptr]),
