@@ -4,8 +4,9 @@ Mirrors xgutils/optutil.py:44-70 (`load_option` with recursive `inherit_from`), 
 (`dictUpdate`: replace wholesale unless both sides are mappings of the same type) and :148-156
 (`load_object`, `instantiate_from_opt`: returns None when `class` is missing/None), so the reference's
 YAMLs load UNCHANGED:  every `class: shapeformer....` path the hot path names resolves to the MI355X-native
-class with the same ctor kwargs.  Classes off the hot path (datasets, Lightning
-callbacks' rendering half, trainer) are not provided — resolving them raises with a clear message.
+class with the same ctor kwargs.  The two inference callbacks resolve to their compute + export
+halves (callbacks.py: tokens, meshes, eval samples; no rendering).  Classes off the hot path (datasets, Lightning
+trainer) are not provided — resolving them raises with a clear message.
 
     opt   = get_opt("configs/shapeformer/shapenet_scale.yaml")
     model = instantiate_from_opt(opt["pl_model_opt"])          # -> ShapeFormerModel on cuda:0
@@ -209,7 +210,16 @@ def default_vqdif_kwargs(res=16):
 
 
 # --------------------------------------------------------------------------- plugin loader
+def _cb(name):
+    def make(**kw):
+        from . import callbacks
+        return getattr(callbacks, name)(**kw)
+    return make
+
+
 REGISTRY = {
+    "shapeformer.models.vqdif.vqdif.VisSparseRecon3D": _cb("VisSparseRecon3D"),
+    "shapeformer.models.shapeformer.shapeformer.VisShapeFormer": _cb("VisShapeFormer"),
     "shapeformer.models.vqdif.vqdif.VQDIF": VQDIFModel,
     "shapeformer.models.shapeformer.shapeformer.ShapeFormer": ShapeFormerModel,
     "shapeformer.models.shapeformer.transformer.mingpt.CondTupleGPT": CondTupleGPTModel,

@@ -1,5 +1,7 @@
 """GPU: the reference's YAML/plugin surface end to end — instantiate_from_opt on a config with the shipped YAML's keys
 (shapenet_scale.yaml layout, transformer shrunk for test speed), completion and one training step."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -36,3 +38,68 @@ def test_instantiate_complete_and_train(dev):
     model.make_trainer(opt["pl_model_opt"]["kwargs"]["optim_opt"])
     l = [model.training_step(batch).item() for _ in range(4)]
     assert all(np.isfinite(l)) and l[-1] < l[0]
+
+
+class _Items:
+    """Dataset stand-in: dict items of numpy arrays like the reference datasets' __getitem__."""
+
+    def __init__(self, n):
+        from shapeformer_amd import synthetic
+        self.items = [synthetic.make_shape(40 + i, n_full=8192, n_partial=4096) for i in range(n)]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def test_inference_callbacks_compute_cache_and_export(dev, tmp_path):
+    """VisShapeFormer / VisSparseRecon3D resolved from their reference dotted names: compute_batch dict
+    keys, computed/<name>.npy cache (reloaded with load_compute), meshes/*.ply and eval/*.npz, probability order."""
+    from shapeformer_amd import plugin as P, meshio, callbacks as CB
+    opt = P.get_opt(_opt())
+    model = P.instantiate_from_opt(opt["pl_model_opt"])
+    data = _Items(3)
+    cb = P.instantiate_from_opt({"class": "shapeformer.models.shapeformer.shapeformer.VisShapeFormer", "kwargs": dict(
+        no_sanity_check=True, every_n_epoch=4, end_tokens=[4096, 4096], top_k=100, top_p=0.4, depth=4, resolution=[256, 256],
+        render_samples=32, visual_indices=[0, 2], sample_n=4, sample_max_step=12, decode_res=32, data_dir=str(tmp_path / "sf"),
+        keep_logits_history=True)})
+    out = cb.process(model, data)
+    assert sorted(out) == ["0", "2"]
+    comp = np.load(tmp_path / "sf" / "computed" / "0.npy", allow_pickle=True).item()
+    assert set(comp) >= {"batch", "samples", "origin_samples", "logits_history", "c_ind", "z_ind", "empty_index", "log_prob"}
+    S, Ls, _ = comp["samples"].shape
+    assert S == 4 and comp["log_prob"].shape == (4, Ls, 2) and comp["c_ind"].shape[0] == 1
+    assert (comp["c_ind"][0, -1] == 4096).all()                                  # condition ends with the end-token pair
+    # the device-side log-probabilities are the reference's compute_log_probs of the recorded step logits
+    want = CB.compute_log_probs(comp["samples"], comp["logits_history"])
+    live = np.isfinite(want)
+    assert np.abs(comp["log_prob"][live] - want[live]).max() < 1e-4
+    order = cb.sample_order(comp)
+    sums = comp["log_prob"].sum((1, 2))
+    assert (np.diff(sums[order]) <= 0).all()
+    # exported files: one ply per non-degenerate token set, eval npz with the most probable sample first
+    plys = sorted(os.listdir(tmp_path / "sf" / "meshes"))
+    assert any(p.startswith("0_data_c") for p in plys) and all(p.endswith("_mesh.ply") for p in plys)
+    sample_plys = [p for p in plys if p.startswith("0_s")]
+    if sample_plys:
+        ev = np.load(tmp_path / "sf" / "eval" / "0.npz")
+        assert ev["eval_pc"].shape == (100000, 3) and np.array_equal(ev["eval_pc"], ev["recon_0"])
+        v, f = meshio.read_ply(str(tmp_path / "sf" / "meshes" / sample_plys[0]))
+        assert f.max() < len(v) and np.abs(v).max() <= 1.0
+    # load_compute=True reuses the cache: poison the model to prove no recomputation happens
+    cb.load_compute = True
+    cb.compute_batch = None
+    out2 = cb.process(model, data, visual_indices=[0])
+    assert sorted(out2["0"]) == sorted(out["0"])
+    # VQDIF reconstruction callback
+    rc = P.instantiate_from_opt({"class": "shapeformer.models.vqdif.vqdif.VisSparseRecon3D", "kwargs": dict(
+        quant_grid_depth=4, decoder_resolution=32, max_length=512, end_tokens=[4096, 4096], visual_indices=[1],
+        data_dir=str(tmp_path / "vq"))})
+    r = rc.process(model.representer.vqvae_model, data)
+    comp = np.load(tmp_path / "vq" / "computed" / "1.npy", allow_pickle=True).item()
+    assert set(comp) == {"logits", "quant_ind", "sparse", "grid_mask", "batch"}
+    assert comp["logits"].shape == (1, 32 ** 3, 1) and comp["quant_ind"].shape == (1, 16, 16, 16) and comp["sparse"].shape[1] == 3
+    assert comp["grid_mask"].dtype == bool and os.path.exists(tmp_path / "vq" / "meshes" / "1.ply")
+    assert "recon_mesh" in r["1"]
