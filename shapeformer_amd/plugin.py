@@ -5,8 +5,9 @@ Mirrors xgutils/optutil.py:44-70 (`load_option` with recursive `inherit_from`), 
 (`load_object`, `instantiate_from_opt`: returns None when `class` is missing/None), so the reference's
 YAMLs load UNCHANGED:  every `class: shapeformer....` path the hot path names resolves to the MI355X-native
 class with the same ctor kwargs.  The two inference callbacks resolve to their compute + export
-halves (callbacks.py: tokens, meshes, eval samples; no rendering).  Classes off the hot path (datasets, Lightning
-trainer) are not provided — resolving them raises with a clear message.
+halves (callbacks.py: tokens, meshes, eval samples; no rendering) and the datamodule / dataset / partial-selector names
+to data.py.  Classes off the path (Lightning trainer, xgutils rendering) are not provided — resolving them raises with a
+clear message.
 
     opt   = get_opt("configs/shapeformer/shapenet_scale.yaml")
     model = instantiate_from_opt(opt["pl_model_opt"])          # -> ShapeFormerModel on cuda:0
@@ -225,13 +226,19 @@ REGISTRY = {
     "shapeformer.models.shapeformer.transformer.mingpt.CondTupleGPT": CondTupleGPTModel,
     "shapeformer.models.shapeformer.representers.AR_N": ARNRepresenter,
 }
-OUT_OF_SCOPE_PREFIXES = ("shapeformer.datamodule", "shapeformer.data.", "shapeformer.trainer", "xgutils.")
+OUT_OF_SCOPE_PREFIXES = ("shapeformer.trainer", "xgutils.")
 
 
 def load_object(object_path):
     """sysutil.py:148-152, with the hot-path classes mapped onto the MI355X-native implementations."""
     if object_path in REGISTRY:
         return REGISTRY[object_path]
+    if object_path == "shapeformer.datamodule.DataModule" or object_path.startswith("shapeformer.data."):
+        from . import data                      # data side (SURVEY.md §8(f) f3)
+        if object_path == "shapeformer.datamodule.DataModule":
+            return data.DataModule
+        if object_path in data.DATA_REGISTRY:
+            return data.DATA_REGISTRY[object_path]
     if object_path.startswith(OUT_OF_SCOPE_PREFIXES) or object_path.startswith("shapeformer."):
         raise NotImplementedError(f"{object_path}: outside the accelerated hot path (SURVEY.md §8); not provided by shapeformer_amd")
     mod, name = object_path.rsplit(".", 1)

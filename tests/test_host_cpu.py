@@ -86,7 +86,12 @@ def test_yaml_loader_and_plugin_resolution(tmp_path):
     assert P.load_object("shapeformer.models.vqdif.vqdif.VQDIF") is P.VQDIFModel
     assert P.load_object("shapeformer.models.shapeformer.representers.AR_N") is P.ARNRepresenter
     with pytest.raises(NotImplementedError):
-        P.load_object("shapeformer.datamodule.DataModule")
+        P.load_object("shapeformer.trainer.Trainer")
+    from shapeformer_amd import data as D
+    assert P.load_object("shapeformer.datamodule.DataModule") is D.DataModule
+    assert P.load_object("shapeformer.data.partial.VirtualScanSelector") is D.VirtualScanSelector
+    with pytest.raises(NotImplementedError):
+        P.load_object("shapeformer.data.ar_datasets.imnet_datasets.Imnet2LowResDataset_AR")
     # the shipped YAMLs resolve unchanged when the reference tree is present (build container only)
     ref = "/root/reference/configs/shapeformer/shapenet_scale.yaml"
     if os.path.exists(ref):
