@@ -132,6 +132,43 @@ int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpac
 int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, const float* wpack, float* out, int B, int G,
                             int apply_sigmoid, void* stream);
 
+/* ---- Training step of the VQDIF autoencoder (csrc/train_vqdif.hip): vqdif.py:78-137 (forward, VQLoss,
+ *      Adam), quantizer.py:68-89 (EMA codebook, straight-through), backward of enc.py:66-140, updown.py:79-132,
+ *      unet3d.py:79-293,449-474, dec.py:62-100.  Input gradients of convolutions / linears reuse sfmi_conv3d_cl_f32 /
+ *      sfmi_gemm_f32 on tap-flipped / transposed weights. ------------------------------------------------------------- */
+int sfmi_relu_bwd_f32(const float* dy, const float* y, float* dx, long long n, void* stream);
+int sfmi_lincomb_f32(float a, const float* x, float b, const float* y, float* out, long long n, void* stream);   /* a x + b y (y may be NULL) */
+/* out = A[b,c] u + Bc[b,c] v + Cc[b,c] on (B,V,C): GroupNorm backward is affine in (dy, x) per (sample, channel) */
+int sfmi_affine2_cl_f32(const float* u, const float* v, const float* A, const float* Bc, const float* Cc, float* out, int B,
+                        long long V, int C, void* stream);
+/* partial (B,S,C,2) doubles: per slice sums of dy and dy*x per (sample, channel) */
+int sfmi_chan_dot_stats_f32(const float* dy, const float* x, double* partial, int B, long long V, int C, int S, void* stream);
+int sfmi_upsample2_cl_f32(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);            /* nearest x2 */
+int sfmi_sumpool2_cl_f32(const float* dy, float* dx, int B, int Do, int Ho, int Wo, int Ctot, int c0, int Cs, void* stream);
+int sfmi_maxpool2_bwd_cl_f32(const float* x, const float* y, const float* dy, float* dx, int B, int Do, int Ho, int Wo, int C,
+                             void* stream);
+int sfmi_cells_f32(const float* cloud, int* cell, float* p_half, int B, int T, int G, void* stream);             /* common.py:260-321 */
+/* torch_scatter.scatter_max + gather (enc.py:95-112): keys (B,ncell,C) int32 pre-filled with 0x80 bytes */
+int sfmi_cell_max_f32(const float* net, const int* cell, int* keys, float* out, int B, int T, long long ncell, int C, int ldo, int co,
+                      void* stream);
+int sfmi_cell_scatter_add_f32(const float* src, const int* cell, long long* acc, int* count, int B, int T, long long ncell, int C,
+                              int lds, int cs, void* stream);
+int sfmi_cell_max_bwd_f32(const float* net, const int* keys, const long long* acc, const int* cell, float* dnet, int B, int T,
+                          long long ncell, int C, int ldd, int accumulate, void* stream);
+int sfmi_cell_mean_f32(const long long* acc, const int* count, float* grid, int B, long long ncell, int C, void* stream);  /* enc.py:66-75 */
+int sfmi_cell_mean_bwd_f32(const float* dgrid, const int* count, const int* cell, float* dc, int B, int T, long long ncell, int C,
+                           void* stream);
+int sfmi_trilinear_cl_f32(const float* xyz, const float* grid, float* out, int B, long long N, int G, int C, void* stream);   /* dec.py:62-68 */
+int sfmi_trilinear_bwd_cl_f32(const float* xyz, const float* dout, long long* acc, int B, long long N, int G, int C, void* stream);
+int sfmi_bce_logits_f32(const float* logits, const float* label, float* loss_rows, float* dlogits, long long n, float scale,
+                        void* stream);                                                                             /* vqdif.py:151-167 */
+int sfmi_vq_stats_f32(const float* x, const int* idx, long long* sums, int* counts, long long rows, int D, void* stream);
+int sfmi_vq_ema_update_f32(float* N, float* z_avg, float* emb, const float* counts, const float* sums, int K, int D, float gamma,
+                           float eps, void* stream);                                                               /* quantizer.py:68-86 */
+/* part (nsplit, KS^3, Cout, Cin): per-slice sums of dY[r][co] * X[shifted r][ci]; reduce with sfmi_colsum_f32 */
+int sfmi_conv3d_wgrad_f32(const float* dy, const float* x, float* part, int B, int Di, int Hi, int Wi, int Cin, int Cout, int KS,
+                          int stride, int pad, int ldy, int ldx, int nsplit, void* stream);
+
 /* ---- Iso-surface extraction: xgutils/geoutil.py:175-233 array2mesh -> mcubes.marching_cubes
  *      (PyMCubes, third party) at thresh .5 over the decoded occupancy grid; call sites shapeformer.py:355-356 (vis_ind),
  *      xgutils/vis/npfvis.py:88-98 (plot_3d_recon).  Two passes so the caller can size the outputs. ------------------- */

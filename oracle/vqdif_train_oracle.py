@@ -1,0 +1,55 @@
+"""ORACLE (test infrastructure only): the VQDIF training step restated on the functional oracle.
+
+  training_losses   VQDIF.forward in training mode + VQLoss (vqdif.py:78-98,151-167; quantizer.py:31-89): encode ->
+                    nearest code (pre-update codebook) -> straight-through -> decode at Xtg -> BCE-with-logits (mean)
+                    + beta * mean((x - q.detach())^2)
+  ema_update        quantizer.py:68-86 (gamma .99, eps 1e-7): N, z_avg, embedding.weight after one training forward
+  loss_and_grads    torch autograd of training_losses w.r.t. every trainable tensor
+Pinned against the imported reference (real `VQDIF.get_loss(...).backward()` in train mode on hash weights) by
+oracle/make_golden_train.py; fixture tests/golden/vqdif_train.npz.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import vqdif_oracle as VO
+
+
+def training_losses(sd, Xbd, Xtg, Ytg, beta):
+    fea, _ = VO.encode(sd, Xbd)                                  # (B,d,R,R,R)
+    B, d = fea.shape[:2]
+    W = sd["quantizer.embedding.weight"]
+    x = fea.permute(0, 2, 3, 4, 1).contiguous().view(-1, d)
+    with torch.no_grad():
+        dist = (x ** 2).sum(1, keepdim=True) - 2 * torch.mm(x, W.t()) + (W.t() ** 2).sum(0, keepdim=True)
+        idx = torch.max(-dist, dim=1)[1]
+    q = W.detach()[idx].view(B, *fea.shape[2:], d).permute(0, 4, 1, 2, 3).contiguous()
+    q_st = (q - fea).detach() + fea
+    diff = (fea - q.detach()).pow(2).mean()
+    logits = VO.sdf_query(sd, VO.decoder_grid(sd, q_st), Xtg)
+    recon = F.binary_cross_entropy_with_logits(logits, Ytg)
+    return dict(loss=recon + beta * diff, recon_loss=recon, diff_loss=diff, idx=idx, x=x.detach(), logits=logits.detach())
+
+
+def ema_update(sd, x, idx, gamma=0.99, eps=1e-7):
+    """-> (N, z_avg, embedding.weight) after the update; x (n,d) detached latent rows, idx (n,) chosen codes."""
+    K = sd["quantizer.embedding.weight"].shape[0]
+    onehot = F.one_hot(idx, K).to(x.dtype)
+    N = sd["quantizer.N"] * gamma + (1 - gamma) * onehot.sum(0)
+    z = sd["quantizer.z_avg"] * gamma + (1 - gamma) * torch.mm(x.t(), onehot).t()
+    n = N.sum()
+    w = (N + eps) / (n + K * eps) * n
+    return N, z, z / w.unsqueeze(1)
+
+
+def trainable_keys(sd):
+    return [k for k in sd if not k.startswith("quantizer.")]
+
+
+def loss_and_grads(sd, Xbd, Xtg, Ytg, beta):
+    keys = trainable_keys(sd)
+    leaf = dict(sd)
+    for k in keys:
+        leaf[k] = sd[k].clone().requires_grad_(True)
+    out = training_losses(leaf, Xbd, Xtg, Ytg, beta)
+    grads = torch.autograd.grad(out["loss"], [leaf[k] for k in keys], allow_unused=True)
+    return out, {k: g for k, g in zip(keys, grads)}

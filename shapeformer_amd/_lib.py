@@ -21,6 +21,25 @@ i32, i64, sz, f32 = C.c_int, C.c_longlong, C.c_size_t, C.c_float
 PROTOTYPES = {
     "sfmi_version": (i32, []),
     # SDF query
+    "sfmi_relu_bwd_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
+    "sfmi_lincomb_f32": (i32, [f32, c_ptr, f32, c_ptr, c_ptr, i64, c_ptr]),
+    "sfmi_affine2_cl_f32": (i32, [c_ptr] * 6 + [i32, i64, i32, c_ptr]),
+    "sfmi_chan_dot_stats_f32": (i32, [c_ptr, c_ptr, c_ptr, i32, i64, i32, i32, c_ptr]),
+    "sfmi_upsample2_cl_f32": (i32, [c_ptr, c_ptr] + [i32] * 5 + [c_ptr]),
+    "sfmi_sumpool2_cl_f32": (i32, [c_ptr, c_ptr] + [i32] * 7 + [c_ptr]),
+    "sfmi_maxpool2_bwd_cl_f32": (i32, [c_ptr] * 4 + [i32] * 5 + [c_ptr]),
+    "sfmi_cells_f32": (i32, [c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
+    "sfmi_cell_max_f32": (i32, [c_ptr] * 4 + [i32, i32, i64, i32, i32, i32, c_ptr]),
+    "sfmi_cell_scatter_add_f32": (i32, [c_ptr] * 4 + [i32, i32, i64, i32, i32, i32, c_ptr]),
+    "sfmi_cell_max_bwd_f32": (i32, [c_ptr] * 5 + [i32, i32, i64, i32, i32, i32, c_ptr]),
+    "sfmi_cell_mean_f32": (i32, [c_ptr] * 3 + [i32, i64, i32, c_ptr]),
+    "sfmi_cell_mean_bwd_f32": (i32, [c_ptr] * 4 + [i32, i32, i64, i32, c_ptr]),
+    "sfmi_trilinear_cl_f32": (i32, [c_ptr] * 3 + [i32, i64, i32, i32, c_ptr]),
+    "sfmi_trilinear_bwd_cl_f32": (i32, [c_ptr] * 3 + [i32, i64, i32, i32, c_ptr]),
+    "sfmi_bce_logits_f32": (i32, [c_ptr] * 4 + [i64, f32, c_ptr]),
+    "sfmi_vq_stats_f32": (i32, [c_ptr] * 4 + [i64, i32, c_ptr]),
+    "sfmi_vq_ema_update_f32": (i32, [c_ptr] * 5 + [i32, i32, f32, f32, c_ptr]),
+    "sfmi_conv3d_wgrad_f32": (i32, [c_ptr] * 3 + [i32] * 12 + [c_ptr]),
     "sfmi_mc_workspace_bytes": (sz, [i32, i32]),
     "sfmi_mc_count_f32": (i32, [c_ptr, f32, i32, i32, c_ptr, c_ptr, c_ptr]),
     "sfmi_mc_emit_f32": (i32, [c_ptr, f32, i32, i32, c_ptr, c_ptr] + [f32] * 6 + [c_ptr, c_ptr, c_ptr]),

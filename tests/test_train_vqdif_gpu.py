@@ -1,0 +1,91 @@
+"""GPU: VQDIF training step against torch autograd of the CPU oracle and the reference-pinned
+fixture tests/golden/vqdif_train.npz (losses, per-tensor gradient checksums of the REAL reference backward)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(ROOT, "tests", "golden", "vqdif_train.npz"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _sd():
+    from shapeformer_amd import weights as W
+    return W.make_state_dict(W.vqdif_spec(16))
+
+
+def _to_ref_layout(tr, name, g):
+    g = g.detach().cpu().numpy()
+    if name in tr.kind:
+        ks = tr.kind[name][1]
+        g = np.ascontiguousarray(g.transpose(1, 2, 0)).reshape(g.shape[1], g.shape[2], ks, ks, ks)
+    return g
+
+
+def test_losses_and_every_gradient_match_oracle_and_reference_checksums(dev):
+    from oracle import vqdif_oracle as VO, vqdif_train_oracle as TO
+    from shapeformer_amd.train_vqdif import VQDIFTrainer
+    sd = _sd()
+    tr = VQDIFTrainer(sd, res=16, device=dev, beta=float(G["beta"]))
+    out = tr.loss_and_grad(G["Xbd"], G["Xtg"], G["Ytg"])
+    # losses: the reference's own numbers
+    assert abs(float(out["loss"]) - float(G["loss"])) < 2e-5
+    assert abs(float(out["recon_loss"]) - float(G["recon_loss"])) < 2e-5 and abs(float(out["diff_loss"]) - float(G["diff_loss"])) < 2e-5
+    assert np.array_equal(tr._last[1].cpu().numpy().astype(np.int16), G["idx"])            # chosen codes: bit-exact
+    # gradients: full tensors against oracle autograd (oracle == reference to 4e-7, oracle/make_golden_train.py)
+    tsd = VO.to_torch_sd(sd)
+    _, og = TO.loss_and_grads(tsd, *(torch.from_numpy(G[k]) for k in ("Xbd", "Xtg", "Ytg")), float(G["beta"]))
+    worst = ("", 0.0)
+    for k, ref in og.items():
+        got = _to_ref_layout(tr, k, tr.g[k])
+        ref = ref.numpy()
+        assert got.shape == ref.shape, k
+        e = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 5e-4, (k, e)
+    print("worst gradient rel err", worst)
+    # and the reference's per-tensor checksums stored in the fixture
+    for k, s, a in zip(G["grad_names"], G["grad_sum"], G["grad_abs"]):
+        got = _to_ref_layout(tr, str(k), tr.g[str(k)]).astype(np.float64)
+        assert abs(np.abs(got).sum() - a) <= 1e-3 * a + 1e-9, k
+        assert abs(got.sum() - s) <= 1e-3 * a + 1e-9, k
+    # EMA codebook update
+    N, z, emb = TO.ema_update(tsd, TO.training_losses(tsd, *(torch.from_numpy(G[k]) for k in ("Xbd", "Xtg", "Ytg")), float(G["beta"]))["x"],
+                              torch.from_numpy(G["idx"].astype(np.int64)))
+    tr.ema_update()
+    assert np.abs(tr.N.cpu().numpy() - N.numpy()).max() < 1e-5
+    assert np.abs((tr.z_avg.cpu().numpy() - z.numpy()) / (np.abs(z.numpy()) + 1e-3)).max() < 1e-4
+    assert np.abs((tr.emb.cpu().numpy() - emb.numpy()) / (np.abs(emb.numpy()) + 1e-3)).max() < 1e-4
+    assert abs(float(tr.N.double().sum()) - float(G["ema_N_sum"])) < 1e-3
+
+
+def test_training_steps_reduce_the_loss_and_export_loads_into_the_inference_path(dev):
+    from shapeformer_amd.train_vqdif import VQDIFTrainer
+    from shapeformer_amd.vqdif import VQDIF
+    tr = VQDIFTrainer(_sd(), res=16, device=dev, lr=1e-3, beta=0.001)
+    batch = dict(Xbd=np.repeat(G["Xbd"], 2, 0), Xtg=np.repeat(G["Xtg"], 2, 0), Ytg=np.repeat(G["Ytg"], 2, 0))
+    losses = [float(tr.training_step(batch)["recon_loss"]) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    sd = tr.state_dict()
+    assert sd["decoder.unet3d.decoders.0.basic_module.SingleConv1.conv.weight"].shape == (256, 768, 3, 3, 3)
+    vq = VQDIF(sd, res=16, device=dev)
+    q, mode, enc = vq.quantize_cloud(torch.from_numpy(batch["Xbd"][:1]).to(dev))
+    assert q.shape == (1, 16, 16, 16)
+
+
+def test_res32_configuration_runs(dev):
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.train_vqdif import VQDIFTrainer
+    tr = VQDIFTrainer(W.make_state_dict(W.vqdif_spec(32)), res=32, device=dev)
+    out = tr.training_step(dict(Xbd=G["Xbd"], Xtg=G["Xtg"][:, :256], Ytg=G["Ytg"][:, :256]))
+    assert np.isfinite(float(out["loss"]))
