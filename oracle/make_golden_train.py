@@ -35,7 +35,17 @@ def main():
     model = refimport.build_vqdif(16)
     model.train()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    Xbd, Xtg, Ytg = batch()
+    Xbd, Xtg, Ytg = batch(Nt=4096)
+    # keep 512 query points whose MLP pre-activations are all >= 2e-3 away from a ReLU kink (see sdf_head_margin)
+    with torch.no_grad():
+        tsd = {k: v for k, v in sd.items()}
+        idx = TO.training_losses(tsd, torch.from_numpy(Xbd), torch.from_numpy(Xtg[:, :8]), torch.from_numpy(Ytg[:, :8]), 0.001)["idx"]
+        grid = VO.decoder_grid(tsd, VO.get_code(tsd, idx.view(1, 16, 16, 16)))
+        margin = TO.sdf_head_margin(tsd, grid, torch.from_numpy(Xtg))[0].numpy()
+    keep = np.nonzero(margin > 2e-3)[0][:512]
+    assert len(keep) == 512, len(keep)
+    print("query points kept:", len(keep), "of 4096; min margin", float(margin[keep].min()))
+    Xtg, Ytg = Xtg[:, keep], Ytg[:, keep]
     b = {k: torch.from_numpy(v) for k, v in dict(Xbd=Xbd, Xtg=Xtg, Ytg=Ytg).items()}
     beta = float(model.criterion.beta)
     t0 = time.time()

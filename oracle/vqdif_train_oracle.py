@@ -53,3 +53,22 @@ def loss_and_grads(sd, Xbd, Xtg, Ytg, beta):
     out = training_losses(leaf, Xbd, Xtg, Ytg, beta)
     grads = torch.autograd.grad(out["loss"], [leaf[k] for k in keys], allow_unused=True)
     return out, {k: g for k, g in zip(keys, grads)}
+
+
+def sdf_head_margin(sd, grid, Xtg):
+    """Per query point: the smallest |pre-activation| over every ReLU of the implicit decoder's MLP (dec.py:88-100).
+    Two fp32 implementations agree to ~1e-5 on these values; a point whose margin is below that can take the other
+    branch of a ReLU, which changes ITS whole gradient contribution (1/N of every upstream gradient).  The parity
+    fixture therefore keeps only points with a margin far above the fp32 noise."""
+    with torch.no_grad():
+        p = (Xtg / 2.0).float()
+        c = VO.trilinear_sample(grid, p)
+        net = F.linear(p, sd["decoder.fc_p.weight"], sd["decoder.fc_p.bias"])
+        m = torch.full(net.shape[:2], float("inf"))
+        for i in range(5):
+            net = net + F.linear(c, sd[f"decoder.fc_c.{i}.weight"], sd[f"decoder.fc_c.{i}.bias"])
+            m = torch.minimum(m, net.abs().min(-1)[0])
+            h = F.linear(F.relu(net), sd[f"decoder.blocks.{i}.fc_0.weight"], sd[f"decoder.blocks.{i}.fc_0.bias"])
+            m = torch.minimum(m, h.abs().min(-1)[0])
+            net = net + F.linear(F.relu(h), sd[f"decoder.blocks.{i}.fc_1.weight"], sd[f"decoder.blocks.{i}.fc_1.bias"])
+        return torch.minimum(m, net.abs().min(-1)[0])
