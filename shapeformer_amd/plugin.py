@@ -94,10 +94,35 @@ class VQDIFModel:
             state_dict = load_pl_state_dict(ckpt_path)
         self.hparams = dict(encoder_opt=encoder_opt, decoder_opt=decoder_opt, quantizer_opt=quantizer_opt, vq_beta=vq_beta,
                             optim_opt=optim_opt)
+        self.Xct_as_Xbd = Xct_as_Xbd
         self.core = VQDIF(state_dict, res=res, device=device or _device(), vocab_size=qk["vocab_size"])
 
     def __getattr__(self, name):  # encode / quantize_cloud / decode / decode_index / forward ...
         return getattr(self.core, name)
+
+    # ---- training (vqdif.py:93-137) -----------------------------------------------------------------------------------
+    def make_trainer(self, optim_opt=None, dist=None):
+        """HIP training state for this model: Adam(lr) over all parameters + EMA codebook (train_vqdif.VQDIFTrainer)."""
+        from .train_vqdif import VQDIFTrainer
+        oo = optim_opt or self.hparams.get("optim_opt") or {}
+        self.trainer = VQDIFTrainer(self.core.state_dict_np(), res=self.core.res, device=self.core.dev, lr=oo.get("lr", 1e-4),
+                                    beta=self.hparams.get("vq_beta", 1.0), dist=dist)
+        return self.trainer
+
+    def training_step(self, batch, batch_idx=0):
+        """VQDIF.training_step: batch {Xbd (or Xct when Xct_as_Xbd), Xtg, Ytg} -> loss; the inference weights follow."""
+        if not hasattr(self, "trainer"):
+            self.make_trainer()
+        b = dict(batch, Xbd=batch["Xct"] if self.Xct_as_Xbd else batch["Xbd"])
+        out = self.trainer.training_step(b)
+        self._stale = True
+        return out["loss"]
+
+    def sync_inference_weights(self):
+        """Re-pack the trained parameters into the inference kernels' layouts (call before encode/decode after training)."""
+        if getattr(self, "_stale", False):
+            self.core.load_state_dict(self.trainer.state_dict())
+            self._stale = False
 
     @classmethod
     def load_from_checkpoint(cls, ckpt_path, **kw):

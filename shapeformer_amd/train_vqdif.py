@@ -70,8 +70,9 @@ class VQDIFTrainer:
                 self.kind[k] = ("conv", ks)
             host[k] = v
         self.names = sorted(host)
-        n = sum(v.size for v in host.values())
-        self.flat_p = torch.empty(n, device=self.dev)
+        al = lambda k: (k + 3) // 4 * 4                          # every tensor starts 16-byte aligned (float4 loads in the GEMMs)
+        n = sum(al(v.size) for v in host.values())
+        self.flat_p = torch.zeros(n, device=self.dev)
         self.flat_g = torch.zeros(n, device=self.dev)
         self.flat_m = torch.zeros(n, device=self.dev)
         self.flat_v = torch.zeros(n, device=self.dev)
@@ -82,7 +83,7 @@ class VQDIFTrainer:
             self.flat_p[o:o + v.size] = torch.from_numpy(v.reshape(-1)).to(self.dev)
             self.p[k] = self.flat_p[o:o + v.size].view(v.shape)
             self.g[k] = self.flat_g[o:o + v.size].view(v.shape)
-            o += v.size
+            o += al(v.size)
         self.K = state_dict["quantizer.embedding.weight"].shape[0]
         self.emb = torch.from_numpy(np.asarray(state_dict["quantizer.embedding.weight"], np.float32)).to(self.dev).contiguous()
         self.N = torch.from_numpy(np.asarray(state_dict["quantizer.N"], np.float32)).to(self.dev).contiguous()

@@ -63,9 +63,14 @@ class VQDIF:
         self._ws = {}
 
     # ------------------------------------------------------------------ weights
+    def state_dict_np(self):
+        """The (numpy, reference-layout) state dict the packed device weights were built from."""
+        return self._sd
+
     def load_state_dict(self, sd):
         dev = self.dev
         lib = L.lib()
+        self._sd = {k: np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in sd.items()}
         cat = lambda fmt, n=5: np.ascontiguousarray(np.stack([_np(sd, fmt.format(i)) for i in range(n)]))
         enc = np.empty(lib.sfmi_enc_pack_floats(), np.float32)
         a = [_np(sd, "encoder.fc_pos.weight"), _np(sd, "encoder.fc_pos.bias"), cat("encoder.blocks.{}.fc_0.weight"),

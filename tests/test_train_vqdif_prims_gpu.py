@@ -176,4 +176,4 @@ def test_bce_and_sdf_head_chain(tr):
     xt = x.double().requires_grad_(True)
     lt = F.binary_cross_entropy_with_logits(xt, t.double())
     lt.backward()
-    assert abs(float(rows.double().mean()) - float(lt)) < 1e-6 and rel(dx, xt.grad) < TOL
+    assert abs(float(rows.double().mean()) - float(lt.detach())) < 1e-6 and rel(dx, xt.grad) < TOL
