@@ -69,18 +69,19 @@ int sfmi_sparse2dense_i32(const int* tokens, const int* start, const int* len, c
 
 /* ---- CondTupleGPT: transformer/mingpt.py:46-111 (Block), :256-310 (embeddings, two-stage tuple head),
  *      shapeformer.py:54-123 (sample_indices), representers.py:120-155,188-196,432-442, models/common.py:260-299 ---- */
-/* prefill (M = B*P rows): plain GEMM y[remap(m)] = act(x W^T + bias) + resid */
+/* prefill: rows (b,t), t < P, either as a (B,P) rectangle (rowoff NULL; t >= nval[b] is padding) or PACKED back to back
+ * (rowoff (B+1) exclusive offsets, M = rowoff[B] rows: no work on padding).  Plain GEMM y[remap(m)] = act(x W^T + bias) + resid */
 int sfmi_gemm_f32(const float* x, const float* W, const float* bias, const float* resid, float* y, long long M, int N, int K,
                   int act, long long out_group, long long out_group_stride, void* stream);
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                        const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, int* extra_out,
                        float* resid_out, float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax,
-                       int end0, void* stream);
+                       int end0, const int* rowoff, int M_packed, void* stream);
 int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* bias, const float* Eadd, const int* seq,
                          const int* len, const int* Lc, const int* nval, float* resid_out, float* xn, const float* gamma,
-                         const float* beta, int S, int M, int P, int D, int Lmax, void* stream);
+                         const float* beta, int S, int M, int P, int D, int Lmax, const int* rowoff, int B, void* stream);
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
-                              int Lmax, void* stream);
+                              int Lmax, const int* rowoff, void* stream);
 int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream); /* shapeformer.py:132-140 */
 /* decode step (M = B <= 192 rows; packed x/out/resid must hold ceil(M/64)*64 rows when M > 64) */
 size_t sfmi_skinny16_pack_floats(int N, int K);

@@ -39,14 +39,22 @@ struct RowPrepArgs {
   float* xn;               // (M,D) or null (LayerNorm output)
   const float *gamma, *beta;
   int mode, S, M, D, Lmax, P /*0: decode (t = len[b]-1); >0: prefill rows m=(b,t), t<P*/, end0;
+  const int* rowoff;       // optional (nB+1): PACKED prefill rows - sequence b owns rows rowoff[b] .. rowoff[b+1]-1 (t = m - rowoff[b])
+  int nB;
 };
 
 __global__ __launch_bounds__(256) void rowprep_kernel(RowPrepArgs a) {
   __shared__ float red[8];
   const int m = blockIdx.x, tid = threadIdx.x;
-  const int b = a.P ? m / a.P : m;
-  int t;
-  if (a.P) { t = m - b * a.P; } else { t = a.len ? a.len[b] - 1 : 0; }
+  int b, t;
+  if (a.P && a.rowoff) {   // ragged rows packed back to back: no work on padding positions
+    int lo = 0, hi = a.nB;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.rowoff[mid] <= m) lo = mid; else hi = mid; }
+    b = lo; t = m - a.rowoff[b];
+  } else {
+    b = a.P ? m / a.P : m;
+    if (a.P) { t = m - b * a.P; } else { t = a.len ? a.len[b] - 1 : 0; }
+  }
   const int lc = a.Lc ? a.Lc[b] : 0;
   if (a.P) { int tmax = (a.nval ? a.nval[b] : lc - 1) - 1; if (tmax < 0) tmax = 0; if (t > tmax) t = tmax; }  // padded rows: harmless clamp
   const int nq = a.D / 4;
@@ -614,10 +622,11 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
                                                            float* __restrict__ Vc, const int* __restrict__ nval,
                                                            float* __restrict__ y /*(B*P,D)*/, int P, int D, int Lmax,
-                                                           float scale) {
+                                                           float scale, const int* __restrict__ rowoff /*optional packed rows*/) {
   __shared__ __attribute__((aligned(16))) float Ks[64][64], Vs[64][64];
   const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x;
   const int n = min(P, max(nval[b], 0));  // valid prefill positions of this row
+  const long long base = rowoff ? rowoff[b] : (long long)b * P;
   const int q0 = qb * 64;
   if (q0 >= n) return;
   const int qi = tid >> 2, c16 = tid & 3;
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
   const bool qok = tq < n;
   f32x4 qf[4];
   {
-    const float* qp = qkv + ((long long)b * P + (qok ? tq : q0)) * 3 * D + h * 64 + 16 * c16;
+    const float* qp = qkv + (base + (qok ? tq : q0)) * 3 * D + h * 64 + 16 * c16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) qf[e] = reinterpret_cast<const f32x4*>(qp)[e] * scale;
   }
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
     for (int i = tid; i < 64 * 16; i += 256) {
       const int r = i >> 4, c = i & 15;
       const int tk = min(k0 + r, n - 1);
-      const float* src = qkv + ((long long)b * P + tk) * 3 * D + h * 64 + 4 * c;
+      const float* src = qkv + (base + tk) * 3 * D + h * 64 + 4 * c;
       const f32x4 kv = *reinterpret_cast<const f32x4*>(src + D), vv = *reinterpret_cast<const f32x4*>(src + 2 * D);
       *reinterpret_cast<f32x4*>(&Ks[r][4 * c]) = kv;
       *reinterpret_cast<f32x4*>(&Vs[r][4 * c]) = vv;
@@ -670,7 +679,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
   }
   if (qok) {
     const float inv = 1.0f / lrun;
-    float* yp = y + ((long long)b * P + tq) * D + h * 64 + 16 * c16;
+    float* yp = y + (base + tq) * D + h * 64 + 16 * c16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) reinterpret_cast<f32x4*>(yp)[e] = acc[e] * inv;
   }
@@ -1052,13 +1061,15 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                        const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, int* extra_out,
                        float* resid_out, float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax,
-                       int end0, void* stream) {
+                       int end0, const int* rowoff, int M_packed, void* stream) {
   if (!E0 || !E1 || !Ex || !pos_emb || !cond_pos_emb || !seq || !len || !Lc || D % 4 || D > 4096) return SFMI_EINVAL;
+  if (rowoff && (P <= 0 || M_packed <= 0)) return SFMI_EINVAL;
   RowPrepArgs a = {};
   a.E0 = E0; a.E1 = E1; a.Ex = Ex; a.pos_emb = pos_emb; a.cond_pos_emb = cond_pos_emb; a.seq = seq; a.len = len; a.Lc = Lc;
   a.nval = nval; a.extra = extra; a.extra_out = extra_out;
   a.resid_out = resid_out; a.xn = xn; a.gamma = gamma; a.beta = beta; a.mode = 0; a.M = P ? B * P : B; a.D = D; a.Lmax = Lmax;
-  a.P = P; a.end0 = end0;
+  a.P = P; a.end0 = end0; a.rowoff = rowoff; a.nB = B;
+  if (rowoff) a.M = M_packed;
   hipLaunchKernelGGL(rowprep_kernel, dim3(a.M), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
@@ -1068,11 +1079,12 @@ int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const 
 // (+ tok_embs[0][next pos], mingpt.py:294) ; resid_out = x ; xn = LN(x)
 int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* bias, const float* Eadd, const int* seq,
                          const int* len, const int* Lc, const int* nval, float* resid_out, float* xn, const float* gamma,
-                         const float* beta, int S, int M, int P, int D, int Lmax, void* stream) {
-  if (!resid_in || D % 4 || D > 4096 || (Eadd && (!seq || !len))) return SFMI_EINVAL;
+                         const float* beta, int S, int M, int P, int D, int Lmax, const int* rowoff, int B, void* stream) {
+  if (!resid_in || D % 4 || D > 4096 || (Eadd && (!seq || !len)) || (rowoff && B <= 0)) return SFMI_EINVAL;
   RowPrepArgs a = {};
   a.resid_in = resid_in; a.part = part; a.bias = bias; a.Eadd = Eadd; a.seq = seq; a.len = len; a.Lc = Lc; a.nval = nval;
   a.resid_out = resid_out; a.xn = xn; a.gamma = gamma; a.beta = beta; a.mode = 1; a.S = S; a.M = M; a.D = D; a.Lmax = Lmax; a.P = P;
+  a.rowoff = rowoff; a.nB = B;
   hipLaunchKernelGGL(rowprep_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
@@ -1091,10 +1103,10 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
 
 // causal self-attention over the conditioning prefix (positions 0..Lc[b]-2), also fills the KV caches
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
-                              int Lmax, void* stream) {
+                              int Lmax, const int* rowoff, void* stream) {
   if (!qkv || !Kc || !Vc || !nval || !y || D / H != 64 || P <= 0) return SFMI_EINVAL;
   hipLaunchKernelGGL(attn_prefill_kernel, dim3(B, H, (P + 63) / 64), dim3(256), 0, (hipStream_t)stream, qkv, Kc, Vc, nval, y, P, D,
-                     Lmax, 0.125f);
+                     Lmax, 0.125f, rowoff);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -157,7 +157,8 @@ class CondTupleGPT:
                                              L.ptr(st["Lc"]) if st else None, L.ptr(st.get("nval")) if st else None,
                                              L.ptr(resid_out), L.ptr(xn),
                                              L.ptr(ln[0]) if ln else None, L.ptr(ln[1]) if ln else None, S, M, P, self.D,
-                                             self.Lmax + 1, L.stream_ptr()), "sfmi_gpt_rowprep_f32")
+                                             self.Lmax + 1, L.ptr(st.get("rowoff")) if st else None,
+                                             st["seq"].shape[0] if st else 0, L.stream_ptr()), "sfmi_gpt_rowprep_f32")
 
     def _embed(self, st, B, P, resid, xn, ln):
         L.check(L.lib().sfmi_gpt_embed_f32(L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb),
@@ -165,7 +166,7 @@ class CondTupleGPT:
                                            L.ptr(st.get("nval")), L.ptr(st.get("extra")), L.ptr(st.get("extra_out")),
                                            L.ptr(resid), L.ptr(xn), L.ptr(ln[0]) if ln else None, L.ptr(ln[1]) if ln else None,
                                            B, P, self.D, self.Lmax + 1,
-                                           self.end[0], L.stream_ptr()), "sfmi_gpt_embed_f32")
+                                           self.end[0], L.ptr(st.get("rowoff")), int(st.get("M_packed") or 0), L.stream_ptr()), "sfmi_gpt_embed_f32")
 
     def _gemm(self, x, w, bias, resid, y, M, N, K, act=0, og=0, ogs=0):
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, og, ogs,
@@ -188,7 +189,9 @@ class CondTupleGPT:
         positions (B,P) via .send() (they become seq[:, 1:P+1, 0], the tok_embs[0] add of mingpt.py:309), then yields the
         stage-1 logits — the protocol of CondTupleGPT.sample_next_tuple (mingpt.py:297-310)."""
         D, dev = self.D, self.dev
-        M = B * P
+        rowoff = st.get("rowoff")                 # packed ragged rows (sampling prefill) or the (B,P) rectangle
+        M = int(st["M_packed"]) if rowoff is not None else B * P
+        assert rowoff is None or not want_logits
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         resid, xn, qkv, y, h = f(M, D), f(M, D), f(M, 3 * D), f(M, D), f(M, 4 * D)
         if st.get("nval") is None:
@@ -207,7 +210,7 @@ class CondTupleGPT:
         for li, ly in enumerate(self.layers):
             self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
             L.check(L.lib().sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]), L.ptr(st["nval"]),
-                                                      L.ptr(y), B, P, D, self.H, self.Lmax + 1, L.stream_ptr()), "attn_prefill")
+                                                      L.ptr(y), B, P, D, self.H, self.Lmax + 1, L.ptr(rowoff), L.stream_ptr()), "attn_prefill")
             self._gemm(y, ly.wproj, ly.bproj, resid, resid, M, D, D)
             self._rowprep(resid, None, None, 0, M, None, xn, ly.ln2)
             self._gemm(xn, ly.wfc1, ly.bfc1, None, h, M, 4 * D, D, act=2)
@@ -248,6 +251,7 @@ class CondTupleGPT:
         st["len"] = torch.full((B,), Lq, device=self.dev, dtype=torch.int32)
         st["nval"] = torch.full((B,), Lq, device=self.dev, dtype=torch.int32)
         st["extra"] = None
+        st["rowoff"], st["M_packed"] = None, 0      # teacher-forced rows are a full (B,L) rectangle
         if extra_idx is not None:
             ex = torch.zeros(B, self.Lmax + 1, device=self.dev, dtype=torch.int32)
             ex[:, :Lq] = torch.as_tensor(extra_idx).to(self.dev, torch.int32)[..., 0]
@@ -267,6 +271,7 @@ class CondTupleGPT:
         st["len"] = torch.full((B,), Lq, device=self.dev, dtype=torch.int32)
         st["nval"] = torch.full((B,), Lq, device=self.dev, dtype=torch.int32)
         st["extra"] = None
+        st["rowoff"], st["M_packed"] = None, 0      # teacher-forced rows are a full (B,L) rectangle
         if extra_idx is not None:
             ex = torch.zeros(B, self.Lmax + 1, device=self.dev, dtype=torch.int32)
             ex[:, :Lq] = torch.as_tensor(extra_idx).to(self.dev, torch.int32)[..., 0]
@@ -363,7 +368,11 @@ class CondTupleGPT:
             use_graph = False
         P = Lc_max - 1
         st["nval"], st["extra"] = None, None
-        if P > 0:
+        # ragged condition prefixes are packed back to back: the prefill GEMMs / attention do no work on padding rows
+        nrow = [max(l - 1, 0) for l in Lc_host]
+        st["M_packed"] = sum(nrow)
+        st["rowoff"] = torch.tensor([0] + list(np.cumsum(nrow)), dtype=torch.int32).to(self.dev)
+        if P > 0 and st["M_packed"] > 0:
             self.prefill(st, B, P)
         # embedding of the last condition token (step-0 input) into the fragment-packed residual buffer
         L.check(L.lib().sfmi_gpt_embed_packed_f32(L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb),

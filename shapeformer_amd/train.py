@@ -151,7 +151,7 @@ class GPTTrainer:
             self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
             y = self._f(M, D)
             L.check(lib.sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
-                                                  g.H, g.Lmax + 1, L.stream_ptr()), "attn")
+                                                  g.H, g.Lmax + 1, None, L.stream_ptr()), "attn")
             r1 = self._f(M, D)
             self._gemm(y, ly.wproj, ly.bproj, resid, r1, M, D, D)
             xn2 = self._f(M, D)
