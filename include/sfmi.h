@@ -10,7 +10,8 @@
  *   - all pointers are DEVICE pointers unless the function is marked [host];
  *   - `stream` is a hipStream_t (passed as void*); launches are asynchronous on it, no internal sync;
  *   - returns 0 on success, a negative SFMI_E* code for bad arguments, or a positive hipError_t;
- *   - no global mutable state; re-entrant for distinct streams and buffers;
+ *   - no global mutable state (apart from immutable, once-initialised tables: the rocBLAS function pointers and one
+ *     rocblas_handle per host thread, csrc/blas.hip); re-entrant for distinct streams and buffers;
  *   - layouts: feature grids are channels-last (B,D,H,W,C) f32; token buffers are int32; decode activations of the
  *     transformer are "fragment-packed" [ceil(M/16)][N/16][64][4] (see sfmi_decode_gemm_f32).
  */
@@ -23,6 +24,7 @@ extern "C" {
 
 #define SFMI_OK 0
 #define SFMI_EINVAL (-1)
+#define SFMI_ENOBLAS (-3) /* rocBLAS could not be bound (csrc/blas.hip); callers fall back to the tile kernels */
 
 int sfmi_version(void);
 
@@ -73,6 +75,13 @@ int sfmi_sparse2dense_i32(const int* tokens, const int* start, const int* len, c
  * (rowoff (B+1) exclusive offsets, M = rowoff[B] rows: no work on padding).  Plain GEMM y[remap(m)] = act(x W^T + bias) + resid */
 int sfmi_gemm_f32(const float* x, const float* W, const float* bias, const float* resid, float* y, long long M, int N, int K,
                   int act, long long out_group, long long out_group_stride, void* stream);
+/* plain large GEMMs through rocBLAS, bound lazily with dlopen (csrc/blas.hip): row-major C = alpha op(A) op(B) + beta C;
+ * transX != 0: the stored matrix is the transpose.  sfmi_gemm_blas_f32 == sfmi_gemm_f32 without the row remap. */
+int sfmi_blas_available(void);
+int sfmi_sgemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                   float beta, float* C, int ldc, void* stream);
+int sfmi_gemm_blas_f32(const float* x, const float* W, const float* bias, const float* resid, float* y, int M, int N, int K, int act,
+                       void* stream);
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                        const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, int* extra_out,
                        float* resid_out, float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax,

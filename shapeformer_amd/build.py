@@ -66,7 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if verbose:
                     print(f"[sfmi build] compiled {os.path.basename(s)}", file=sys.stderr)
     if jobs or force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

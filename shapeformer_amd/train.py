@@ -70,8 +70,26 @@ class GPTTrainer:
     def _f(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
 
+    def _blas(self):
+        """Plain M-thousands-row GEMMs of the training step go through rocBLAS when it can be bound (csrc/blas.hip)."""
+        if not hasattr(self, "_has_blas"):
+            self._has_blas = bool(L.lib().sfmi_blas_available())
+        return self._has_blas
+
     def _gemm(self, x, w, bias, resid, y, M, N, K, act=0):
+        if self._blas() and M >= 1024 and N % 4 == 0 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
+            L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
+            return
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, 0, 0, L.stream_ptr()), "gemm")
+
+    def _dx(self, dY, wname, w, M, N, K):
+        """dX (M,K) = dY (M,N) W (N,K): library NN product, or the tile kernel on a cached transposed weight copy."""
+        dx = self._f(M, K)
+        if self._blas() and M >= 1024:
+            L.check(L.lib().sfmi_sgemm_f32(0, 0, M, K, N, 1.0, L.ptr(dY), N, L.ptr(w), K, 0.0, L.ptr(dx), K, L.stream_ptr()), "sgemm dx")
+        else:
+            self._gemm(dY, self._wt(wname, w), None, None, dx, M, K, N)
+        return dx
 
     def _T(self, x, R, C, ld=None, Rpad=None):
         Rpad = Rpad or _ru(R, 16)
@@ -88,6 +106,11 @@ class GPTTrainer:
 
     def _dW(self, dY, X, M, N, K, gname):
         """grad[gname] (N,K) += dY^T (N,M) X (M,K)  via NT GEMM on transposed activations (K-dim = M padded to 16)."""
+        if self._blas() and M >= 1024:      # dY^T X directly (transposed left operand), accumulating when asked to
+            out = self.grad[gname]
+            L.check(L.lib().sfmi_sgemm_f32(1, 0, N, K, M, 1.0, L.ptr(dY), N, L.ptr(X), K, 1.0 if self._acc else 0.0, L.ptr(out), K,
+                                           L.stream_ptr()), "sgemm dW")
+            return
         Mp = _ru(M, 16)
         dYT, XT = self._T(dY, M, N, Rpad=Mp), self._T(X, M, K, Rpad=Mp)
         Np = _ru(N, 1)
@@ -216,21 +239,18 @@ class GPTTrainer:
             # fc2
             self._colsum(dr, M, D, p + "bfc2")
             self._dW(dr, s["h"], M, D, 4 * D, p + "wfc2")
-            dh = self._f(M, 4 * D)
-            self._gemm(dr, self._wt(p + "wfc2", ly.wfc2), None, None, dh, M, 4 * D, D)
+            dh = self._dx(dr, p + "wfc2", ly.wfc2, M, D, 4 * D)
             dhpre = self._f(M, 4 * D)
             L.check(lib.sfmi_gelu_bwd_f32(L.ptr(dh), L.ptr(s["hpre"]), L.ptr(dhpre), M * 4 * D, L.stream_ptr()), "gelu_bwd")
             # fc1
             self._colsum(dhpre, M, 4 * D, p + "bfc1")
             self._dW(dhpre, s["xn2"], M, 4 * D, D, p + "wfc1")
-            dxn2 = self._f(M, D)
-            self._gemm(dhpre, self._wt(p + "wfc1", ly.wfc1), None, None, dxn2, M, D, 4 * D)
+            dxn2 = self._dx(dhpre, p + "wfc1", ly.wfc1, M, 4 * D, D)
             dr1 = self._ln_bwd(dxn2, s["r1"], ly.ln2[0], dr, M, p + "ln2.w", p + "ln2.b")
             # proj
             self._colsum(dr1, M, D, p + "bproj")
             self._dW(dr1, s["y"], M, D, D, p + "wproj")
-            dy = self._f(M, D)
-            self._gemm(dr1, self._wt(p + "wproj", ly.wproj), None, None, dy, M, D, D)
+            dy = self._dx(dr1, p + "wproj", ly.wproj, M, D, D)
             # attention
             dqkv = self._f(M, 3 * D)
             L.check(lib.sfmi_attn_bwd_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(lse), L.ptr(dqkv), B, Lq, D, g.H,
@@ -238,8 +258,7 @@ class GPTTrainer:
             # qkv
             self._colsum(dqkv, M, 3 * D, p + "bqkv")
             self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv")
-            dxn1 = self._f(M, D)
-            self._gemm(dqkv, self._wt(p + "wqkv", ly.wqkv), None, None, dxn1, M, D, 3 * D)
+            dxn1 = self._dx(dqkv, p + "wqkv", ly.wqkv, M, 3 * D, D)
             dr = self._ln_bwd(dxn1, s["x_in"], ly.ln1[0], dr1, M, p + "ln1.w", p + "ln1.b")
             saved[li] = None
             self._ready(f"L{li}")     # this block's 50 MB of gradients are final: all-reduce under the next blocks' backward

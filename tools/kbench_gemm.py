@@ -11,7 +11,8 @@ for M, N, K in ((10048, 3072, 1024), (10048, 1024, 1024), (10048, 4096, 1024), (
     y = torch.empty(M, N, device=dev)
     f1 = lambda: L.check(lib.sfmi_gemm_f32(L.ptr(x), L.ptr(W), L.ptr(b), None, L.ptr(y), M, N, K, 0, 0, 0, L.stream_ptr()), "gemm")
     f2 = lambda: torch.addmm(b, x, W.t(), out=y)
-    f1(); f2(); torch.cuda.synchronize()
-    t1, t2 = ev_time(f1, 10), ev_time(f2, 10)
+    f3 = lambda: L.check(lib.sfmi_gemm_blas_f32(L.ptr(x), L.ptr(W), L.ptr(b), None, L.ptr(y), M, N, K, 0, L.stream_ptr()), "gemm_blas")
+    f1(); f2(); f3(); torch.cuda.synchronize()
+    t1, t2, t3 = ev_time(f1, 10), ev_time(f2, 10), ev_time(f3, 10)
     fl = 2.0 * M * N * K
-    print(f"M={M:6d} N={N:5d} K={K:5d}: sfmi {t1*1e3:8.1f} us {fl/t1/1e9:6.1f} TF | library {t2*1e3:8.1f} us {fl/t2/1e9:6.1f} TF")
+    print(f"M={M:6d} N={N:5d} K={K:5d}: sfmi {t1*1e3:8.1f} us {fl/t1/1e9:6.1f} TF | torch.addmm {t2*1e3:8.1f} us {fl/t2/1e9:6.1f} TF | sfmi_gemm_blas {t3*1e3:8.1f} us {fl/t3/1e9:6.1f} TF")
