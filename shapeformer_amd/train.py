@@ -77,7 +77,7 @@ class GPTTrainer:
         return self._has_blas
 
     def _gemm(self, x, w, bias, resid, y, M, N, K, act=0):
-        if self._blas() and M >= 1024 and N % 4 == 0 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
+        if self._blas() and M >= 256 and N % 4 == 0 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
             L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
             return
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, 0, 0, L.stream_ptr()), "gemm")
@@ -85,7 +85,7 @@ class GPTTrainer:
     def _dx(self, dY, wname, w, M, N, K):
         """dX (M,K) = dY (M,N) W (N,K): library NN product, or the tile kernel on a cached transposed weight copy."""
         dx = self._f(M, K)
-        if self._blas() and M >= 1024:
+        if self._blas() and M >= 256:
             L.check(L.lib().sfmi_sgemm_f32(0, 0, M, K, N, 1.0, L.ptr(dY), N, L.ptr(w), K, 0.0, L.ptr(dx), K, L.stream_ptr()), "sgemm dx")
         else:
             self._gemm(dY, self._wt(wname, w), None, None, dx, M, K, N)
@@ -106,7 +106,7 @@ class GPTTrainer:
 
     def _dW(self, dY, X, M, N, K, gname):
         """grad[gname] (N,K) += dY^T (N,M) X (M,K)  via NT GEMM on transposed activations (K-dim = M padded to 16)."""
-        if self._blas() and M >= 1024:      # dY^T X directly (transposed left operand), accumulating when asked to
+        if self._blas() and M >= 256:      # dY^T X directly (transposed left operand), accumulating when asked to
             out = self.grad[gname]
             L.check(L.lib().sfmi_sgemm_f32(1, 0, N, K, M, 1.0, L.ptr(dY), N, L.ptr(X), K, 1.0 if self._acc else 0.0, L.ptr(out), K,
                                            L.stream_ptr()), "sgemm dW")
