@@ -92,13 +92,13 @@ int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* 
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                               int Lmax, const int* rowoff, void* stream);
 int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream); /* shapeformer.py:132-140 */
-/* decode step (M = B <= 192 rows; packed x/out/resid must hold ceil(M/64)*64 rows when M > 64) */
+/* decode step (M = B <= 256 rows; packed x/out/resid must hold ceil(M/64)*64 rows when M > 96, ceil(M/16)*16 otherwise) */
 size_t sfmi_skinny16_pack_floats(int N, int K);
 int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out); /* [host] (N,K) -> [N/16][K/16][64][4] */
 size_t sfmi_decode_gemm_slab_floats(int M, int N, int S);
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
                          int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, void* stream);
-/* same contract, always the two-n-tiles-per-wave kernel (sfmi_decode_gemm_f32 routes M > 64 here) */
+/* same contract, always the two-n-tiles-per-wave kernel (sfmi_decode_gemm_f32 routes M > 96 here) */
 int sfmi_decode_gemm_wide_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
                               int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, void* stream);
 int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,

@@ -5,7 +5,7 @@
 // (valid by SURVEY Appendix A11) made of a handful of weight-streaming kernels that read all
 // per-row state (lengths, tokens) from device memory, so one captured hipGraph replays every step:
 //
-//   dgemm     LayerNorm-fused weight-streaming GEMM for M <= 64 rows on f32 MFMA 16x16x4 (mingpt.py:103-111):
+//   dgemm     LayerNorm-fused weight-streaming GEMM for M <= 96 rows on f32 MFMA 16x16x4 (mingpt.py:103-111):
 //             weights AND activations in MFMA-fragment order (every wave access = 1 KiB contiguous), final
 //             outputs (bias / GELU / residual in the epilogue), optional in-kernel deterministic split-K
 //   attn      one workgroup per (row, head): KV append, softmax(QK^T/8)V over the row's own cached length
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void rowprep_kernel(RowPrepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode GEMM with fused LayerNorm / bias / GELU / residual  (M <= 64 rows, 16x16x4 f32 MFMA)
+// decode GEMM with fused LayerNorm / bias / GELU / residual  (M <= 96 rows, 16x16x4 f32 MFMA)
 //
 //   plain : out[m][n] = act( sum_k x[m][k] W[n][k] + c2[n] ) (+ resid[m][n])
 //   LN    : LayerNorm commutes with the GEMM:  LN(x) W^T = rstd[m] (x W'^T - mean[m] c1[n]) + c2[n]
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// wide decode GEMM: 64 < M <= 256 rows in ONE launch (MT = 8, 12 or 16 row tiles), same math / layouts as dgemm_kernel.
+// wide decode GEMM: 96 < M <= 256 rows in ONE launch (MT = 8, 12 or 16 row tiles), same math / layouts as dgemm_kernel.
 //   - each wave owns TWO adjacent 16-column n-tiles over all MT row tiles, so an activation fragment feeds 8 MFMAs
 //     instead of 4 (per-CU L1 traffic (MT+2)/(2 MT) KB per 128 MFMA-clk per wave, 18.7 B/clk at MT = 12 against
 //     40 B/clk for the 64-row kernel and ~25 B/clk the L1 sustains), and the weights are streamed ONCE for all rows;
@@ -1034,8 +1034,8 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   if (out_packed && N % 16) return SFMI_EINVAL;
   if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
   const int kslice = K / S;
-  if (M > 64) return sfmi_decode_gemm_wide_f32(x, Wp16, c1, c2, resid, out, M, N, K, ldo, ln, act, out_packed, S, slab, cnt, stream);
-  const int NWv = kslice >= 2048 ? 16 : 8;
+  if (M > 96) return sfmi_decode_gemm_wide_f32(x, Wp16, c1, c2, resid, out, M, N, K, ldo, ln, act, out_packed, S, slab, cnt, stream);
+  const int NWv = (kslice >= 2048 && M <= 64) ? 16 : 8;
   if (kslice % (16 * NWv)) return SFMI_EINVAL;
   DGemmArgs a;
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
@@ -1044,12 +1044,14 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   dim3 grid((N + 15) / 16, S);
   const int MT = (M + 15) / 16;
   const int steps = kslice / NWv / 16;
-  int un = MT == 1 ? 8 : (MT == 2 ? 4 : 2);   // UN weight + UN*MT activation float4 loads in flight per wave
+  int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 4 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave
   while (un > 1 && steps % un) un >>= 1;
 #define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
 #define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
   if (NWv == 16) { if (MT == 1) DGU(1, 16); else if (MT == 2) DGU(2, 16); else if (MT == 3) DGU(3, 16); else DGU(4, 16); }
-  else           { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
+  else if (MT <= 4) { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
+  else if (MT == 5) DG(5, 8, 1);   // 65..96 rows: still the co-residency-friendly 8-wave kernel (<= 128 VGPRs)
+  else DG(6, 8, 1);
 #undef DGU
 #undef DG
   SFMI_CHECK_LAUNCH();

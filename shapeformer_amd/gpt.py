@@ -128,7 +128,7 @@ class CondTupleGPT:
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off); the wide GEMM (B > 64) works on
         # groups of four row tiles
-        Bp = (B + 15) // 16 * 16 if B <= 64 else (B + 63) // 64 * 64
+        Bp = (B + 15) // 16 * 16 if B <= 96 else (B + 63) // 64 * 64
         st = dict(key=key,
                   seq=torch.zeros(B, self.Lmax + 1, 2, device=dev, dtype=torch.int32),
                   len=torch.zeros(B, device=dev, dtype=torch.int32), Lc=torch.zeros(B, device=dev, dtype=torch.int32),
@@ -317,7 +317,7 @@ class CondTupleGPT:
         lib = L.lib()
         r = st["resid"]
         # in-kernel split-K per GEMM: 64-row kernel (B <= 64) / wide kernel (one launch for up to 256 rows)
-        Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if B > 64 else (1, self.S_PROJ if B <= 16 else 4, 1, self.S_FC2, 1)
+        Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if B > 96 else (1, self.S_PROJ if B <= 16 else 4, 1, self.S_FC2, 1)
         for li, ly in enumerate(self.layers):
             self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
             L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),

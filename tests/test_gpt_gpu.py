@@ -200,7 +200,8 @@ def test_sample_next_tuple_generator_protocol(dev):
     assert torch.equal(l1, w1)
 
 
-@pytest.mark.parametrize("reps", [24, 46, 70])   # 72 / 138 / 210 rows -> 8 / 12 / 16 row tiles of the wide decode GEMM
+# 72 / 90 rows: 5 / 6 row tiles of the 8-wave kernel; 105 / 138 / 210 rows: 8 / 12 / 16 row tiles of the wide decode GEMM
+@pytest.mark.parametrize("reps", [24, 30, 35, 46, 70])
 def test_wide_single_chain_decode_matches_64_row_kernels(dev, reps):
     """One hipGraph chain of more than 64 rows (csrc/gpt.hip dgemm_wide_kernel: one GEMM launch for all rows, in-kernel
     split-K) against the 64-row kernels on the same rows: teacher-forced step logits within 2e-4, greedy picks equal."""
