@@ -221,12 +221,16 @@ def main():
     B = a.batch
     # synthetic partial clouds; keep only shapes whose condition length leaves room for ALL ar_steps inside the
     # 812-token block (the unit of work is exactly 512 sampled tuples), decided before the timed region
-    cand = torch.from_numpy(synthetic.make_batch(314 + rank * 4 * B, B + max(8, B // 8), n_partial=a.points)["Xct"]).to(dev)
-    lcs = torch.cat([pipe.encode_cloud(cand[i:i + 64])["Lc"].clone() for i in range(0, cand.shape[0], 64)])
-    keep = torch.nonzero(lcs <= gpt.Lmax - a.ar_steps).flatten()[:B]
-    assert keep.numel() == B, "not enough synthetic shapes with a short enough condition"
-    Xct = cand[keep].contiguous()
-    del cand
+    kept, seed0 = [], 314 + rank * 16 * B
+    while sum(k.shape[0] for k in kept) < B:          # any rank, any seed: keep drawing until B shapes qualify
+        n = max(16, B // 4)
+        cand = torch.from_numpy(synthetic.make_batch(seed0, n, n_partial=a.points)["Xct"]).to(dev)
+        seed0 += n
+        lcs = torch.cat([pipe.encode_cloud(cand[i:i + 64])["Lc"].clone() for i in range(0, n, 64)])
+        kept.append(cand[torch.nonzero(lcs <= gpt.Lmax - a.ar_steps).flatten()])
+        assert seed0 < 314 + (rank + 1) * 16 * B, "synthetic generator yields too few shapes with a short enough condition"
+    Xct = torch.cat(kept)[:B].contiguous()
+    del kept, cand
 
     def step(i):
         return pipe.complete(Xct, max_steps=a.ar_steps, decode_res=a.decode_res, seed=i, stop_early=False, sigmoid=True, n_micro=a.micro)
