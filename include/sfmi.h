@@ -117,6 +117,10 @@ int sfmi_set_len_i32(int* len, const int* src, int B, int delta, void* stream);
  *      backward of mingpt.py:46-111; GEMM-shaped gradients reuse sfmi_gemm_f32 on transposed operands ------------------- */
 int sfmi_transpose_f32(const float* in, float* out, int R, int C, int ldin, int Rpad, void* stream);
 int sfmi_colsum_f32(const float* x, float* out, int M, int N, int ld, int accumulate, void* stream);          /* bias gradients */
+int sfmi_colsum_slices(int M, int N);
+/* two-stage form for tall inputs; scratch: sfmi_colsum_slices(M,N)*N floats */
+int sfmi_colsum_ws_f32(const float* x, float* out, int M, int N, int ld, int accumulate, float* scratch, void* stream);
+size_t sfmi_layernorm_bwd_scratch_floats(int M, int D);                                                        /* size of `stats` below */
 int sfmi_gelu_f32(const float* x, float* y, long long n, void* stream);                                       /* mingpt.py:103 */
 int sfmi_gelu_bwd_f32(const float* dy, const float* x, float* dx, long long n, void* stream);
 int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* dgamma,

@@ -91,6 +91,9 @@ PROTOTYPES = {
     # training step (csrc/train.hip)
     "sfmi_transpose_f32": (i32, [c_ptr, c_ptr, i32, i32, i32, i32, c_ptr]),
     "sfmi_colsum_f32": (i32, [c_ptr, c_ptr, i32, i32, i32, i32, c_ptr]),
+    "sfmi_colsum_slices": (i32, [i32, i32]),
+    "sfmi_colsum_ws_f32": (i32, [c_ptr, c_ptr, i32, i32, i32, i32, c_ptr, c_ptr]),
+    "sfmi_layernorm_bwd_scratch_floats": (sz, [i32, i32]),
     "sfmi_gelu_f32": (i32, [c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_gelu_bwd_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_layernorm_bwd_f32": (i32, [c_ptr] * 8 + [i32, i32, c_ptr]),

@@ -43,6 +43,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// two-stage, fixed-order column sum for tall inputs: block (cb, rs) sums the rows of slice rs for 64 columns ->
+// part[rs][n]; colsum_finish adds the RS partials in slice order (deterministic).  Grid (ceil(N/64), RS).
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int N, int ld,
+                                                          int rows_per) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+  float s = 0.f;
+  if (n < N)
+    for (int m = m0 + rl; m < m1; m += 4) s += x[(long long)m * ld + n];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && n < N)
+    part[(long long)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int RS, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float t = 0.f;
+  for (int r = 0; r < RS; ++r) t += part[(long long)r * N + n];
+  out[n] = accumulate ? out[n] + t : t;
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
@@ -116,6 +139,37 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
     dgamma[c] += (rg[0][threadIdx.x] + rg[1][threadIdx.x]) + (rg[2][threadIdx.x] + rg[3][threadIdx.x]);
     dbeta[c] += (rb[0][threadIdx.x] + rb[1][threadIdx.x]) + (rb[2][threadIdx.x] + rb[3][threadIdx.x]);
   }
+}
+
+// the same parameter sums in two stages for tall inputs (grid (ceil(D/64), RS)): part[rs][0][c] = dgamma, part[rs][1][c] = dbeta
+__global__ __launch_bounds__(256) void ln_bwd_params_part_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ stats, float* __restrict__ part, int M, int D,
+                                                                 int rows_per) {
+  __shared__ float rg[4][64], rb[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+  float g = 0.f, b = 0.f;
+  if (c < D)
+    for (int m = m0 + rl; m < m1; m += 4) {
+      const float d = dy[(long long)m * D + c];
+      g += d * (x[(long long)m * D + c] - stats[2 * m]) * stats[2 * m + 1];
+      b += d;
+    }
+  rg[rl][threadIdx.x & 63] = g; rb[rl][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    float* o = part + (long long)blockIdx.y * 2 * D;
+    o[c] = (rg[0][threadIdx.x] + rg[1][threadIdx.x]) + (rg[2][threadIdx.x] + rg[3][threadIdx.x]);
+    o[D + c] = (rb[0][threadIdx.x] + rb[1][threadIdx.x]) + (rb[2][threadIdx.x] + rb[3][threadIdx.x]);
+  }
+}
+__global__ void ln_bwd_params_finish_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, int D,
+                                            int RS) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float g = 0.f, b = 0.f;
+  for (int r = 0; r < RS; ++r) { g += part[(long long)r * 2 * D + c]; b += part[(long long)r * 2 * D + D + c]; }
+  dgamma[c] += g; dbeta[c] += b;
 }
 
 // softmax cross-entropy: loss_row[m] = lse - logit[target] ; dlogits = (softmax - onehot) * scale for rows with
@@ -368,6 +422,23 @@ int sfmi_colsum_f32(const float* x, float* out, int M, int N, int ld, int accumu
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
+// row slices used by the two-stage column reductions: enough (column block, slice) pairs to fill the chip
+int sfmi_colsum_slices(int M, int N) {
+  const int cb = (N + 63) / 64;
+  int rs = (2048 + cb - 1) / cb;
+  if (rs > M / 16) rs = M / 16;
+  return rs < 1 ? 1 : rs;
+}
+// same result contract as sfmi_colsum_f32 (fixed summation order), with scratch of sfmi_colsum_slices(M,N)*N floats
+int sfmi_colsum_ws_f32(const float* x, float* out, int M, int N, int ld, int accumulate, float* scratch, void* stream) {
+  if (!x || !out || !scratch || M <= 0 || N <= 0) return SFMI_EINVAL;
+  const int RS = sfmi_colsum_slices(M, N), rows_per = (M + RS - 1) / RS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, RS), dim3(256), 0, st, x, scratch, M, N, ld, rows_per);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, out, N, RS, accumulate);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
 int sfmi_gelu_f32(const float* x, float* y, long long n, void* stream) {  // nn.GELU (mingpt.py:103)
   if (!x || !y || n <= 0) return SFMI_EINVAL;
   hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
@@ -380,13 +451,20 @@ int sfmi_gelu_bwd_f32(const float* dy, const float* x, float* dx, long long n, v
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
-// LayerNorm backward: dx = dLN/dx (+ dres) ; dgamma/dbeta ACCUMULATE.  stats: M*2 floats of scratch.
+// LayerNorm backward: dx = dLN/dx (+ dres) ; dgamma/dbeta ACCUMULATE.
+// stats: scratch of sfmi_layernorm_bwd_scratch_floats(M, D) floats (row statistics + two-stage parameter partials).
+size_t sfmi_layernorm_bwd_scratch_floats(int M, int D) { return (size_t)2 * M + (size_t)2 * D * sfmi_colsum_slices(M, D); }
 int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* dgamma,
                            float* dbeta, float* stats, int M, int D, void* stream) {
   if (!dy || !x || !gamma || !dx || !stats || M <= 0 || D <= 0) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3(M), dim3(256), 0, st, dy, x, gamma, dres, dx, stats, D);
-  if (dgamma && dbeta) hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((D + 63) / 64), dim3(256), 0, st, dy, x, stats, dgamma, dbeta, M, D);
+  if (dgamma && dbeta) {
+    const int RS = sfmi_colsum_slices(M, D), rows_per = (M + RS - 1) / RS;
+    float* part = stats + (size_t)2 * M;
+    hipLaunchKernelGGL(ln_bwd_params_part_kernel, dim3((D + 63) / 64, RS), dim3(256), 0, st, dy, x, stats, part, M, D, rows_per);
+    hipLaunchKernelGGL(ln_bwd_params_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, dgamma, dbeta, D, RS);
+  }
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

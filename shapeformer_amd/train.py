@@ -119,11 +119,16 @@ class GPTTrainer:
         self._gemm(dYT, XT, None, out if self._acc else None, out, N, K, Mp)
 
     def _colsum(self, x, M, N, gname):
-        L.check(L.lib().sfmi_colsum_f32(L.ptr(x), L.ptr(self.grad[gname]), M, N, N, int(self._acc), L.stream_ptr()), "colsum")
+        lib = L.lib()
+        if M >= 256:      # tall: two-stage reduction over (column block, row slice) pairs, fixed order
+            ws = self._f(lib.sfmi_colsum_slices(M, N) * N)
+            L.check(lib.sfmi_colsum_ws_f32(L.ptr(x), L.ptr(self.grad[gname]), M, N, N, int(self._acc), L.ptr(ws), L.stream_ptr()), "colsum_ws")
+        else:
+            L.check(lib.sfmi_colsum_f32(L.ptr(x), L.ptr(self.grad[gname]), M, N, N, int(self._acc), L.stream_ptr()), "colsum")
 
     def _ln_bwd(self, dy, x, gamma, dres, M, gw, gb):
         dx = self._f(M, self.D)
-        stats = self._f(M, 2)
+        stats = self._f(L.lib().sfmi_layernorm_bwd_scratch_floats(M, self.D))
         L.check(L.lib().sfmi_layernorm_bwd_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(self.grad[gw]),
                                                L.ptr(self.grad[gb]), L.ptr(stats), M, self.D, L.stream_ptr()), "ln_bwd")
         return dx

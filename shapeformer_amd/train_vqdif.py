@@ -114,7 +114,11 @@ class VQDIFTrainer:
         return dx
 
     def _colsum_into(self, x, M, N, gname):
-        _ck(self.lib.sfmi_colsum_f32(L.ptr(x), L.ptr(self.g[gname]), M, N, N, 0, L.stream_ptr()), "colsum")
+        if M >= 256:
+            ws = self._f(self.lib.sfmi_colsum_slices(M, N) * N)
+            _ck(self.lib.sfmi_colsum_ws_f32(L.ptr(x), L.ptr(self.g[gname]), M, N, N, 0, L.ptr(ws), L.stream_ptr()), "colsum_ws")
+        else:
+            _ck(self.lib.sfmi_colsum_f32(L.ptr(x), L.ptr(self.g[gname]), M, N, N, 0, L.stream_ptr()), "colsum")
 
     def _wgrad_into(self, dy, x, gname, B, Di, Hi, Wi, Cin, Cout, KS, stride, pad, ldy=None, ldx=None, rows=None):
         """dW[tap][co][ci] of a channels-last conv (KS == 1: a Linear over `Wi` rows) -> self.g[gname] (first Cin cols)."""
