@@ -89,7 +89,15 @@ class CondTupleGPT:
                 ly.stage = s
                 self.layers.append(ly)
         self.head_ln = [(g(f"heads.{s}.0.weight"), g(f"heads.{s}.0.bias")) for s in range(2)]
-        self.head_w = [g(f"heads.{s}.1.weight") for s in range(2)]
+        # head weights live in their GEMM-padded (Vpad, D) buffers; head_w are views of the first V rows, so the optimizer's
+        # in-place updates reach the padded copies the teacher-forced forward multiplies with
+        self.head_w_pad = []
+        for s in range(2):
+            w = g(f"heads.{s}.1.weight")
+            wp = torch.zeros(self.Vpad, self.D, device=dev)
+            wp[:self.V] = w
+            self.head_w_pad.append(wp)
+        self.head_w = [wp[:self.V] for wp in self.head_w_pad]
         self.zero_bqkv = torch.zeros(3 * self.D, device=dev)
         self.refresh_decode_weights()
 
@@ -112,8 +120,12 @@ class CondTupleGPT:
             ly.pfc1, ly.c1fc1, ly.c2fc1 = fold(ly.wfc1, ly.bfc1, ly.ln2)
             ly.pproj, ly.pfc2 = pack_skinny16(ly.wproj), pack_skinny16(ly.wfc2)
         self.head_f = [fold(self.head_w[s], None, self.head_ln[s]) for s in range(2)]
-        self.head_w_pad = [torch.cat([w, w.new_zeros(self.Vpad - self.V, self.D)], 0).contiguous() for w in self.head_w]
         self._graphs = {}
+        self._decode_stale = False
+
+    def mark_decode_weights_stale(self):
+        """The raw parameters changed (optimizer step): re-fold / re-pack lazily, at the next decode use."""
+        self._decode_stale = True
 
     # ------------------------------------------------------------------ state
     def _alloc(self, B, max_steps, slot=0):
@@ -347,6 +359,8 @@ class CondTupleGPT:
         B = c_tokens.shape[0]
         if B > 256:
             raise L.SfmiError("decode kernels support up to 256 rows per (micro-)batch")
+        if getattr(self, "_decode_stale", False):
+            self.refresh_decode_weights()
         Lc_host = Lc.cpu().tolist()
         Lc_max = max(Lc_host)
         steps = min(max_steps, self.Lmax - Lc_max)   # never exceed block_size (stop, don't crop)

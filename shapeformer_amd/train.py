@@ -300,7 +300,7 @@ class GPTTrainer:
                                            self.wd if decay else 0.0, self.step_count, L.stream_ptr()), "adamw")
             o += n
         self._wT.clear()                 # transposed copies are stale now
-        self.g.refresh_decode_weights()  # LN-folded / fragment-packed decode weights follow the raw weights
+        self.g.mark_decode_weights_stale()  # LN-folded / fragment-packed decode weights are rebuilt at the next decode use
 
     @torch.no_grad()
     def training_step(self, c_indices, z_indices):
