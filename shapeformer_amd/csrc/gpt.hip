@@ -686,6 +686,120 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// causal self-attention over a prefix on the MATRIX cores (prefill of the condition, teacher-forced forward, training
+// forward; mingpt.py:73-91), same contract as attn_prefill_kernel: grid (B, H, ceil(P/64)), 4 waves, wave w owns query
+// rows q0+16w .. +15 and walks the key blocks 0 .. q0 (64 keys each, staged once per workgroup in LDS).
+//   S (16 x 64)  = Q K^T   : 4 key tiles x 16 k-steps of v_mfma_f32_16x16x4_f32, Q fragments live in 16 registers
+//   online softmax on the C/D layout (row 4(l>>4)+j lives in register j of lanes with the same l>>4: 16-lane reductions)
+//   O (16 x 64) += P V     : P goes through a per-wave LDS tile to become an A operand; 4 d tiles x 16 k-steps
+// LDS row strides 68 (K, P: 16 rows x 4 k-columns per operand read hit 64 distinct banks) and 80 (V: 4 rows x 16 columns).
+// ------------------------------------------------------------------------------------------------
+constexpr int AP_KS = 68, AP_VS = 80;
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
+                                                                float* __restrict__ Vc, const int* __restrict__ nval,
+                                                                float* __restrict__ y, int P, int D, int Lmax, float scale,
+                                                                const int* __restrict__ rowoff) {
+  __shared__ __attribute__((aligned(16))) float Ks[64 * AP_KS], Vs[64 * AP_VS], Ps[4][16 * AP_KS];
+  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(P, max(nval[b], 0));
+  const long long base = rowoff ? rowoff[b] : (long long)b * P;
+  const int q0 = qb * 64;
+  if (q0 >= n) return;
+  const int lr = lane & 15, lq = lane >> 4;
+  // Q fragments (A operand: row lr, k = 4 kk + lq), pre-scaled
+  float qf[16];
+  {
+    const int tq = min(q0 + 16 * wave + lr, n - 1);
+    const float* qp = qkv + (base + tq) * 3 * D + h * 64 + lq;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) qf[kk] = qp[4 * kk] * scale;
+  }
+  float mrun[4], lrun[4];
+  f32x4 o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; o[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int kend = min(n, q0 + 64);
+  float* Pw = Ps[wave];
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      const int tk = min(k0 + r, n - 1);
+      const float* src = qkv + (base + tk) * 3 * D + h * 64 + 4 * c;
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(src + D), vv = *reinterpret_cast<const f32x4*>(src + 2 * D);
+      *reinterpret_cast<f32x4*>(&Ks[r * AP_KS + 4 * c]) = kv;
+      *reinterpret_cast<f32x4*>(&Vs[r * AP_VS + 4 * c]) = vv;
+      if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
+        const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * 64 + 4 * c;  // (B,H,Lmax,64)
+        *reinterpret_cast<f32x4*>(Kc + co) = kv;
+        *reinterpret_cast<f32x4*>(Vc + co) = vv;
+      }
+    }
+    __syncthreads();
+    // S = Q K^T
+    f32x4 sacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* kp = &Ks[(16 * t + lr) * AP_KS + lq];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kk], kp[4 * kk], sacc[t], 0, 0, 0);
+    }
+    // causal / length mask, online softmax per row (row of register j: q0 + 16 wave + 4 lq + j)
+    float corr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qrow = q0 + 16 * wave + 4 * lq + j;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int key = k0 + 16 * t + lr;
+        if (key > qrow || key >= n) sacc[t][j] = -INFINITY;
+        mx = fmaxf(mx, sacc[t][j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+      const float mnew = fmaxf(mrun[j], mx);
+      const float ms = mnew == -INFINITY ? 0.f : mnew;        // fully masked so far: keep everything at zero
+      corr[j] = __expf(mrun[j] - ms);
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float p = __expf(sacc[t][j] - ms);
+        ps += p;
+        Pw[(4 * lq + j) * AP_KS + 16 * t + lr] = p;
+      }
+      ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64); ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
+      lrun[j] = lrun[j] * corr[j] + ps;
+      mrun[j] = mnew;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] *= corr[j];
+    __builtin_amdgcn_wave_barrier();   // P tile written and read by this wave only; LDS ops of a wave execute in order
+    // O += P V
+    const float* pp = &Pw[lr * AP_KS + lq];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float pa = pp[4 * kk];
+      const float* vp = &Vs[(4 * kk + lq) * AP_VS + lr];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vp[16 * dt], o[dt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tq = q0 + 16 * wave + 4 * lq + j;
+    if (tq >= n) continue;
+    const float inv = 1.0f / lrun[j];
+    float* yp = y + (base + tq) * D + h * 64 + lr;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) yp[16 * dt] = o[dt][j] * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused sampler: one workgroup per row
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned fkey_u(float f) {
@@ -1107,8 +1221,8 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                               int Lmax, const int* rowoff, void* stream) {
   if (!qkv || !Kc || !Vc || !nval || !y || D / H != 64 || P <= 0) return SFMI_EINVAL;
-  hipLaunchKernelGGL(attn_prefill_kernel, dim3(B, H, (P + 63) / 64), dim3(256), 0, (hipStream_t)stream, qkv, Kc, Vc, nval, y, P, D,
-                     Lmax, 0.125f, rowoff);
+  hipLaunchKernelGGL(attn_prefill_mfma_kernel, dim3(B, H, (P + 63) / 64), dim3(256), 0, (hipStream_t)stream, qkv, Kc, Vc, nval, y, P,
+                     D, Lmax, 0.125f, rowoff);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
