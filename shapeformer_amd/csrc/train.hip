@@ -172,6 +172,227 @@ __global__ void ln_bwd_params_finish_kernel(const float* __restrict__ part, floa
   dgamma[c] += g; dbeta[c] += b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention backward on the matrix cores (16x16x4 f32 MFMA), same maths and I/O as the VALU kernels above.
+// Shared conventions (csrc/gpt.hip attn_prefill_mfma_kernel): 4 waves, wave w owns 16 rows of the block; an A operand is
+// (row = lane & 15, k = 4 kk + (lane >> 4)), a B operand (k = 4 kk + (lane >> 4), col = lane & 15), C/D register j holds
+// row 4 (lane >> 4) + j, column lane & 15.  LDS tiles are 64 rows x stride 68: "row-major" operand reads (16 rows x 4
+// k-columns) are conflict-free, "k-major" reads (4 rows x 16 columns) are ~2-way.
+//   stats : lse[row] = logsumexp_k(scale q.k) (64 MFMAs per 16x64 tile), delta[row] = sum_d dO O
+//   dq    : per query block:  S = Q K^T, dP = dO V^T, dS = exp(S - lse) (dP - delta), dQ += dS K          (192 MFMAs / tile)
+//   dkv   : per key block:    S^T = K Q^T, dP^T = V dO^T, P^T, dS^T; dV += P^T dO, dK += dS^T Q           (256 MFMAs / tile)
+// ------------------------------------------------------------------------------------------------
+constexpr int AB_S = 68;
+#define AB_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+
+// stage rows [r0, r0+64) of one (b, h) 64-wide slice of `src` (row stride ld floats) into a stride-68 LDS tile
+__device__ __forceinline__ void ab_stage(float* __restrict__ dst, const float* __restrict__ src, long long row_base, int r0, int L, int ld,
+                                         int tid) {
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int r = i >> 4, c = i & 15;
+    const int t = min(r0 + r, L - 1);
+    *reinterpret_cast<f32x4*>(&dst[r * AB_S + 4 * c]) = *reinterpret_cast<const f32x4*>(src + (row_base + t) * ld + 4 * c);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_stats_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ y,
+                                                              const float* __restrict__ dy, float* __restrict__ lse,
+                                                              float* __restrict__ delta, int L, int D, float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[64 * AB_S];
+  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4, q0 = qb * 64;
+  const long long rb = (long long)b * L;
+  const int trow = min(q0 + 16 * wave + lr, L - 1);
+  float qf[16], dl = 0.f;
+  {
+    const float* qp = qkv + (rb + trow) * 3 * D + h * 64 + lq;
+    const float* yp = y + (rb + trow) * D + h * 64 + lq;
+    const float* dp = dy + (rb + trow) * D + h * 64 + lq;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { qf[kk] = qp[4 * kk] * scale; dl += yp[4 * kk] * dp[4 * kk]; }
+  }
+  dl += __shfl_xor(dl, 16, 64); dl += __shfl_xor(dl, 32, 64);      // all four lane groups now hold delta of row lr
+  float mrun[4], lrun[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
+  const int kend = min(L, q0 + 64);
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    ab_stage(Ks, qkv + D + h * 64, rb, k0, L, 3 * D, tid);
+    __syncthreads();
+    f32x4 sacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* kp = &Ks[(16 * t + lr) * AB_S + lq];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) sacc[t] = AB_MFMA(qf[kk], kp[4 * kk], sacc[t]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qrow = q0 + 16 * wave + 4 * lq + j;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int key = k0 + 16 * t + lr;
+        if (key > qrow || key >= L) sacc[t][j] = -INFINITY;
+        mx = fmaxf(mx, sacc[t][j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+      const float mnew = fmaxf(mrun[j], mx), ms = mnew == -INFINITY ? 0.f : mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ps += __expf(sacc[t][j] - ms);
+      ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64); ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
+      lrun[j] = lrun[j] * __expf(mrun[j] - ms) + ps;
+      mrun[j] = mnew;
+    }
+  }
+  const long long sb = ((long long)b * H + h) * L;
+  if (lr == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tq = q0 + 16 * wave + 4 * lq + j;
+      if (tq < L) lse[sb + tq] = mrun[j] + __logf(lrun[j]);
+    }
+  }
+  if (lq == 0 && q0 + 16 * wave + lr < L) delta[sb + q0 + 16 * wave + lr] = dl;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               float* __restrict__ dqkv, int L, int D, float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[64 * AB_S], Vs[64 * AB_S], Ts[4][16 * AB_S];
+  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4, q0 = qb * 64;
+  const long long rb = (long long)b * L, sb = ((long long)b * H + h) * L;
+  const int trow = min(q0 + 16 * wave + lr, L - 1);
+  float qf[16], dof[16];
+  {
+    const float* qp = qkv + (rb + trow) * 3 * D + h * 64 + lq;
+    const float* dp = dy + (rb + trow) * D + h * 64 + lq;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { qf[kk] = qp[4 * kk] * scale; dof[kk] = dp[4 * kk]; }
+  }
+  float ls[4], dl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tq = min(q0 + 16 * wave + 4 * lq + j, L - 1);
+    ls[j] = lse[sb + tq]; dl[j] = delta[sb + tq];
+  }
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float* Tw = Ts[wave];
+  const int kend = min(L, q0 + 64);
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    ab_stage(Ks, qkv + D + h * 64, rb, k0, L, 3 * D, tid);
+    ab_stage(Vs, qkv + 2 * D + h * 64, rb, k0, L, 3 * D, tid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+      const float* kp = &Ks[(16 * t + lr) * AB_S + lq];
+      const float* vp = &Vs[(16 * t + lr) * AB_S + lq];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) { sa = AB_MFMA(qf[kk], kp[4 * kk], sa); pa = AB_MFMA(dof[kk], vp[4 * kk], pa); }
+      const int key = k0 + 16 * t + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int qrow = q0 + 16 * wave + 4 * lq + j;
+        const float ds = (key > qrow || key >= L) ? 0.f : __expf(sa[j] - ls[j]) * (pa[j] - dl[j]);
+        Tw[(4 * lq + j) * AB_S + 16 * t + lr] = ds;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* tp = &Tw[lr * AB_S + lq];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float a = tp[4 * kk];
+      const float* kb = &Ks[(4 * kk + lq) * AB_S + lr];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = AB_MFMA(a, kb[16 * dt], dq[dt]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tq = q0 + 16 * wave + 4 * lq + j;
+    if (tq >= L) continue;
+    float* o = dqkv + (rb + tq) * 3 * D + h * 64 + lr;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[16 * dt] = dq[dt][j] * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                float* __restrict__ dqkv, int L, int D, float scale) {
+  __shared__ __attribute__((aligned(16))) float Qs[64 * AB_S], Os[64 * AB_S], Pt[4][16 * AB_S], St[4][16 * AB_S];
+  const int b = blockIdx.x, h = blockIdx.y, kb_ = blockIdx.z, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4, k0 = kb_ * 64;
+  const long long rb = (long long)b * L, sb = ((long long)b * H + h) * L;
+  const int krow = min(k0 + 16 * wave + lr, L - 1);
+  float kf[16], vf[16];
+  {
+    const float* kp = qkv + (rb + krow) * 3 * D + D + h * 64 + lq;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { kf[kk] = kp[4 * kk] * scale; vf[kk] = kp[D + 4 * kk]; }
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
+  float* Pw = Pt[wave];
+  float* Sw = St[wave];
+  for (int q0 = k0; q0 < L; q0 += 64) {
+    __syncthreads();
+    ab_stage(Qs, qkv + h * 64, rb, q0, L, 3 * D, tid);
+    ab_stage(Os, dy + h * 64, rb, q0, L, D, tid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+      const float* qp = &Qs[(16 * t + lr) * AB_S + lq];
+      const float* op = &Os[(16 * t + lr) * AB_S + lq];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) { sa = AB_MFMA(kf[kk], qp[4 * kk], sa); pa = AB_MFMA(vf[kk], op[4 * kk], pa); }
+      const int qcol = q0 + 16 * t + lr;                       // this lane's column = a query row
+      const int qc = min(qcol, L - 1);
+      const float lsq = lse[sb + qc], dlq = delta[sb + qc];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = k0 + 16 * wave + 4 * lq + j;
+        const bool live = qcol < L && key <= qcol && key < L;
+        const float pv = live ? __expf(sa[j] - lsq) : 0.f;
+        Pw[(4 * lq + j) * AB_S + 16 * t + lr] = pv;
+        Sw[(4 * lq + j) * AB_S + 16 * t + lr] = pv * (pa[j] - dlq);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* pp = &Pw[lr * AB_S + lq];
+    const float* sp = &Sw[lr * AB_S + lq];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float pa = pp[4 * kk], sa = sp[4 * kk];
+      const float* ob = &Os[(4 * kk + lq) * AB_S + lr];
+      const float* qb2 = &Qs[(4 * kk + lq) * AB_S + lr];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dv[dt] = AB_MFMA(pa, ob[16 * dt], dv[dt]); dk[dt] = AB_MFMA(sa, qb2[16 * dt], dk[dt]); }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tk = k0 + 16 * wave + 4 * lq + j;
+    if (tk >= L) continue;
+    float* o = dqkv + (rb + tk) * 3 * D + D + h * 64 + lr;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { o[16 * dt] = dk[dt][j] * scale; o[D + 16 * dt] = dv[dt][j]; }
+  }
+}
+
 // softmax cross-entropy: loss_row[m] = lse - logit[target] ; dlogits = (softmax - onehot) * scale for rows with
 // t >= t0 (row m = (b, t), t = m % L), zero otherwise (F.cross_entropy mean over B*L_z rows, shapeformer.py:134-139)
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int* __restrict__ target,
@@ -476,15 +697,17 @@ int sfmi_ce_fwd_bwd_f32(const float* logits, const int* target, float* loss_rows
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
-// causal self-attention backward (mingpt.py:73-91), head dim 64: dqkv (B*L,3D) from qkv, y, dy.  lse: B*H*L scratch.
+// causal self-attention backward (mingpt.py:73-91), head dim 64: dqkv (B*L,3D) from qkv, y, dy.  lse: 2*B*H*L floats of scratch
+// (row log-sum-exps, then row sums of dO*O).
 int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* lse, float* dqkv, int B, int L, int D, int H,
                       void* stream) {
   if (!qkv || !y || !dy || !lse || !dqkv || D / H != 64) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(B, H, (L + 63) / 64);
-  hipLaunchKernelGGL(attn_lse_kernel, grid, dim3(256), 0, st, qkv, lse, L, D, 0.125f);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, qkv, y, dy, lse, dqkv, L, D, 0.125f);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, qkv, y, dy, lse, dqkv, L, D, 0.125f);
+  float* delta = lse + (size_t)B * H * L;
+  hipLaunchKernelGGL(attn_stats_mfma_kernel, grid, dim3(256), 0, st, qkv, y, dy, lse, delta, L, D, 0.125f);
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f);
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -232,7 +232,7 @@ class GPTTrainer:
         self._ready("heads")
         # ---- backward through the blocks -----------------------------------------------------------------------------
         dr = d_head[1]
-        lse = self._f(B, g.H, Lq)
+        lse = self._f(2, B, g.H, Lq)      # row log-sum-exps + row sums of dO*O (scratch of sfmi_attn_bwd_f32)
         for li in range(len(g.layers) - 1, -1, -1):
             ly, s, p = g.layers[li], saved[li], f"L{li}."
             if li + 1 < len(g.layers) and g.layers[li + 1].stage != ly.stage:
