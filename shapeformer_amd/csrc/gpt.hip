@@ -614,80 +614,11 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// prefill attention (causal, flash-style): grid (B, H, ceil(P/64)); qkv (B*P, 3D) rows m=(b,t); HD == 64
-//   each thread: query qi = tid>>2, dims [16*(tid&3), +16); also writes the K/V rows of its query block
-//   into the caches.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
-                                                           float* __restrict__ Vc, const int* __restrict__ nval,
-                                                           float* __restrict__ y /*(B*P,D)*/, int P, int D, int Lmax,
-                                                           float scale, const int* __restrict__ rowoff /*optional packed rows*/) {
-  __shared__ __attribute__((aligned(16))) float Ks[64][64], Vs[64][64];
-  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x;
-  const int n = min(P, max(nval[b], 0));  // valid prefill positions of this row
-  const long long base = rowoff ? rowoff[b] : (long long)b * P;
-  const int q0 = qb * 64;
-  if (q0 >= n) return;
-  const int qi = tid >> 2, c16 = tid & 3;
-  const int tq = q0 + qi;
-  const bool qok = tq < n;
-  f32x4 qf[4];
-  {
-    const float* qp = qkv + (base + (qok ? tq : q0)) * 3 * D + h * 64 + 16 * c16;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) qf[e] = reinterpret_cast<const f32x4*>(qp)[e] * scale;
-  }
-  float mrun = -INFINITY, lrun = 0.f;
-  f32x4 acc[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int kend = min(n, q0 + 64);
-  for (int k0 = 0; k0 < kend; k0 += 64) {
-    __syncthreads();
-    for (int i = tid; i < 64 * 16; i += 256) {
-      const int r = i >> 4, c = i & 15;
-      const int tk = min(k0 + r, n - 1);
-      const float* src = qkv + (base + tk) * 3 * D + h * 64 + 4 * c;
-      const f32x4 kv = *reinterpret_cast<const f32x4*>(src + D), vv = *reinterpret_cast<const f32x4*>(src + 2 * D);
-      *reinterpret_cast<f32x4*>(&Ks[r][4 * c]) = kv;
-      *reinterpret_cast<f32x4*>(&Vs[r][4 * c]) = vv;
-      if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
-        const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * 64 + 4 * c;  // (B,H,Lmax,64)
-        *reinterpret_cast<f32x4*>(Kc + co) = kv;
-        *reinterpret_cast<f32x4*>(Vc + co) = vv;
-      }
-    }
-    __syncthreads();
-    const int jn = min(64, kend - k0);
-    for (int j = 0; j < jn; ++j) {
-      const f32x4* kr = reinterpret_cast<const f32x4*>(&Ks[j][16 * c16]);
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const f32x4 kf = kr[e]; d += (qf[e][0] * kf[0] + qf[e][1] * kf[1]) + (qf[e][2] * kf[2] + qf[e][3] * kf[3]); }
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
-      if (k0 + j > tq) d = -INFINITY;  // causal
-      const float mnew = fmaxf(mrun, d);
-      if (mnew == -INFINITY) continue;
-      const float corr = __expf(mrun - mnew), p = __expf(d - mnew);
-      lrun = lrun * corr + p;
-      const f32x4* vr = reinterpret_cast<const f32x4*>(&Vs[j][16 * c16]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = acc[e] * corr + vr[e] * p;
-      mrun = mnew;
-    }
-  }
-  if (qok) {
-    const float inv = 1.0f / lrun;
-    float* yp = y + (base + tq) * D + h * 64 + 16 * c16;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) reinterpret_cast<f32x4*>(yp)[e] = acc[e] * inv;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // causal self-attention over a prefix on the MATRIX cores (prefill of the condition, teacher-forced forward, training
-// forward; mingpt.py:73-91), same contract as attn_prefill_kernel: grid (B, H, ceil(P/64)), 4 waves, wave w owns query
+// forward; mingpt.py:73-91): rows (b,t<P) of qkv (rectangle or packed, see sfmi_gpt_attn_prefill_f32), also fills the KV
+// caches; grid (B, H, ceil(P/64)), 4 waves, wave w owns query
 // rows q0+16w .. +15 and walks the key blocks 0 .. q0 (64 keys each, staged once per workgroup in LDS).
 //   S (16 x 64)  = Q K^T   : 4 key tiles x 16 k-steps of v_mfma_f32_16x16x4_f32, Q fragments live in 16 registers
 //   online softmax on the C/D layout (row 4(l>>4)+j lives in register j of lanes with the same l>>4: 16-lane reductions)

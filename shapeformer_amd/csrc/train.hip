@@ -173,7 +173,7 @@ __global__ void ln_bwd_params_finish_kernel(const float* __restrict__ part, floa
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention backward on the matrix cores (16x16x4 f32 MFMA), same maths and I/O as the VALU kernels above.
+// Attention backward on the matrix cores (16x16x4 f32 MFMA): dqkv (B*L,3D) from qkv, y, dy (mingpt.py:73-91), head dim 64.
 // Shared conventions (csrc/gpt.hip attn_prefill_mfma_kernel): 4 waves, wave w owns 16 rows of the block; an A operand is
 // (row = lane & 15, k = 4 kk + (lane >> 4)), a B operand (k = 4 kk + (lane >> 4), col = lane & 15), C/D register j holds
 // row 4 (lane >> 4) + j, column lane & 15.  LDS tiles are 64 rows x stride 68: "row-major" operand reads (16 rows x 4
@@ -429,168 +429,8 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
   if (tid == 0) loss_rows[m] = mx + __logf(tot) - row[tg];
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// causal attention backward (recompute form).  qkv (B*L, 3D) rows m=(b,t) [q|k|v], y = attention output (B*L, D),
-// dy = its gradient.  Head dim 64.  lse[b][h][t] = log-sum-exp of the scaled scores of row t (written by the forward).
-//   delta_i = dy_i . y_i ; p_ij = exp(s_ij - lse_i) ; ds_ij = p_ij (dy_i . v_j - delta_i)
-//   dq_i = scale sum_j ds_ij k_j ; dk_j = scale sum_i ds_ij q_i ; dv_j = sum_i p_ij dy_i
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_lse_kernel(const float* __restrict__ qkv, float* __restrict__ lse, int L, int D,
-                                                       float scale) {
-  // grid (B, H, ceil(L/64)); thread (qi = tid>>2, c16 = tid&3)
-  __shared__ __attribute__((aligned(16))) float Ks[64][64];
-  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, H = gridDim.y, tid = threadIdx.x;
-  const int q0 = qb * 64, qi = tid >> 2, c16 = tid & 3, tq = q0 + qi;
-  const bool qok = tq < L;
-  f32x4 qf[4];
-  const float* qp = qkv + ((long long)b * L + (qok ? tq : q0)) * 3 * D + h * 64 + 16 * c16;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) qf[e] = reinterpret_cast<const f32x4*>(qp)[e] * scale;
-  float mrun = -INFINITY, lrun = 0.f;
-  const int kend = min(L, q0 + 64);
-  for (int k0 = 0; k0 < kend; k0 += 64) {
-    __syncthreads();
-    for (int i = tid; i < 64 * 16; i += 256) {
-      const int r = i >> 4, c = i & 15;
-      const int tk = min(k0 + r, L - 1);
-      *reinterpret_cast<f32x4*>(&Ks[r][4 * c]) = *reinterpret_cast<const f32x4*>(qkv + ((long long)b * L + tk) * 3 * D + D + h * 64 + 4 * c);
-    }
-    __syncthreads();
-    const int jn = min(64, kend - k0);
-    for (int j = 0; j < jn; ++j) {
-      const f32x4* kr = reinterpret_cast<const f32x4*>(&Ks[j][16 * c16]);
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const f32x4 kf = kr[e]; d += (qf[e][0] * kf[0] + qf[e][1] * kf[1]) + (qf[e][2] * kf[2] + qf[e][3] * kf[3]); }
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
-      if (k0 + j > tq) continue;
-      const float mnew = fmaxf(mrun, d);
-      lrun = lrun * __expf(mrun - mnew) + __expf(d - mnew);
-      mrun = mnew;
-    }
-  }
-  if (qok && c16 == 0) lse[((long long)b * H + h) * L + tq] = mrun + __logf(lrun);
-}
 
-// dq: grid (B, H, ceil(L/64)) ; thread (qi, c16)
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ y,
-                                                          const float* __restrict__ dy, const float* __restrict__ lse,
-                                                          float* __restrict__ dqkv, int L, int D, float scale) {
-  __shared__ __attribute__((aligned(16))) float Ks[64][64], Vs[64][64];
-  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, H = gridDim.y, tid = threadIdx.x;
-  const int q0 = qb * 64, qi = tid >> 2, c16 = tid & 3, tq = q0 + qi;
-  const bool qok = tq < L;
-  const long long mrow = (long long)b * L + (qok ? tq : q0);
-  f32x4 qf[4], dyf[4], acc[4];
-  float delta = 0.f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    qf[e] = reinterpret_cast<const f32x4*>(qkv + mrow * 3 * D + h * 64 + 16 * c16)[e] * scale;
-    dyf[e] = reinterpret_cast<const f32x4*>(dy + mrow * D + h * 64 + 16 * c16)[e];
-    const f32x4 yf = reinterpret_cast<const f32x4*>(y + mrow * D + h * 64 + 16 * c16)[e];
-    delta += (dyf[e][0] * yf[0] + dyf[e][1] * yf[1]) + (dyf[e][2] * yf[2] + dyf[e][3] * yf[3]);
-    acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  delta += __shfl_xor(delta, 1, 64); delta += __shfl_xor(delta, 2, 64);
-  const float ls = qok ? lse[((long long)b * H + h) * L + tq] : 0.f;
-  const int kend = min(L, q0 + 64);
-  for (int k0 = 0; k0 < kend; k0 += 64) {
-    __syncthreads();
-    for (int i = tid; i < 64 * 16; i += 256) {
-      const int r = i >> 4, c = i & 15;
-      const int tk = min(k0 + r, L - 1);
-      const float* src = qkv + ((long long)b * L + tk) * 3 * D + h * 64 + 4 * c;
-      *reinterpret_cast<f32x4*>(&Ks[r][4 * c]) = *reinterpret_cast<const f32x4*>(src + D);
-      *reinterpret_cast<f32x4*>(&Vs[r][4 * c]) = *reinterpret_cast<const f32x4*>(src + 2 * D);
-    }
-    __syncthreads();
-    const int jn = min(64, kend - k0);
-    for (int j = 0; j < jn; ++j) {
-      const f32x4* kr = reinterpret_cast<const f32x4*>(&Ks[j][16 * c16]);
-      const f32x4* vr = reinterpret_cast<const f32x4*>(&Vs[j][16 * c16]);
-      float s = 0.f, dp = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 kf = kr[e], vf = vr[e];
-        s += (qf[e][0] * kf[0] + qf[e][1] * kf[1]) + (qf[e][2] * kf[2] + qf[e][3] * kf[3]);
-        dp += (dyf[e][0] * vf[0] + dyf[e][1] * vf[1]) + (dyf[e][2] * vf[2] + dyf[e][3] * vf[3]);
-      }
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-      dp += __shfl_xor(dp, 1, 64); dp += __shfl_xor(dp, 2, 64);
-      if (k0 + j > tq) continue;
-      const float ds = __expf(s - ls) * (dp - delta) * scale;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = acc[e] + kr[e] * ds;
-    }
-  }
-  if (qok) {
-    float* o = dqkv + mrow * 3 * D + h * 64 + 16 * c16;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) reinterpret_cast<f32x4*>(o)[e] = acc[e];
-  }
-}
 
-// dk, dv: grid (B, H, ceil(L/64)) ; thread (kj, c16) ; loops over queries i >= first key of the block
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ y,
-                                                           const float* __restrict__ dy, const float* __restrict__ lse,
-                                                           float* __restrict__ dqkv, int L, int D, float scale) {
-  __shared__ __attribute__((aligned(16))) float Qs[64][64], Gs[64][64];
-  __shared__ float Ls[64], Ds[64];
-  const int b = blockIdx.x, h = blockIdx.y, kb = blockIdx.z, H = gridDim.y, tid = threadIdx.x;
-  const int k0 = kb * 64, kj = tid >> 2, c16 = tid & 3, tk = k0 + kj;
-  const bool kok = tk < L;
-  const long long krow = (long long)b * L + (kok ? tk : k0);
-  f32x4 kf[4], vf[4], dk[4], dv[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    kf[e] = reinterpret_cast<const f32x4*>(qkv + krow * 3 * D + D + h * 64 + 16 * c16)[e];
-    vf[e] = reinterpret_cast<const f32x4*>(qkv + krow * 3 * D + 2 * D + h * 64 + 16 * c16)[e];
-    dk[e] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[e] = dk[e];
-  }
-  for (int i0 = k0; i0 < L; i0 += 64) {
-    __syncthreads();
-    for (int i = tid; i < 64 * 16; i += 256) {
-      const int r = i >> 4, c = i & 15;
-      const int ti = min(i0 + r, L - 1);
-      const long long mr = (long long)b * L + ti;
-      *reinterpret_cast<f32x4*>(&Qs[r][4 * c]) = *reinterpret_cast<const f32x4*>(qkv + mr * 3 * D + h * 64 + 4 * c);
-      *reinterpret_cast<f32x4*>(&Gs[r][4 * c]) = *reinterpret_cast<const f32x4*>(dy + mr * D + h * 64 + 4 * c);
-    }
-    if (tid < 64) {
-      const int ti = min(i0 + tid, L - 1);
-      const long long mr = (long long)b * L + ti;
-      Ls[tid] = lse[((long long)b * H + h) * L + ti];
-      float d = 0.f;
-      for (int c = 0; c < 64; ++c) d += dy[mr * D + h * 64 + c] * y[mr * D + h * 64 + c];
-      Ds[tid] = d;
-    }
-    __syncthreads();
-    const int in_ = min(64, L - i0);
-    for (int i = 0; i < in_; ++i) {
-      const f32x4* qr = reinterpret_cast<const f32x4*>(&Qs[i][16 * c16]);
-      const f32x4* gr = reinterpret_cast<const f32x4*>(&Gs[i][16 * c16]);
-      float s = 0.f, dp = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 qv = qr[e], gv = gr[e];
-        s += (qv[0] * kf[e][0] + qv[1] * kf[e][1]) + (qv[2] * kf[e][2] + qv[3] * kf[e][3]);
-        dp += (gv[0] * vf[e][0] + gv[1] * vf[e][1]) + (gv[2] * vf[e][2] + gv[3] * vf[e][3]);
-      }
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-      dp += __shfl_xor(dp, 1, 64); dp += __shfl_xor(dp, 2, 64);
-      if (i0 + i < tk) continue;  // causal: query index must be >= key index
-      const float p = __expf(s * scale - Ls[i]);
-      const float ds = p * (dp - Ds[i]) * scale;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { dk[e] = dk[e] + qr[e] * ds; dv[e] = dv[e] + gr[e] * p; }
-    }
-  }
-  if (kok) {
-    float* o = dqkv + krow * 3 * D + h * 64 + 16 * c16;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { reinterpret_cast<f32x4*>(o + D)[e] = dk[e]; reinterpret_cast<f32x4*>(o + 2 * D)[e] = dv[e]; }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // embedding gradients: acc[idx[m]][:] += dx[m][:] in 2^-32 fixed point (int64 atomics: associative => deterministic)
