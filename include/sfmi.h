@@ -134,6 +134,10 @@ int sfmi_fixed_to_float_f32(const long long* acc, float* out, long long n, int a
 int sfmi_add_f32(const float* a, const float* b, float* out, long long n, void* stream);
 int sfmi_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, void* stream);                                                /* shapeformer.py:198-206 */
+/* the same update over a table of tensors in one launch (device tables; per-tensor weight decay = the two AdamW groups) */
+int sfmi_adamw_multi_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
+                         const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                         float eps, int step, void* stream);
 
 /* ---- Implicit decoder SDF/occupancy query: dec.py:62-100 (grid_sample + 5-block conditioned MLP), layers.py:39-48 - */
 size_t sfmi_sdf_pack_floats(void);

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "sfmi_fixed_to_float_f32": (i32, [c_ptr, c_ptr, i64, i32, c_ptr]),
     "sfmi_add_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_adamw_f32": (i32, [c_ptr] * 4 + [i64] + [C.c_float] * 5 + [i32, c_ptr]),
+    "sfmi_adamw_multi_f32": (i32, [c_ptr] * 6 + [i32, c_ptr, c_ptr, c_ptr, f32, f32, f32, f32, i32, c_ptr]),
 }
 
 

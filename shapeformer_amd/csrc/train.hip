@@ -469,6 +469,29 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// one launch for a whole parameter table: chunk c updates elements [coff[c], coff[c] + clen[c]) of tensor ctensor[c];
+// gradient / moment buffers are flat (tensor t starts at foff[t]); weight decay is per tensor (AdamW parameter groups)
+struct AdamMultiArgs {
+  float* const* p; const long long* foff; const float* wd;
+  const int* ctensor; const long long* coff; const int* clen;
+  const float* g; float* m; float* v;
+  float lr, b1, b2, eps, bc1, bc2;
+};
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
+  const int c = blockIdx.x, t = a.ctensor[c];
+  const long long o = a.coff[c], fo = a.foff[t] + o;
+  const int n = a.clen[c];
+  float* p = a.p[t] + o;
+  const float decay = 1.0f - a.lr * a.wd[t], sb2 = sqrtf(a.bc2), step = a.lr / a.bc1;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float gi = a.g[fo + i];
+    const float mi = a.b1 * a.m[fo + i] + (1.0f - a.b1) * gi;
+    const float vi = a.b2 * a.v[fo + i] + (1.0f - a.b2) * gi * gi;
+    a.m[fo + i] = mi; a.v[fo + i] = vi;
+    p[i] = p[i] * decay - step * (mi / (sqrtf(vi) / sb2 + a.eps));
+  }
+}
+
 extern "C" {
 
 int sfmi_transpose_f32(const float* in, float* out, int R, int C, int ldin, int Rpad, void* stream) {
@@ -578,6 +601,21 @@ int sfmi_adamw_f32(float* p, const float* g, float* m, float* v, long long n, fl
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                      eps, weight_decay, bc1, bc2);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// the same update for a table of tensors in ONE launch.  Device tables: p (T pointers), foff (T flat offsets), wd (T),
+// chunk tables ctensor / coff / clen (nchunks; any partition of every tensor into chunks, e.g. 16384 elements each).
+int sfmi_adamw_multi_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
+                         const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                         float eps, int step, void* stream) {
+  if (!p || !foff || !wd || !ctensor || !coff || !clen || !g || !m || !v || nchunks <= 0 || step <= 0) return SFMI_EINVAL;
+  AdamMultiArgs a;
+  a.p = p; a.foff = foff; a.wd = wd; a.ctensor = ctensor; a.coff = coff; a.clen = clen; a.g = g; a.m = m; a.v = v;
+  a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+  a.bc1 = 1.0f - powf(beta1, (float)step); a.bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

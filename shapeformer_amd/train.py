@@ -292,13 +292,24 @@ class GPTTrainer:
     def optimizer_step(self):
         """torch.optim.AdamW over the two reference groups (shapeformer.py:198-206)."""
         self.step_count += 1
-        o = 0
-        for name, t, decay in self.params:
-            n = t.numel()
-            L.check(L.lib().sfmi_adamw_f32(L.ptr(t), L.ptr(self.flat_grad[o:o + n]), L.ptr(self.flat_m[o:o + n]),
-                                           L.ptr(self.flat_v[o:o + n]), n, self.lr, self.betas[0], self.betas[1], self.eps,
-                                           self.wd if decay else 0.0, self.step_count, L.stream_ptr()), "adamw")
-            o += n
+        if not hasattr(self, "_adam_tab"):      # device tables for the one-launch update (built once)
+            CH = 16384
+            ptrs, foff, wd, ct, co, cl = [], [], [], [], [], []
+            o = 0
+            for ti, (name, t, decay) in enumerate(self.params):
+                n = t.numel()
+                ptrs.append(t.data_ptr()); foff.append(o); wd.append(self.wd if decay else 0.0)
+                for c0 in range(0, n, CH):
+                    ct.append(ti); co.append(c0); cl.append(min(CH, n - c0))
+                o += n
+            dev = self.dev
+            self._adam_tab = dict(p=torch.tensor(ptrs, dtype=torch.int64, device=dev), foff=torch.tensor(foff, dtype=torch.int64, device=dev),
+                                  wd=torch.tensor(wd, dtype=torch.float32, device=dev), ct=torch.tensor(ct, dtype=torch.int32, device=dev),
+                                  co=torch.tensor(co, dtype=torch.int64, device=dev), cl=torch.tensor(cl, dtype=torch.int32, device=dev), n=len(ct))
+        tb = self._adam_tab
+        L.check(L.lib().sfmi_adamw_multi_f32(L.ptr(tb["p"]), L.ptr(tb["foff"]), L.ptr(tb["wd"]), L.ptr(tb["ct"]), L.ptr(tb["co"]), L.ptr(tb["cl"]),
+                                             tb["n"], L.ptr(self.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), self.lr, self.betas[0],
+                                             self.betas[1], self.eps, self.step_count, L.stream_ptr()), "adamw_multi")
         self._wT.clear()                 # transposed copies are stale now
         self.g.mark_decode_weights_stale()  # LN-folded / fragment-packed decode weights are rebuilt at the next decode use
 
