@@ -510,6 +510,7 @@ int sfmi_colsum_f32(const float* x, float* out, int M, int N, int ld, int accumu
 int sfmi_colsum_slices(int M, int N) {
   const int cb = (N + 63) / 64;
   int rs = (2048 + cb - 1) / cb;
+  if (rs > 128) rs = 128;          // the finishing pass walks the slices serially per column
   if (rs > M / 16) rs = M / 16;
   return rs < 1 ? 1 : rs;
 }

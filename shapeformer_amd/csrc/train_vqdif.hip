@@ -45,22 +45,33 @@ __global__ void affine2_kernel(const float* __restrict__ u, const float* __restr
   out[i] = A[k] * u[i] + Bc[k] * v[i] + Cc[k];
 }
 
-// per (b, c): sum_v dy, sum_v dy*x  -> partial (B, S, C, 2) doubles
+// per (b, c): sum_v dy, sum_v dy*x  -> partial (B, S, C, 2) doubles.  256 threads = (256/C4) voxel lanes x C4 float4
+// channel groups (C4 = C/4 <= 256), LDS tree over the voxel lanes.
 __global__ __launch_bounds__(256) void chan_dot_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              double* __restrict__ partial, long long V, int C, int S) {
-  const int s = blockIdx.x, b = blockIdx.y;
+  __shared__ double red[256 * 8];
+  const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cg = C / 4, rpp = 256 / cg;
   const long long v0 = V * s / S, v1 = V * (s + 1) / S;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double a0 = 0.0, a1 = 0.0;
-    const float* pd = dy + ((long long)b * V) * C + c;
-    const float* px = x + ((long long)b * V) * C + c;
-    for (long long v = v0; v < v1; ++v) {
-      const float d = pd[v * C];
-      a0 += (double)d;
-      a1 += (double)d * (double)px[v * C];
+  const int g = tid % cg, ro = tid / cg;
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (ro < rpp)
+    for (long long v = v0 + ro; v < v1; v += rpp) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((long long)b * V + v) * C + 4 * g);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((long long)b * V + v) * C + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] += (double)d[e]; a1[e] += (double)d[e] * (double)xv[e]; }
     }
-    double* o = partial + (((long long)b * S + s) * C + c) * 2;
-    o[0] = a0; o[1] = a1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = a0[e]; red[tid * 8 + 4 + e] = a1[e]; }
+  __syncthreads();
+  if (ro == 0) {
+    for (int r = 1; r < rpp; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] += red[(tid + r * cg) * 8 + e]; a1[e] += red[(tid + r * cg) * 8 + 4 + e]; }
+    double* o = partial + (((long long)b * S + s) * C + 4 * g) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = a0[e]; o[2 * e + 1] = a1[e]; }
   }
 }
 
@@ -390,7 +401,7 @@ int sfmi_affine2_cl_f32(const float* u, const float* v, const float* A, const fl
 
 /* partial: B*S*C*2 doubles with S = sfmi_gn_splits(V) */
 int sfmi_chan_dot_stats_f32(const float* dy, const float* x, double* partial, int B, long long V, int C, int S, void* stream) {
-  if (!dy || !x || !partial || S <= 0) return SFMI_EINVAL;
+  if (!dy || !x || !partial || S <= 0 || C % 4 || C > 1024) return SFMI_EINVAL;
   hipLaunchKernelGGL(chan_dot_stats_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, dy, x, partial, V, C, S);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
