@@ -232,8 +232,9 @@ def main():
     Xct = torch.cat(kept)[:B].contiguous()
     del kept, cand
 
-    def step(i):
-        return pipe.complete(Xct, max_steps=a.ar_steps, decode_res=a.decode_res, seed=i, stop_early=False, sigmoid=True, n_micro=a.micro)
+    def step(i, timings=None):
+        return pipe.complete(Xct, max_steps=a.ar_steps, decode_res=a.decode_res, seed=i, stop_early=False, sigmoid=True, n_micro=a.micro,
+                             timings=timings)
 
     def barrier():
         torch.cuda.synchronize()
@@ -272,6 +273,19 @@ def main():
             "sanity": sanity,
         }
         if not a.no_roofline:
+            # one extra, untimed pass with stage marks: where the batch time goes, and the AR loop against its HBM stream
+            tm = {}
+            step(a.warmup + a.steps, timings=tm)
+            lc = r["Lc"].float()
+            kv_bytes = float((2 * (lc + (a.ar_steps - 1) / 2.0) * gpt.D * 4 * len(gpt.layers)).sum().item())   # mean over the steps
+            n_chain = a.micro or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
+            w_bytes = 4.0 * n_chain * (sum(l.wqkv.numel() + l.wproj.numel() + l.wfc1.numel() + l.wfc2.numel() for l in gpt.layers)
+                                       + sum(w.numel() for w in gpt.head_w))
+            ms_step = tm["ar_loop"] / a.ar_steps
+            line["stages_ms"] = {k: round(v, 1) for k, v in tm.items()}
+            line["ar_loop"] = {"ms_per_step": round(ms_step, 3), "hbm_bytes_per_step": int(kv_bytes + w_bytes),
+                               "achieved_TBps": round((kv_bytes + w_bytes) / ms_step / 1e9, 3), "frac_of_hbm_peak": round((kv_bytes + w_bytes) / ms_step / 1e9 / 8.0, 4),
+                               "note": "algorithmic bytes: f32 KV cache of every row at its mean length + one weight stream per decode chain"}
             nm = a.micro or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
             Bk = -(-B // nm)     # rows per decode launch (micro-batch)
             ks = kernel_rooflines(vq, gpt, Bk, dev, lc_mean=sanity["Lc_mean"])

@@ -425,7 +425,7 @@ class CondTupleGPT:
     @torch.no_grad()
     def sample(self, c_tokens, Lc, max_steps=512, top_k=100, top_p=0.4, temperature=1.0, best_in_first=True,
                mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True, use_graph=True,
-               return_logits=False, check_every=32, force_tokens=None, to_host=True):
+               return_logits=False, check_every=32, force_tokens=None, to_host=True, after_prefill=None):
         """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32.
 
         Returns dict(samples (B,steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
@@ -435,6 +435,8 @@ class CondTupleGPT:
         ctx = self._prepare(c_tokens, Lc, max_steps, sp_kw, return_logits=return_logits, force_tokens=force_tokens,
                             use_graph=use_graph)
         st, sp, B, steps, g, hist, Lc_host = (ctx[k] for k in ("st", "sp", "B", "steps", "graph", "hist", "Lc_host"))
+        if after_prefill is not None:
+            after_prefill()
         done = 0
         if g is not None:
             while done < steps:
@@ -466,7 +468,7 @@ class CondTupleGPT:
     @torch.no_grad()
     def sample_microbatched(self, c_tokens, Lc, n_micro=2, max_steps=512, top_k=100, top_p=0.4, temperature=1.0,
                             best_in_first=True, mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True,
-                            check_every=32):
+                            check_every=32, after_prefill=None):
         """Same result as `sample(..., to_host=False)` (identical tokens: the uniform stream and the greedy row are
         indexed by GLOBAL row), but the rows are split into `n_micro` independent micro-batches whose decode steps are
         separate hipGraphs replayed on separate HIP streams: one micro-batch's HBM-bound attention overlaps the other's
@@ -479,6 +481,8 @@ class CondTupleGPT:
         for i, (lo, hi) in enumerate(groups):
             ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B))
         steps = min(c["steps"] for c in ctxs)
+        if after_prefill is not None:
+            after_prefill()
         if not hasattr(self, "_mb_streams") or len(self._mb_streams) < len(ctxs):
             self._mb_streams = [torch.cuda.Stream(device=self.dev) for _ in ctxs]
         cur = torch.cuda.current_stream()

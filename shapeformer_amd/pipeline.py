@@ -30,9 +30,20 @@ class ShapeCompletion:
     @torch.no_grad()
     def complete(self, Xct, max_steps=512, decode_res=128, top_k=100, top_p=0.4, temperature=1.0, seed=0,
                  best_in_first=False, stop_early=True, sigmoid=True, mask_invalid=True, mask_invalid_completion=True,
-                 n_micro=None):
-        """One (pos,val) sequence per input cloud -> dict(samples tokens, dense code grid, occupancy (B,Q^3))."""
+                 n_micro=None, timings=None):
+        """One (pos,val) sequence per input cloud -> dict(samples tokens, dense code grid, occupancy (B,Q^3)).
+        timings: optional dict filled with stage times in ms (encode / prefill / ar_loop / decode), HIP events on the
+        current stream (the chain streams are joined before each mark)."""
+        marks = []
+
+        def mark(name):
+            if timings is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((name, ev))
+        mark("start")
         enc = self.encode_cloud(Xct)
+        mark("encode")
         g = self.gpt
         B = Xct.shape[0]
         # interleaved hipGraph chains (gpt.py:sample_microbatched): <= 64 rows each; 2 chains already for 32..64 rows
@@ -40,12 +51,18 @@ class ShapeCompletion:
         kw = dict(max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature, best_in_first=best_in_first,
                   mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion, seed=seed, stop_early=stop_early)
         if n_micro > 1:
-            res = g.sample_microbatched(enc["c_tokens"], enc["Lc"], n_micro=n_micro, **kw)
+            res = g.sample_microbatched(enc["c_tokens"], enc["Lc"], n_micro=n_micro, after_prefill=lambda: mark("prefill"), **kw)
         else:
-            res = g.sample(enc["c_tokens"], enc["Lc"], to_host=False, **kw)
+            res = g.sample(enc["c_tokens"], enc["Lc"], to_host=False, after_prefill=lambda: mark("prefill"), **kw)
+        mark("ar_loop")
         st = res["state"]
         dense = T.sparse2dense_dev(st["seq"], st["len"], enc["empty_index"], self.R, self.end, start=st["Lc"])
         out = self.vq.decode_index(dense, grid_Q=decode_res, sigmoid=sigmoid)
+        mark("decode")
+        if timings is not None:
+            torch.cuda.synchronize()
+            for (_, e0), (name, e1) in zip(marks, marks[1:]):
+                timings[name] = e0.elapsed_time(e1)
         return dict(c_ind=enc["c_tokens"], Lc=enc["Lc"], empty_index=enc["empty_index"], state=st, steps=res["steps"],
                     dense=dense, occupancy=out["logits"][..., 0], log_prob=st["logp"])
 
