@@ -477,20 +477,17 @@ class CondTupleGPT:
         bounds = [round(i * B / n_micro) for i in range(n_micro + 1)]
         groups = [(bounds[i], bounds[i + 1]) for i in range(n_micro) if bounds[i + 1] > bounds[i]]
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
-        if not hasattr(self, "_mb_streams") or len(self._mb_streams) < len(groups):
-            self._mb_streams = [torch.cuda.Stream(device=self.dev) for _ in groups]
-        cur = torch.cuda.current_stream()
         ctxs = []
         for i, (lo, hi) in enumerate(groups):
-            # every chain prefills on ITS stream: chain 0 starts decoding (HBM-bound attention) while the later chains are
-            # still in their MFMA-bound prefill GEMMs
-            s = self._mb_streams[i]
-            s.wait_stream(cur)
-            with torch.cuda.stream(s):
-                ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B))
+            ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B))
         steps = min(c["steps"] for c in ctxs)
         if after_prefill is not None:
             after_prefill()
+        if not hasattr(self, "_mb_streams") or len(self._mb_streams) < len(ctxs):
+            self._mb_streams = [torch.cuda.Stream(device=self.dev) for _ in ctxs]
+        cur = torch.cuda.current_stream()
+        for s in self._mb_streams[:len(ctxs)]:
+            s.wait_stream(cur)
         done = 0
         while done < steps:
             n = min(check_every, steps - done) if stop_early else steps - done
