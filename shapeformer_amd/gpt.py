@@ -41,6 +41,12 @@ class _Layer:
 
 class CondTupleGPT:
     S_PROJ, S_FC2 = 1, 4   # in-kernel split-K of the N = n_embd GEMMs (64 n-tiles -> 256 workgroups)
+    PREFILL_BLAS_ROWS = 2048   # prefill GEMMs with at least this many rows use the library sgemm (None: never)
+
+    def _blas(self):
+        if not hasattr(self, "_has_blas"):
+            self._has_blas = bool(L.lib().sfmi_blas_available())
+        return self._has_blas
 
     def __init__(self, state_dict=None, n_embd=1024, n_head=16, n_layers=(20, 4), block_size=812,
                  vocab_sizes=(4097, 4097), extra_vocab_sizes=(4097,), end_tokens=(4096, 4096), device="cuda:0",
@@ -181,6 +187,13 @@ class CondTupleGPT:
                                            self.end[0], L.ptr(st.get("rowoff")), int(st.get("M_packed") or 0), L.stream_ptr()), "sfmi_gpt_embed_f32")
 
     def _gemm(self, x, w, bias, resid, y, M, N, K, act=0, og=0, ogs=0):
+        # plain GEMMs of a long prefill go to rocBLAS (csrc/blas.hip; +2 % on the 192-shape pass).  Its kernel choice depends
+        # on M, so per-row results can differ in the last bits between different row counts; set PREFILL_BLAS_ROWS = None
+        # to keep every prefill on the tile kernel, whose per-row result is independent of the launch size.
+        if self.PREFILL_BLAS_ROWS is not None and M >= self.PREFILL_BLAS_ROWS and not og and N % 4 == 0 and self._blas() \
+                and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
+            L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
+            return
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, og, ogs,
                                       L.stream_ptr()), "sfmi_gemm_f32")
 
