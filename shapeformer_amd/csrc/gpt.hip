@@ -177,6 +177,9 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
 #ifndef XIDX
 #define XIDX(i) (i)
 #endif
+#ifndef DG_WLOAD   // weight stream of the 64..96-row kernel: plain loads allocate in the Infinity Cache, so the second and third
+#define DG_WLOAD(p_) (*(p_))   // interleaved chain re-read a layer's weights from there (tools/ubench/mall_probe.hip: 8.3 vs 5.1-5.6 TB/s)
+#endif
 #ifndef DG_MFMA
 #define DG_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 #endif
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     f32x4 w[UN], xb[UN][MT];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      w[u] = __builtin_nontemporal_load(wp + (s0 + u) * 64);   // weights are streamed once
+      w[u] = DG_WLOAD(wp + (s0 + u) * 64);
 #pragma unroll
       for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][XIDX((s0 + u) * 64)];
     }
