@@ -81,3 +81,16 @@ def test_mesh_of_a_reconstructed_shape(dev):
     v, f, voff, toff = mcubes.marching_cubes_dev(occ, iso)
     vo, fo = MO.marching_cubes(occ[0].cpu().numpy(), iso)
     assert len(fo) > 100 and np.array_equal(f.cpu().numpy(), fo) and np.abs(v.cpu().numpy() - vo).max() < 1e-6
+
+
+def test_config4_resolution_256(dev):
+    """BASELINE config 4 queries a 256^3 lattice: 50 M grid edges in one call (index scratch 268 MB), same properties."""
+    from oracle import mc_oracle as MO
+    from shapeformer_amd import mcubes
+    occ = torch.from_numpy(_sphere(256, 0.7).astype(np.float32))[None].to(dev)
+    v, f, voff, toff = mcubes.marching_cubes_dev(occ, 0.5)
+    v, f = v.cpu().numpy(), f.cpu().numpy()
+    assert MO.edge_use(f) and MO.euler_characteristic(v, f) == 2
+    assert abs(MO.signed_volume(v, f) / (4 / 3 * np.pi * 0.7 ** 3) - 1) < 1e-3
+    r = np.linalg.norm(v, axis=1)
+    assert abs(r.mean() - 0.7) < 1e-3 and r.std() < 2e-3

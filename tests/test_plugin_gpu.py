@@ -124,3 +124,18 @@ def test_vqdif_model_training_step_through_the_plugin(dev):
     vq.sync_inference_weights()
     after = vq.decode_index(vq.quantize_cloud(torch.from_numpy(Xbd[:1]).to(dev))[0], Xtg=torch.from_numpy(Xtg[:1]).to(dev))["logits"]
     assert float((after - before).abs().max()) > 1e-4
+
+
+def test_res32_reconstruction_callback(dev, tmp_path):
+    """VQDIF-32 (configs/vqdif/shapenet_res32.yaml layout: one down/up-sampling step, d = 64, 32^3 latent) through the
+    reconstruction callback: 32^3 code grid, tokens with the res-32 end tokens, mesh on disk."""
+    from shapeformer_amd import plugin as P
+    vq = P.instantiate_from_opt({"class": "shapeformer.models.vqdif.vqdif.VQDIF", "kwargs": P.default_vqdif_kwargs(32)})
+    rc = P.instantiate_from_opt({"class": "shapeformer.models.vqdif.vqdif.VisSparseRecon3D", "kwargs": dict(
+        quant_grid_depth=5, decoder_resolution=48, max_length=2048, end_tokens=[32768, 4096], visual_indices=[0],
+        data_dir=str(tmp_path / "vq32"))})
+    out = rc.process(vq, _Items(1))
+    comp = np.load(tmp_path / "vq32" / "computed" / "0.npy", allow_pickle=True).item()
+    assert comp["quant_ind"].shape == (1, 32, 32, 32) and comp["logits"].shape == (1, 48 ** 3, 1)
+    assert comp["sparse"][:, 1].max() < 32768 and comp["sparse"][:, 2].max() < 4096
+    assert os.path.exists(tmp_path / "vq32" / "meshes" / "0.ply") and "recon_mesh" in out["0"]
