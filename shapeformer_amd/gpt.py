@@ -72,6 +72,33 @@ class CondTupleGPT:
         return {k: W.make_tensor_torch(k, shp, self.dev) for k, shp in spec.items()}
 
     # ------------------------------------------------------------------ weights
+    def state_dict(self):
+        """The reference's 419-tensor key set (mingpt.py:187-254) from the live device parameters: the fused QKV
+        rows are split back into query / key / value, the causal-mask buffers are regenerated (tril), tensors on the CPU."""
+        D, sd = self.D, {}
+        cpu = lambda t: t.detach().cpu().clone()
+        sd["pos_emb"], sd["cond_pos_emb"] = cpu(self.pos_emb).view(1, -1, D), cpu(self.cond_pos_emb).view(1, -1, D)
+        sd["tok_embs.0.weight"], sd["tok_embs.1.weight"], sd["extra_tok_embs.0.weight"] = cpu(self.E[0]), cpu(self.E[1]), cpu(self.Ex)
+        mask = torch.tril(torch.ones(self.Lmax, self.Lmax)).view(1, 1, self.Lmax, self.Lmax)
+        li = 0
+        for s_, nl in enumerate(self.n_layers):
+            for n in range(nl):
+                ly, p = self.layers[li], f"blocks.{s_}.{n}."
+                li += 1
+                sd[p + "ln1.weight"], sd[p + "ln1.bias"] = cpu(ly.ln1[0]), cpu(ly.ln1[1])
+                sd[p + "ln2.weight"], sd[p + "ln2.bias"] = cpu(ly.ln2[0]), cpu(ly.ln2[1])
+                for i, nm in enumerate(("query", "key", "value")):
+                    sd[p + f"attn.{nm}.weight"] = cpu(ly.wqkv[i * D:(i + 1) * D])
+                    sd[p + f"attn.{nm}.bias"] = cpu(ly.bqkv[i * D:(i + 1) * D])
+                sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = cpu(ly.wproj), cpu(ly.bproj)
+                sd[p + "attn.mask"] = mask.clone()
+                sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"] = cpu(ly.wfc1), cpu(ly.bfc1)
+                sd[p + "mlp.2.weight"], sd[p + "mlp.2.bias"] = cpu(ly.wfc2), cpu(ly.bfc2)
+        for s_ in range(2):
+            sd[f"heads.{s_}.0.weight"], sd[f"heads.{s_}.0.bias"] = cpu(self.head_ln[s_][0]), cpu(self.head_ln[s_][1])
+            sd[f"heads.{s_}.1.weight"] = cpu(self.head_w[s_])
+        return sd
+
     def load_state_dict(self, sd):
         dev = self.dev
         g = lambda k: _t(sd, k, dev)

@@ -118,6 +118,28 @@ class VQDIFModel:
         self._stale = True
         return out["loss"]
 
+    def save_checkpoint(self, path, epoch=0):
+        """Lightning-layout checkpoint of the trained autoencoder (+ Adam state): loadable by load_from_checkpoint / the reference."""
+        self.sync_inference_weights()
+        sd = self.trainer.state_dict() if hasattr(self, "trainer") else self.core.state_dict_np()
+        ck = dict(state_dict={k: torch.as_tensor(v) for k, v in sd.items()}, hyper_parameters=dict(self.hparams), epoch=epoch,
+                  global_step=getattr(getattr(self, "trainer", None), "step_count", 0))
+        if hasattr(self, "trainer"):
+            ck["optimizer_states"] = [self.trainer.optimizer_state()]
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(ck, path)
+        return path
+
+    def resume(self, path):
+        """Continue training from save_checkpoint's file: weights, EMA codebook buffers, Adam moments, step count."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.core.load_state_dict(ck["state_dict"])
+        lr = self.trainer.lr if hasattr(self, "trainer") else None
+        self.make_trainer(dict(lr=lr) if lr else None, dist=getattr(getattr(self, "trainer", None), "dist", None))
+        if ck.get("optimizer_states"):
+            self.trainer.load_optimizer_state(ck["optimizer_states"][0])
+        return ck
+
     def sync_inference_weights(self):
         """Re-pack the trained parameters into the inference kernels' layouts (call before encode/decode after training)."""
         if getattr(self, "_stale", False):
@@ -211,6 +233,34 @@ class ShapeFormerModel:
             self.make_trainer()
         c, z = self.get_indices(batch["Xct"], batch["Xbd"], stage="train")
         return self.trainer.training_step(c, z)
+
+    # ---- checkpoint / resume (Lightning `.ckpt` = torch.save dict) ---------------------------------------------
+    def state_dict(self):
+        """`transformer.*` + frozen `representer.vqvae_model.*` keys, as in a reference ShapeFormer checkpoint."""
+        sd = {"transformer." + k: v for k, v in self.transformer.state_dict().items()}
+        sd.update({"representer.vqvae_model." + k: torch.as_tensor(v) for k, v in self.representer.vqvae_model.core.state_dict_np().items()})
+        return sd
+
+    def save_checkpoint(self, path, hyper_parameters=None, epoch=0):
+        ck = dict(state_dict=self.state_dict(), hyper_parameters=hyper_parameters or {}, epoch=epoch,
+                  global_step=getattr(getattr(self, "trainer", None), "step_count", 0))
+        if hasattr(self, "trainer"):
+            ck["optimizer_states"] = [self.trainer.optimizer_state()]
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(ck, path)
+        return path
+
+    def load_checkpoint(self, path, resume_optimizer=True):
+        """Weights (and, when present and asked for, the AdamW state) from a checkpoint written by save_checkpoint or by the
+        reference's Lightning trainer (its optimizer state is per-tensor and is not read)."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        sd = ck.get("state_dict", ck)
+        self.transformer.load_state_dict({k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")})
+        if resume_optimizer and ck.get("optimizer_states") and "exp_avg" in ck["optimizer_states"][0]:
+            old = getattr(self, "trainer", None)       # parameter tensors were re-created by load_state_dict: new table
+            self.make_trainer(dict(lr=old.lr) if old else None, dist=old.dist if old else None)
+            self.trainer.load_optimizer_state(ck["optimizer_states"][0])
+        return ck
 
     def complete(self, Xct, **kw):
         kw.setdefault("mask_invalid", self.representer.mask_invalid)

@@ -313,6 +313,17 @@ class GPTTrainer:
         self._wT.clear()                 # transposed copies are stale now
         self.g.mark_decode_weights_stale()  # LN-folded / fragment-packed decode weights are rebuilt at the next decode use
 
+    def optimizer_state(self):
+        """Resume state: AdamW moments (flat, in parameter-table order) and the step count."""
+        return dict(step=self.step_count, exp_avg=self.flat_m.detach().cpu(), exp_avg_sq=self.flat_v.detach().cpu(),
+                    names=[n for n, _, _ in self.params])
+
+    def load_optimizer_state(self, st):
+        assert st["names"] == [n for n, _, _ in self.params], "optimizer state does not match this parameter table"
+        self.step_count = int(st["step"])
+        self.flat_m.copy_(st["exp_avg"].to(self.dev))
+        self.flat_v.copy_(st["exp_avg_sq"].to(self.dev))
+
     @torch.no_grad()
     def training_step(self, c_indices, z_indices):
         loss = self.loss_and_grad(c_indices, z_indices, sync=True)

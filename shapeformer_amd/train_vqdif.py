@@ -464,6 +464,15 @@ class VQDIFTrainer:
         self.optimizer_step()
         return out
 
+    def optimizer_state(self):
+        return dict(step=self.step_count, exp_avg=self.flat_m.detach().cpu(), exp_avg_sq=self.flat_v.detach().cpu(), names=list(self.names))
+
+    def load_optimizer_state(self, st):
+        assert st["names"] == list(self.names), "optimizer state does not match this parameter table"
+        self.step_count = int(st["step"])
+        self.flat_m.copy_(st["exp_avg"].to(self.dev))
+        self.flat_v.copy_(st["exp_avg_sq"].to(self.dev))
+
     def state_dict(self):
         """Reference layouts / key names (usable by VQDIF.load_state_dict and torch.save as a Lightning `state_dict`)."""
         sd = {}

@@ -139,3 +139,47 @@ def test_res32_reconstruction_callback(dev, tmp_path):
     assert comp["quant_ind"].shape == (1, 32, 32, 32) and comp["logits"].shape == (1, 48 ** 3, 1)
     assert comp["sparse"][:, 1].max() < 32768 and comp["sparse"][:, 2].max() < 4096
     assert os.path.exists(tmp_path / "vq32" / "meshes" / "0.ply") and "recon_mesh" in out["0"]
+
+
+def test_checkpoint_resume_is_bit_exact_for_both_models(dev, tmp_path):
+    """SURVEY §5 checkpoint/resume: Lightning-layout .ckpt (state_dict with the reference key names + optimizer state);
+    a run resumed from the file continues with exactly the losses of the uninterrupted run."""
+    from shapeformer_amd import plugin as P, synthetic
+    b = synthetic.make_batch(9, 2, n_full=8192, n_partial=4096)
+    batch = {k: torch.from_numpy(v) for k, v in b.items()}
+
+    def steps(model, n, seed0):
+        out = []
+        for i in range(n):
+            np.random.seed(seed0 + i)             # get_indices('train') draws the condition subset from numpy
+            out.append(float(model.training_step(batch)))
+        return out
+    opt = P.get_opt(_opt())
+    m1 = P.instantiate_from_opt(opt["pl_model_opt"])
+    m1.make_trainer(dict(lr=1e-3))
+    steps(m1, 2, 0)
+    path = m1.save_checkpoint(str(tmp_path / "ck" / "sf.ckpt"), hyper_parameters=opt["pl_model_opt"]["kwargs"])
+    want = steps(m1, 2, 2)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert "transformer.blocks.0.1.attn.key.weight" in ck["state_dict"] and "transformer.blocks.1.0.attn.mask" in ck["state_dict"]
+    assert "representer.vqvae_model.encoder.fc_pos.weight" in ck["state_dict"] and ck["global_step"] == 2
+    m2 = P.instantiate_from_opt(opt["pl_model_opt"])
+    m2.make_trainer(dict(lr=1e-3))
+    m2.load_checkpoint(path)
+    assert m2.trainer.step_count == 2 and m2.trainer.lr == 1e-3
+    assert steps(m2, 2, 2) == want
+    # VQDIF: weights + EMA codebook + Adam state
+    rs = np.random.RandomState(0)
+    Xtg = rs.uniform(-1, 1, (2, 512, 3)).astype(np.float32)
+    vb = dict(Xbd=b["Xbd"], Xtg=Xtg, Ytg=(np.linalg.norm(Xtg, axis=-1, keepdims=True) < 0.5).astype(np.float32))
+    kw = P.default_vqdif_kwargs(16)
+    v1 = P.instantiate_from_opt({"class": "shapeformer.models.vqdif.vqdif.VQDIF", "kwargs": kw})
+    v1.make_trainer(dict(lr=1e-3))
+    [float(v1.training_step(vb)) for _ in range(2)]
+    vpath = v1.save_checkpoint(str(tmp_path / "ck" / "vq.ckpt"))
+    want = [float(v1.training_step(vb)) for _ in range(2)]
+    v2 = P.VQDIFModel.load_from_checkpoint(vpath)           # the reference's own loading route (hyper_parameters + state_dict)
+    v2.make_trainer(dict(lr=1e-3))
+    v2.resume(vpath)
+    assert v2.trainer.step_count == 2
+    assert [float(v2.training_step(vb)) for _ in range(2)] == want
