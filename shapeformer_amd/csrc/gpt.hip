@@ -1083,7 +1083,11 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
   const int kslice = K / S;
   if (M > 96) return sfmi_decode_gemm_wide_f32(x, Wp16, c1, c2, resid, out, M, N, K, ldo, ln, act, out_packed, S, slab, cnt, stream);
+#ifdef DG_FORCE_NW    // tuning hook of tools/ubench/dgemm_chain.hip
+  const int NWv = DG_FORCE_NW;
+#else
   const int NWv = (kslice >= 2048 && M <= 64) ? 16 : 8;
+#endif
   if (kslice % (16 * NWv)) return SFMI_EINVAL;
   DGemmArgs a;
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
@@ -1093,6 +1097,9 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   const int MT = (M + 15) / 16;
   const int steps = kslice / NWv / 16;
   int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 4 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave
+#ifdef DG_FORCE_UN
+  un = DG_FORCE_UN;
+#endif
   while (un > 1 && steps % un) un >>= 1;
 #define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
 #define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
