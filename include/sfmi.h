@@ -27,10 +27,6 @@ extern "C" {
 #define SFMI_ENOBLAS (-3) /* rocBLAS could not be bound (csrc/blas.hip); callers fall back to the tile kernels */
 
 int sfmi_version(void);
-/* [host] a stream restricted to CUs i with (i % of) < every (hipExtStreamCreateWithCUMask): lets a throughput pipeline run the
- * MFMA-bound decode stage of one batch beside the decode chains of the next without occupying every CU */
-int sfmi_stream_create_cu_subset(int every, int of, int total_cus, void** stream_out);
-int sfmi_stream_destroy(void* stream);
 
 /* ---- VQDIF encoder, per-point path: enc.py:95-140 (LocalPoolPointnet.forward up to scatter_mean), layers.py:39-48,
  *      vqdif/common.py:260-321, torch_scatter.scatter_max / scatter_mean call sites enc.py:70-74,103-110 ---------- */

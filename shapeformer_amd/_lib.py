@@ -40,8 +40,6 @@ PROTOTYPES = {
     "sfmi_vq_stats_f32": (i32, [c_ptr] * 4 + [i64, i32, c_ptr]),
     "sfmi_vq_ema_update_f32": (i32, [c_ptr] * 5 + [i32, i32, f32, f32, c_ptr]),
     "sfmi_conv3d_wgrad_f32": (i32, [c_ptr] * 3 + [i32] * 12 + [c_ptr]),
-    "sfmi_stream_create_cu_subset": (i32, [i32, i32, i32, c_ptr]),
-    "sfmi_stream_destroy": (i32, [c_ptr]),
     "sfmi_blas_available": (i32, []),
     "sfmi_sgemm_f32": (i32, [i32] * 5 + [f32, c_ptr, i32, c_ptr, i32, f32, c_ptr, i32, c_ptr]),
     "sfmi_gemm_blas_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [c_ptr]),

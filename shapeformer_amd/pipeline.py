@@ -75,13 +75,7 @@ class ShapeCompletion:
         from .vqdif import VQDIF
         if not hasattr(self, "_dec_vq"):
             self._dec_vq = VQDIF(self.vq.state_dict_np(), res=self.vq.res, device=self.vq.dev, vocab_size=self.vq.K)
-            import ctypes, os
-            from . import _lib as L
-            every, of = (int(x) for x in os.environ.get("SFMI_DECODE_CUS", "3/16").split("/"))
-            h = ctypes.c_void_p()
-            ncu = torch.cuda.get_device_properties(self.vq.dev).multi_processor_count
-            L.check(L.lib().sfmi_stream_create_cu_subset(every, of, ncu, ctypes.byref(h)), "sfmi_stream_create_cu_subset")
-            self._dec_stream = torch.cuda.ExternalStream(h.value, device=self.vq.dev)
+            self._dec_stream = torch.cuda.Stream(device=self.vq.dev, priority=0)
         g, cur = self.gpt, torch.cuda.current_stream()
         pending = None
 
@@ -109,7 +103,7 @@ class ShapeCompletion:
             if pending is not None:
                 ready = finish(pending)      # enqueue the previous batch's decode BEFORE this batch's chains: it runs under them
             if n_micro > 1:
-                res = g.sample_microbatched(enc["c_tokens"], enc["Lc"], n_micro=n_micro, **skw)
+                res = g.sample_microbatched(enc["c_tokens"], enc["Lc"], n_micro=n_micro, high_priority=True, **skw)
             else:
                 res = g.sample(enc["c_tokens"], enc["Lc"], to_host=False, **skw)
                 res = dict(res, state={k: res["state"][k].clone() for k in ("seq", "len", "Lc", "logp")})   # pooled state: next batch reuses it
