@@ -37,7 +37,6 @@ def parse():
     ap.add_argument("--ar-steps", type=int, default=512)
     ap.add_argument("--decode-res", type=int, default=128)
     ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--pipeline", type=int, default=0, help="1: decode stage of batch i overlapped with the AR chains of batch i+1 (ShapeCompletion.complete_pipelined)")
     ap.add_argument("--micro", type=int, default=None, help="micro-batches of the AR loop (default: ceil(B/64); 2 for 32..64 rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -243,21 +242,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(n, seed0):
-        if not a.pipeline:
-            for i in range(n):
-                out = step(seed0 + i)
-            return out
-        out = None
-        for out in pipe.complete_pipelined((Xct for _ in range(n)), seeds=list(range(seed0, seed0 + n)), max_steps=a.ar_steps,
-                                           decode_res=a.decode_res, sigmoid=True, stop_early=False, n_micro=a.micro):
-            pass
-        return out
-
-    r = run(a.warmup, 0) if a.warmup else None
+    for i in range(a.warmup):
+        r = step(i)
     barrier()
     t0 = time.perf_counter()
-    r = run(a.steps, a.warmup)
+    for i in range(a.steps):
+        r = step(a.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

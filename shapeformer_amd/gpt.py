@@ -508,7 +508,7 @@ class CondTupleGPT:
     @torch.no_grad()
     def sample_microbatched(self, c_tokens, Lc, n_micro=2, max_steps=512, top_k=100, top_p=0.4, temperature=1.0,
                             best_in_first=True, mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True,
-                            check_every=32, after_prefill=None, high_priority=False):
+                            check_every=32, after_prefill=None):
         """Same result as `sample(..., to_host=False)` (identical tokens: the uniform stream and the greedy row are
         indexed by GLOBAL row), but the rows are split into `n_micro` independent micro-batches whose decode steps are
         separate hipGraphs replayed on separate HIP streams: one micro-batch's HBM-bound attention overlaps the other's
@@ -523,9 +523,8 @@ class CondTupleGPT:
         steps = min(c["steps"] for c in ctxs)
         if after_prefill is not None:
             after_prefill()
-        if not hasattr(self, "_mb_streams") or len(self._mb_streams) < len(ctxs) or getattr(self, "_mb_prio", False) != high_priority:
-            self._mb_streams = [torch.cuda.Stream(device=self.dev, priority=-1 if high_priority else 0) for _ in ctxs]
-            self._mb_prio = high_priority
+        if not hasattr(self, "_mb_streams") or len(self._mb_streams) < len(ctxs):
+            self._mb_streams = [torch.cuda.Stream(device=self.dev) for _ in ctxs]
         cur = torch.cuda.current_stream()
         for s in self._mb_streams[:len(ctxs)]:
             s.wait_stream(cur)

@@ -67,56 +67,6 @@ class ShapeCompletion:
                     dense=dense, occupancy=out["logits"][..., 0], log_prob=st["logp"])
 
     @torch.no_grad()
-    def complete_pipelined(self, batches, seeds=None, max_steps=512, decode_res=128, sigmoid=True, **kw):
-        """Throughput mode over a stream of batches: yields the same dicts as `complete`, one batch late.  The decode stage
-        (UNet3D + up-sampler + SDF query: MFMA-bound, ~13 % of a batch) of batch i runs on its own LOW-priority HIP stream,
-        with a second set of decoder buffers, while the HIGH-priority decode chains of batch i+1 stream the KV caches
-        (HBM-bound).  Per batch the arithmetic and the results are those of `complete`."""
-        from .vqdif import VQDIF
-        if not hasattr(self, "_dec_vq"):
-            self._dec_vq = VQDIF(self.vq.state_dict_np(), res=self.vq.res, device=self.vq.dev, vocab_size=self.vq.K)
-            self._dec_stream = torch.cuda.Stream(device=self.vq.dev, priority=0)
-        g, cur = self.gpt, torch.cuda.current_stream()
-        pending = None
-
-        def finish(p):
-            enc, st, steps, ev = p
-            for t in (st["seq"], st["len"], st["Lc"], enc["empty_index"]):
-                t.record_stream(self._dec_stream)          # allocated on the caller's stream, read on the decode stream
-            with torch.cuda.stream(self._dec_stream):
-                self._dec_stream.wait_event(ev)
-                dense = T.sparse2dense_dev(st["seq"], st["len"], enc["empty_index"], self.R, self.end, start=st["Lc"])
-                out = self._dec_vq.decode_index(dense, grid_Q=decode_res, sigmoid=sigmoid)
-                done = torch.cuda.Event()
-                done.record()
-            return dict(c_ind=enc["c_tokens"], Lc=enc["Lc"], empty_index=enc["empty_index"], state=st, steps=steps, dense=dense,
-                        occupancy=out["logits"][..., 0], log_prob=st["logp"], ready=done)
-        for i, Xct in enumerate(batches):
-            enc = self.encode_cloud(Xct)
-            enc = {k: v.clone() for k, v in enc.items()}           # the encoder's pooled buffers are reused by the next batch
-            B = Xct.shape[0]
-            n_micro = kw.get("n_micro") or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
-            skw = dict(max_steps=max_steps, top_k=kw.get("top_k", 100), top_p=kw.get("top_p", 0.4), temperature=kw.get("temperature", 1.0),
-                       best_in_first=kw.get("best_in_first", False), mask_invalid=kw.get("mask_invalid", True),
-                       mask_invalid_completion=kw.get("mask_invalid_completion", True), seed=seeds[i] if seeds is not None else i,
-                       stop_early=kw.get("stop_early", True))
-            if pending is not None:
-                ready = finish(pending)      # enqueue the previous batch's decode BEFORE this batch's chains: it runs under them
-            if n_micro > 1:
-                res = g.sample_microbatched(enc["c_tokens"], enc["Lc"], n_micro=n_micro, high_priority=True, **skw)
-            else:
-                res = g.sample(enc["c_tokens"], enc["Lc"], to_host=False, **skw)
-                res = dict(res, state={k: res["state"][k].clone() for k in ("seq", "len", "Lc", "logp")})   # pooled state: next batch reuses it
-            ev = torch.cuda.Event()
-            ev.record()
-            if pending is not None:
-                yield ready
-            pending = (enc, res["state"], res["steps"], ev)
-        if pending is not None:
-            yield finish(pending)
-        cur.wait_stream(self._dec_stream)
-
-    @torch.no_grad()
     def reconstruct(self, Xbd, decode_res=128, max_length=512, sigmoid=False):
         """VisSparseRecon3D.compute_batch (vqdif.py:243-269): quantize -> sparse -> dense -> decode_index."""
         q, mode, raw, mask, latent = self.vq.quantize_cloud_dev(Xbd, per_shape_mode=False)
