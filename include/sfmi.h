@@ -82,13 +82,18 @@ int sfmi_sgemm_f32(int transA, int transB, int M, int N, int K, float alpha, con
                    float beta, float* C, int ldc, void* stream);
 int sfmi_gemm_blas_f32(const float* x, const float* W, const float* bias, const float* resid, float* y, int M, int N, int K, int act,
                        void* stream);
+/* get_embeddings (mingpt.py:256-286) + AR_N extra index (representers.py:188-196,432-442) + ln1 of the first block, one
+ * row per (b,t<P) (P == 0: one row per sequence at t = len[b]-1); extra_out receives the extra index used (for the backward) */
 int sfmi_gpt_embed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                        const int* seq, const int* len, const int* Lc, const int* nval, const int* extra, int* extra_out,
                        float* resid_out, float* xn, const float* gamma, const float* beta, int B, int P, int D, int Lmax,
                        int end0, const int* rowoff, int M_packed, void* stream);
+/* residual add + LayerNorm of Block.forward (mingpt.py:107-111): x = resid + sum_s part[s] + bias (+ tok_embs[0][next pos] at
+ * the stage boundary, mingpt.py:294); resid_out = x, xn = LN(x) */
 int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* bias, const float* Eadd, const int* seq,
                          const int* len, const int* Lc, const int* nval, float* resid_out, float* xn, const float* gamma,
                          const float* beta, int S, int M, int P, int D, int Lmax, const int* rowoff, int B, void* stream);
+/* CausalSelfAttention.forward over the rows of a prefix (mingpt.py:73-91) on f32 MFMA; also writes the (B,H,Lmax,64) KV caches */
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                               int Lmax, const int* rowoff, void* stream);
 int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream); /* shapeformer.py:132-140 */
@@ -101,11 +106,17 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
 /* same contract, always the two-n-tiles-per-wave kernel (sfmi_decode_gemm_f32 routes M > 96 here) */
 int sfmi_decode_gemm_wide_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
                               int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, void* stream);
+/* embedding of the token at t = len[b]-1 into the fragment-packed residual buffer (input of the first decode step) */
 int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                               const int* seq, const int* len, const int* Lc, float* resid, int B, int D, int Lmax, int end0,
                               void* stream);
+/* CausalSelfAttention.forward for ONE new position per row against the KV cache (appends the new K,V row first) */
 int sfmi_gpt_attn_decode_f32(const float* qkv_packed, const float* unused, float* Kc, float* Vc, const int* len, float* y_packed,
                              int S, int B, int D, int H, int Lmax, void* stream);
+/* one tuple element of one sampling step per row: sampling_masker (representers.py:120-155) + filter_sampling_logits /
+ * sample_logits (models/common.py:260-299: temperature, top-k with ties, top-p) + inverse-CDF draw from counter-hash uniforms
+ * indexed (step, tuple, row_offset + b) + best_in_first greedy row + log-prob + optional masked-logit history; writes the
+ * token into seq, and the next GEMM input (tok_embs add / next position's embedding) into `resid` */
 int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, float* logp, float* hist, const int* force,
                         float* resid, const float* E0, const float* E1, const float* Ex, const float* pos_emb, int D, int S,
                         int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
