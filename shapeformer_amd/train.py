@@ -108,6 +108,13 @@ class GPTTrainer:
         """grad[gname] (N,K) += dY^T (N,M) X (M,K)  via NT GEMM on transposed activations (K-dim = M padded to 16)."""
         if self._blas() and M >= 256:      # dY^T X directly (transposed left operand), accumulating when asked to
             out = self.grad[gname]
+            if N > K and not self._acc and M >= 1024:
+                # tall outputs (4096 x 1024) hit a slow library kernel (86 vs 141 TFLOP/s for the wide 1024 x 4096 form):
+                # form dW^T = X^T dY and transpose the 16 MB result
+                tmp = self._f(K, N)
+                L.check(L.lib().sfmi_sgemm_f32(1, 0, K, N, M, 1.0, L.ptr(X), K, L.ptr(dY), N, 0.0, L.ptr(tmp), N, L.stream_ptr()), "sgemm dW^T")
+                L.check(L.lib().sfmi_transpose_f32(L.ptr(tmp), L.ptr(out), K, N, N, K, L.stream_ptr()), "transpose")
+                return
             L.check(L.lib().sfmi_sgemm_f32(1, 0, N, K, M, 1.0, L.ptr(dY), N, L.ptr(X), K, 1.0 if self._acc else 0.0, L.ptr(out), K,
                                            L.stream_ptr()), "sgemm dW")
             return
