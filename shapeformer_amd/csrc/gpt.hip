@@ -543,6 +543,20 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
   const int nq4 = HD / 4;
   float* Kb = Kc + ((long long)b * H + h) * Lmax * HD;
   float* Vb = Vc + ((long long)b * H + h) * Lmax * HD;
+  const int c4 = lane & 15, kk = lane >> 4;
+  const bool cok = c4 < nq4;
+  // the first 256 keys' loads are issued BEFORE the q/k/v hand-off barrier (they only need `t`): the HBM latency of the
+  // first batch overlaps the LDS round trip instead of following it
+  auto load_k = [&](int i0, f32x4 (&kf)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 + wave * 4 + kk;
+      kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Kb + (long long)i * HD + 4 * c4));
+    }
+  };
+  f32x4 kf0[4];
+  load_k(0, kf0);
   if (tid < HD) {
     // qkv is the fragment-packed (M x 3D) output of the fused LN+QKV GEMM (bias already included)
     const float q = qkv_part[pk_off(b, h * HD + tid, 3 * D)];
@@ -553,24 +567,15 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
     Vb[(long long)t * HD + tid] = v;
   }
   __syncthreads();
-  const int c4 = lane & 15, kk = lane >> 4;
-  const bool cok = c4 < nq4;
   f32x4 qf = {0.f, 0.f, 0.f, 0.f};
   if (cok) qf = *reinterpret_cast<const f32x4*>(qs + 4 * c4);
   float lmax = -INFINITY;
   // keys i = it*64 + wave*4 + kk ; 4 iterations in flight
-  for (int i0 = 0; i0 <= t; i0 += 256) {
-    f32x4 kf[4];
+  auto score = [&](int i0, f32x4 (&kf)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * 64 + wave * 4 + kk;
-      kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Kb + (long long)i * HD + 4 * c4));
-      else if (i == t && cok) kf[u] = *reinterpret_cast<const f32x4*>(kn + 4 * c4);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 64 + wave * 4 + kk;
+      if (i == t && cok) kf[u] = *reinterpret_cast<const f32x4*>(kn + 4 * c4);     // the new token's key comes from LDS
       float d = (qf[0] * kf[u][0] + qf[1] * kf[u][1]) + (qf[2] * kf[u][2] + qf[3] * kf[u][3]);
       d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
       if (i <= t) {
@@ -578,7 +583,24 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
         lmax = fmaxf(lmax, d);
       }
     }
+  };
+  score(0, kf0);
+  for (int i0 = 256; i0 <= t; i0 += 256) {
+    f32x4 kf[4];
+    load_k(i0, kf);
+    score(i0, kf);
   }
+  // same for the values: the first 256 rows are requested before the softmax barrier
+  auto load_v = [&](int i0, f32x4 (&vf)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 + wave * 4 + kk;
+      vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vb + (long long)i * HD + 4 * c4));
+    }
+  };
+  f32x4 vf0[4];
+  load_v(0, vf0);
   lmax = wave_max(lmax);
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
@@ -588,20 +610,21 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
   // y = sum_i p_i V[i], p_i = exp(s_i - gmax); the 1/sum is applied at the end
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float ls = 0.f;
-  for (int i0 = 0; i0 <= t; i0 += 256) {
-    f32x4 vf[4];
-    float pr[4];
+  auto accum = [&](int i0, f32x4 (&vf)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * 64 + wave * 4 + kk;
-      vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      pr[u] = 0.f;
-      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vb + (long long)i * HD + 4 * c4));
-      else if (i == t && cok) vf[u] = *reinterpret_cast<const f32x4*>(vn + 4 * c4);
-      if (i <= t) pr[u] = __expf(sc[i] - gmax);
+      if (i == t && cok) vf[u] = *reinterpret_cast<const f32x4*>(vn + 4 * c4);
+      const float pr = i <= t ? __expf(sc[i] - gmax) : 0.f;
+      acc = acc + vf[u] * pr;
+      ls += pr;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { acc = acc + vf[u] * pr[u]; ls += pr[u]; }
+  };
+  accum(0, vf0);
+  for (int i0 = 256; i0 <= t; i0 += 256) {
+    f32x4 vf[4];
+    load_v(i0, vf);
+    accum(i0, vf);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) { acc[e] += __shfl_xor(acc[e], 16, 64); acc[e] += __shfl_xor(acc[e], 32, 64); }
