@@ -325,3 +325,34 @@ def instantiate_from_opt(opt):
     if "class" not in opt or opt["class"] is None:
         return None
     return load_object(opt["class"])(**opt.get("kwargs", dict()))
+
+
+def install_aliases(force=False):
+    """Make the reference's dotted module paths importable: after this call
+    `importlib.import_module("shapeformer.models.vqdif.vqdif").VQDIF` (i.e. the reference's own `sysutil.load_object`,
+    xgutils/sysutil.py:148-152, or a `class:` entry resolved by third-party code) yields the MI355X-native classes.  Synthetic
+    modules are registered in sys.modules; nothing is done when a real `shapeformer` package is importable (force=True
+    shadows it for the names this package provides)."""
+    import importlib.util
+    import sys
+    import types
+    if not force and "shapeformer" not in sys.modules and importlib.util.find_spec("shapeformer") is not None:
+        return False
+    from . import data
+    table = dict(REGISTRY)
+    table.update(data.DATA_REGISTRY)
+    table["shapeformer.datamodule.DataModule"] = data.DataModule
+    for path, obj in table.items():
+        mod_path, name = path.rsplit(".", 1)
+        parts = mod_path.split(".")
+        for i in range(1, len(parts) + 1):
+            mp = ".".join(parts[:i])
+            if mp not in sys.modules or force and not getattr(sys.modules[mp], "__sfmi_alias__", False):
+                m = types.ModuleType(mp)
+                m.__sfmi_alias__ = True
+                m.__path__ = []
+                sys.modules[mp] = m
+                if i > 1:
+                    setattr(sys.modules[".".join(parts[:i - 1])], parts[i - 1], m)
+        setattr(sys.modules[mod_path], name, obj)
+    return True

@@ -153,3 +153,24 @@ def test_two_process_gloo_sharding(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("OK" in o for o in outs), outs
+
+
+def test_reference_dotted_paths_become_importable():
+    """B1: `importlib.import_module("shapeformer....")` - what the reference's own sysutil.load_object does - resolves to the
+    native classes once plugin.install_aliases() ran (synthetic modules; the reference tree is not on sys.path here)."""
+    import importlib
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from shapeformer_amd import plugin as P, data as D\n"
+        "assert P.install_aliases()\n"
+        "import importlib\n"
+        "m = importlib.import_module('shapeformer.models.vqdif.vqdif')\n"
+        "assert m.VQDIF is P.VQDIFModel and callable(m.VisSparseRecon3D)\n"
+        "assert importlib.import_module('shapeformer.models.shapeformer.transformer.mingpt').CondTupleGPT is P.CondTupleGPTModel\n"
+        "assert importlib.import_module('shapeformer.data.partial').VirtualScanSelector is D.VirtualScanSelector\n"
+        "from shapeformer.models.shapeformer.representers import AR_N\n"
+        "assert AR_N is P.ARNRepresenter\n"
+        "import shapeformer.datamodule as dm; assert dm.DataModule is D.DataModule\n"
+        "print('OK')\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr
