@@ -47,6 +47,11 @@ int sfmi_conv_pack_weight(const float* w, int Cout, int Cin, int KS, float* out)
 int sfmi_conv3d_cl_f32(const float* x, const float* wT, const float* in_scale, const float* in_shift, const float* bias,
                        float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int KS, int stride, int pad, int up,
                        int relu, void* stream);
+/* Conv3d(k3,p1) of a nearest-x2-upsampled grid as 8 parity-wise 2^3 convolutions of the low-resolution grid with pre-summed
+ * weights (8/27 of the FLOPs; updown.py:119-132 Upsample + conv): [host] packer + launcher.  x (B,Di,Hi,Wi,Cin) -> y (B,2Di,..,Cout) */
+int sfmi_conv_pack_weight_subpixel(const float* w, int Cout, int Cin, float* out);   /* out: 64*Cout*Cin floats */
+int sfmi_conv3d_up2_cl_f32(const float* x, const float* wsub, const float* in_scale, const float* in_shift, const float* bias,
+                           float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int relu, void* stream);
 int sfmi_gn_splits(int V);
 /* nn.GroupNorm statistics -> scale/shift (B,C) with GN(x) == x*scale+shift; partial: B*sfmi_gn_splits(V)*C*2 doubles */
 int sfmi_groupnorm_coeffs_f32(const float* x, const float* gamma, const float* beta, float* scale, float* shift,

@@ -58,6 +58,8 @@ PROTOTYPES = {
     # conv / groupnorm / pooling
     "sfmi_conv_pack_weight": (i32, [c_ptr, i32, i32, i32, c_ptr]),
     "sfmi_conv3d_cl_f32": (i32, [c_ptr] * 6 + [i32] * 11 + [c_ptr]),
+    "sfmi_conv_pack_weight_subpixel": (i32, [c_ptr, i32, i32, c_ptr]),
+    "sfmi_conv3d_up2_cl_f32": (i32, [c_ptr] * 6 + [i32] * 7 + [c_ptr]),
     "sfmi_gn_splits": (i32, [i32]),
     "sfmi_groupnorm_coeffs_f32": (i32, [c_ptr] * 6 + [i32, i32, i32, i32, C.c_float, c_ptr]),
     "sfmi_affine_cl_f32": (i32, [c_ptr] * 4 + [i32, i64, i32, c_ptr]),

@@ -23,6 +23,10 @@ struct ConvArgs {
   const float* resid;                     // optional residual added in the epilogue (same row mapping as y)
   long long out_group, out_group_stride;  // output row remap: m -> (m/out_group)*out_group_stride + m%out_group
   int B, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout, KS, stride, pad, up, relu /*0 none, 1 relu, 2 gelu(erf)*/;
+  // sub-pixel mode (sp_on): this launch computes the outputs of ONE parity (spz,spy,spx) of a nearest-x2-upsampled conv:
+  // leading pad per axis padz/pady/padx (instead of `pad`), output voxel (z,y,x) of the (Do,Ho,Wo) lattice is written to
+  // voxel (2z+spz, 2y+spy, 2x+spx) of the (2Do,2Ho,2Wo) result
+  int sp_on, spz, spy, spx, padz, pady, padx;
 };
 
 template <int CO_TILES, int WM, int WN>
@@ -63,7 +67,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
     int xw = (int)(m % a.Wo); long long r = m / a.Wo;
     int yh = (int)(r % a.Ho); r /= a.Ho;
     int zd = (int)(r % a.Do);
-    vb[i] = (int)(r / a.Do); vz[i] = zd * a.stride - a.pad; vy[i] = yh * a.stride - a.pad; vx[i] = xw * a.stride - a.pad;
+    vb[i] = (int)(r / a.Do);
+    vz[i] = zd * a.stride - (a.sp_on ? a.padz : a.pad); vy[i] = yh * a.stride - (a.sp_on ? a.pady : a.pad);
+    vx[i] = xw * a.stride - (a.sp_on ? a.padx : a.pad);
   }
   const int cpt = a.Cin / KC;                 // chunks per tap
   const int nchunks = a.KS * a.KS * a.KS * cpt;
@@ -142,7 +148,14 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
   for (int j = 0; j < 2; ++j) {
     const long long m_in = m0 + wn * 64 + j * 32 + pl;
     if (m_in >= M) continue;
-    const long long m = a.out_group ? (m_in / a.out_group) * a.out_group_stride + m_in % a.out_group : m_in;
+    long long m = a.out_group ? (m_in / a.out_group) * a.out_group_stride + m_in % a.out_group : m_in;
+    if (a.sp_on) {
+      const int xw = (int)(m_in % a.Wo); long long r = m_in / a.Wo;
+      const int yh = (int)(r % a.Ho); r /= a.Ho;
+      const int zd = (int)(r % a.Do);
+      const long long bb = r / a.Do;
+      m = ((bb * 2 * a.Do + 2 * zd + a.spz) * 2 * a.Ho + 2 * yh + a.spy) * 2 * a.Wo + 2 * xw + a.spx;
+    }
 #pragma unroll
     for (int i = 0; i < CO_TILES; ++i) {
       const int cob = n0 + (wm * CO_TILES + i) * 32 + 4 * hi;
@@ -316,6 +329,7 @@ int sfmi_conv3d_cl_f32(const float* x, const float* wT, const float* in_scale, c
   a.x = x; a.wT = wT; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.y = y;
   a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KS = KS; a.stride = stride; a.pad = pad;
   a.up = up; a.relu = relu; a.resid = nullptr; a.out_group = 0; a.out_group_stride = 0;
+  a.sp_on = 0; a.spz = a.spy = a.spx = 0; a.padz = a.pady = a.padx = 0;
   a.Do = ((Di << up) + 2 * pad - KS) / stride + 1;
   a.Ho = ((Hi << up) + 2 * pad - KS) / stride + 1;
   a.Wo = ((Wi << up) + 2 * pad - KS) / stride + 1;
@@ -333,7 +347,56 @@ int sfmi_gemm_f32(const float* x, const float* W, const float* bias, const float
   a.out_group = out_group; a.out_group_stride = out_group_stride;
   a.B = 1; a.Di = 1; a.Hi = 1; a.Wi = (int)M; a.Do = 1; a.Ho = 1; a.Wo = (int)M; a.Cin = K; a.Cout = N; a.KS = 1;
   a.stride = 1; a.pad = 0; a.up = 0; a.relu = act;
+  a.sp_on = 0; a.spz = a.spy = a.spx = 0; a.padz = a.pady = a.padx = 0;
   return conv_dispatch(a, stream);
+}
+
+// Conv3d(k=3, pad=1) over a nearest-x2-upsampled input WITHOUT the 19 redundant taps: the three taps of an axis read only
+// two distinct low-resolution voxels, so each of the 8 output parities is a 2^3 convolution of the low-resolution grid with
+// pre-summed weights (even parity: [w0, w1+w2] at offsets (-1, 0); odd: [w0+w1, w2] at (0, +1)); zero padding and the
+// per-channel input affine commute with the merge.  8/27 of the FLOPs of the direct form; results differ from it by fp32
+// rounding of the weight sums only.
+// [host] w (Cout,Cin,3,3,3) -> out [parity = 4 pz + 2 py + px][tap = 4 dz + 2 dy + dx][Cout][Cin]
+int sfmi_conv_pack_weight_subpixel(const float* w, int Cout, int Cin, float* out) {
+  if (!w || !out) return SFMI_EINVAL;
+  // 1-D merge: M[p][d][t] = 1 if original tap t contributes to merged tap d of parity p
+  static const int Mg[2][2][3] = {{{1, 0, 0}, {0, 1, 1}}, {{1, 1, 0}, {0, 0, 1}}};
+  for (int par = 0; par < 8; ++par) {
+    const int pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
+    for (int tap = 0; tap < 8; ++tap) {
+      const int dz = tap >> 2, dy = (tap >> 1) & 1, dx = tap & 1;
+      float* o = out + ((size_t)par * 8 + tap) * Cout * Cin;
+      for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+          float s = 0.f;
+          for (int tz = 0; tz < 3; ++tz)
+            for (int ty = 0; ty < 3; ++ty)
+              for (int tx = 0; tx < 3; ++tx)
+                if (Mg[pz][dz][tz] && Mg[py][dy][ty] && Mg[px][dx][tx]) s += w[(((size_t)co * Cin + ci) * 3 + tz) * 9 + ty * 3 + tx];
+          o[(size_t)co * Cin + ci] = s;
+        }
+    }
+  }
+  return SFMI_OK;
+}
+
+// x (B,Di,Hi,Wi,Cin) low resolution -> y (B,2Di,2Hi,2Wi,Cout) = act(conv3(nearest_x2(affine(x))) + bias); 8 launches
+int sfmi_conv3d_up2_cl_f32(const float* x, const float* wsub, const float* in_scale, const float* in_shift, const float* bias,
+                           float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int relu, void* stream) {
+  if (!x || !wsub || !y || B <= 0 || Cin % KC || Cout % 32) return SFMI_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return SFMI_EINVAL;
+  for (int par = 0; par < 8; ++par) {
+    ConvArgs a;
+    a.x = x; a.wT = wsub + (size_t)par * 8 * Cout * Cin; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.y = y;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KS = 2; a.stride = 1; a.pad = 0; a.up = 0; a.relu = relu;
+    a.resid = nullptr; a.out_group = 0; a.out_group_stride = 0;
+    a.Do = Di; a.Ho = Hi; a.Wo = Wi;
+    a.sp_on = 1; a.spz = par >> 2; a.spy = (par >> 1) & 1; a.spx = par & 1;
+    a.padz = 1 - a.spz; a.pady = 1 - a.spy; a.padx = 1 - a.spx;
+    const int rc = conv_dispatch(a, stream);
+    if (rc != SFMI_OK) return rc;
+  }
+  return SFMI_OK;
 }
 
 int sfmi_gn_splits(int V) { return V >= 32768 ? 64 : (V >= 4096 ? 16 : (V >= 512 ? 4 : 1)); }

@@ -34,12 +34,22 @@ class _Conv:
         packed = np.empty(w.size, np.float32)
         L.check(L.lib().sfmi_conv_pack_weight(w.ctypes.data, self.cout, self.cin, ks, packed.ctypes.data), "conv_pack")
         self.w = torch.from_numpy(packed).to(dev)
+        self.w_up = None     # sub-pixel weights (set for the convs that follow a nearest-x2 upsample)
         self.gamma = self.beta = self.bias = None
         if (prefix + "groupnorm.weight") in sd:
             self.gamma = torch.from_numpy(_np(sd, prefix + "groupnorm.weight")).to(dev)
             self.beta = torch.from_numpy(_np(sd, prefix + "groupnorm.bias")).to(dev)
         if (prefix + "bias") in sd:
             self.bias = torch.from_numpy(_np(sd, prefix + "bias")).to(dev)
+        self._w_host = w
+
+    def pack_subpixel(self, dev):
+        """Pre-summed 2^3 weights of the 8 output parities for conv3(nearest_x2(x)) (csrc/conv3d.hip sfmi_conv3d_up2_cl_f32)."""
+        assert self.ks == 3 and self.pad == 1 and self.stride == 1
+        out = np.empty(64 * self.cout * self.cin, np.float32)
+        L.check(L.lib().sfmi_conv_pack_weight_subpixel(np.ascontiguousarray(self._w_host).ctypes.data, self.cout, self.cin, out.ctypes.data),
+                "conv_pack_subpixel")
+        self.w_up = torch.from_numpy(out).to(dev)
 
 
 class VQDIF:
@@ -97,6 +107,7 @@ class VQDIF:
         self.up = []
         for s in range(self.steps):
             self.up.append(_Conv(sd, f"decoder.upsampler.blocks.{3 * s + 1}.", dev, 3, 1, 1))
+            self.up[-1].pack_subpixel(dev)
             self.up.append(_Conv(sd, f"decoder.upsampler.blocks.{3 * s + 2}.", dev, 3, 1, 1))
         from .ops import sdf_pack_weights
         self.sdf_w = torch.from_numpy(sdf_pack_weights(sd)).to(dev)
@@ -115,6 +126,10 @@ class VQDIF:
         assert Cin == cv.cin, (Cin, cv.cin)
         Do = ((Di << up) + 2 * cv.pad - cv.ks) // cv.stride + 1
         y = self._buf(name, (B, Do, Do, Do, cv.cout))
+        if up and cv.w_up is not None:      # upsample + conv3 as 8 parity-wise 2^3 convolutions of the low-resolution grid
+            L.check(L.lib().sfmi_conv3d_up2_cl_f32(L.ptr(x), L.ptr(cv.w_up), L.ptr(scale), L.ptr(shift), L.ptr(bias), L.ptr(y),
+                                                   B, Di, Hi, Wi, Cin, cv.cout, int(relu), L.stream_ptr()), "sfmi_conv3d_up2_cl_f32")
+            return y
         L.check(L.lib().sfmi_conv3d_cl_f32(L.ptr(x), L.ptr(cv.w), L.ptr(scale), L.ptr(shift), L.ptr(bias), L.ptr(y),
                                            B, Di, Hi, Wi, Cin, cv.cout, cv.ks, cv.stride, cv.pad, up, int(relu),
                                            L.stream_ptr()), "sfmi_conv3d_cl_f32")
