@@ -31,8 +31,8 @@ import torch  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=192, help="shapes per GPU per step (decoded as ceil(B/64) interleaved micro-batches of <= 64 rows)")
     ap.add_argument("--ar-steps", type=int, default=512)
     ap.add_argument("--decode-res", type=int, default=128)
