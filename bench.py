@@ -40,7 +40,39 @@ def parse():
     ap.add_argument("--micro", type=int, default=None, help="micro-batches of the AR loop (default: ceil(B/64); 2 for 32..64 rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="keep the stage / AR-loop breakdown, skip the per-kernel roofline timings")
+    ap.add_argument("--mode", default="complete", choices=["complete", "train"],
+                    help="complete: the shapes/s metric (default); train: DDP training step of the transformer (BASELINE config 5)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="TEST ONLY: all ranks use cuda:0 and rendezvous over gloo (exercises the N-rank path on a 1-GPU box)")
+    ap.add_argument("--train-batch", type=int, default=1, help="--mode train: sequences per GPU per step (shapenet_scale.yaml: 1)")
+    ap.add_argument("--train-lc", type=int, default=200)
+    ap.add_argument("--train-lz", type=int, default=300)
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU,
+    rendezvous on 127.0.0.1) and hand over to them.  Under torchrun (WORLD_SIZE set) this is a no-op; a WORLD_SIZE that
+    disagrees with --gpus, or fewer visible GPUs than ranks, is an error - never a silent 1-rank run."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={env_world}")
+        return
+    if a.gpus == 1:
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus and not (a.share_device and n_dev >= 1):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} requested but only {n_dev} GPU(s) are visible")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.execvpe(sys.executable, cmd, env)
 
 
 def ev_time(fn, n, warm=2):
@@ -195,20 +227,90 @@ def cpu_baseline(points, ar_steps, decode_res):
                         f"({t_ar:.0f}s)"))
 
 
+def synth_tokens(seed, B, Lc, Lz):
+    """(pos,val) rows like the representer emits: ascending positions, end-token padded (representers.py:79-103)."""
+    rs = np.random.RandomState(seed)
+
+    def rows(L):
+        out = np.full((B, L, 2), 4096, np.int64)
+        for b in range(B):
+            n = rs.randint(L // 2, L)           # ragged: pad with end tokens like batch_dense2sparse does
+            out[b, :n, 0] = np.sort(rs.choice(4096, n, replace=False))
+            out[b, :n, 1] = rs.randint(0, 4096, n)
+        return out
+    return torch.from_numpy(rows(Lc)), torch.from_numpy(rows(Lz))
+
+
+def main_train(a, rank, world, dev, dist):
+    """BASELINE config 5: data-parallel training step of the (20+4)-layer d=1024 CondTupleGPT (forward, backward, bucketed
+    gradient all-reduce over RCCL overlapped with the backward, fused AdamW) on synthetic token batches; one process per
+    GPU.  A "step" = one optimizer step on `--train-batch` sequences per GPU of L_c + L_z - 1 tokens."""
+    from shapeformer_amd.gpt import CondTupleGPT
+    from shapeformer_amd.train import GPTTrainer
+    g = CondTupleGPT(device=dev)
+    tr = GPTTrainer(g, lr=1e-5, dist=dist)
+    c, z = synth_tokens(1000 + rank, a.train_batch, a.train_lc, a.train_lz)
+    losses = []
+    for _ in range(a.warmup):
+        losses.append(float(tr.training_step(c, z).item()))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.training_step(c, z)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    losses.append(float(loss.item()))
+    if rank == 0:
+        tok = world * a.train_batch * (a.train_lc + a.train_lz - 1) * a.steps
+        print(json.dumps({
+            "metric": "training tokens/s (CondTupleGPT 20+4 layers d1024, fwd+bwd+AdamW, DDP)", "value": round(tok / dt, 1),
+            "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ShapeFormer DDP training step, synthetic IMNet-style token batches (BASELINE config 5)",
+                       "batch_per_gpu": a.train_batch, "L_c": a.train_lc, "L_z": a.train_lz, "parallelism": f"dp{world}",
+                       "grad_sync": "26 gradient buckets (one per block) all-reduced under the backward pass"},
+            "model_TFLOPs": round(6 * 324.95e6 * tok / dt / 1e12, 2),
+            "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    launch_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if a.share_device:
+        local = 0
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if a.mode == "train":
+        return main_train(a, rank, world, dev, dist)
 
     from shapeformer_amd import synthetic
     from shapeformer_amd.gpt import CondTupleGPT
@@ -251,7 +353,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert int(r["steps"]) == a.ar_steps, f"only {r['steps']} of {a.ar_steps} AR steps were run"
@@ -288,6 +390,9 @@ def main():
                                "note": "algorithmic bytes: f32 KV cache of every row at its mean length + one weight stream per decode chain"}
             nm = a.micro or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
             Bk = -(-B // nm)     # rows per decode launch (micro-batch)
+            if a.no_kernels:
+                print(json.dumps(line), flush=True)
+                return
             ks = kernel_rooflines(vq, gpt, Bk, dev, lc_mean=sanity["Lc_mean"])
             # dominant kernel symbol of the decode step (>90 % of the run): the one with the larger per-layer time
             cands = [k for k in ks if k["kernel"].startswith(("dgemm_kernel", "attn_decode_kernel"))]

@@ -368,16 +368,23 @@ class CondTupleGPT:
         D = self.D
         lib = L.lib()
         r = st["resid"]
+        import os
+        skip = os.environ.get("SFMI_DECODE_SKIP", "")   # timing ablation hook (tools/sweep_dgemm.sh): results are garbage
+        if "@" in skip:      # per-chain form "gemm@0,attn@1,attn@2": chain index = micro-batch slot
+            skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
         # in-kernel split-K per GEMM: 64-row kernel (B <= 64) / wide kernel (one launch for up to 256 rows)
         Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if B > 96 else (1, self.S_PROJ if B <= 16 else 4, 1, self.S_FC2, 1)
         for li, ly in enumerate(self.layers):
-            self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
-            L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
-                                                 L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
-                                                 L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
-            self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st)
-            self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st)
-            self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=Sfc2, st=st)
+            if "gemm" not in skip:
+                self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
+            if "attn" not in skip:
+                L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
+                                                     L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
+                                                     L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
+            if "gemm" not in skip:
+                self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st)
+                self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st)
+                self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=Sfc2, st=st)
             if li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage:
                 s = ly.stage
                 hp, hc1, hc2 = self.head_f[s]
@@ -414,7 +421,7 @@ class CondTupleGPT:
         if return_logits:
             hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
         sp = dict(sp_kw, max_steps=int(max_steps), hist=hist, row_offset=int(row_offset),
-                  rows_total=int(rows_total if rows_total is not None else B))
+                  rows_total=int(rows_total if rows_total is not None else B), chain=int(slot - 100 if slot >= 100 else 0))
         if force_tokens is not None:   # (B,max_steps,2) teacher forcing for stepwise parity tests
             ft = torch.zeros(B, max_steps, 2, dtype=torch.int32)
             ft[:, :force_tokens.shape[1]] = torch.as_tensor(force_tokens).to(torch.int32)
