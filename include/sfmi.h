@@ -73,6 +73,8 @@ int sfmi_dense2sparse_i32(const int* q, const int* mode, int mode_per_row, int* 
                           int max_length, int end0, int end1, void* stream);
 int sfmi_sparse2dense_i32(const int* tokens, const int* start, const int* len, const int* empty, int empty_per_row, int* dense,
                           int B, int ncell, int Lpad, int end0, int end1, void* stream);
+/* AR_N.get_extra_indices + get_next_cond (representers.py:188-196, 432-442): c_pos (B,Lc), z_pos (B,Lz) -> extra (B,Lc+Lz) */
+int sfmi_ar_n_extra_i32(const int* c_pos, const int* z_pos, int* extra, int B, int Lc, int Lz, int end0, void* stream);
 
 /* ---- CondTupleGPT: transformer/mingpt.py:46-111 (Block), :256-310 (embeddings, two-stage tuple head),
  *      shapeformer.py:54-123 (sample_indices), representers.py:120-155,188-196,432-442, models/common.py:260-299 ---- */
@@ -126,7 +128,8 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
                         float* resid, const float* E0, const float* E1, const float* Ex, const float* pos_emb, int D, int S,
                         int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
                         float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
-                        unsigned seed, int advance, int row_offset, int rows_total, void* stream);
+                        unsigned seed, const unsigned* seed_dev /* optional device-resident seed (overrides `seed`) */, int advance,
+                        int row_offset, int rows_total, void* stream);
 int sfmi_set_len_i32(int* len, const int* src, int B, int delta, void* stream);
 
 /* ---- Training step of the transformer (csrc/train.hip): shapeformer.py:26-46,132-207 (forward/loss/AdamW groups),

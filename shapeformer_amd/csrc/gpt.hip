@@ -651,12 +651,14 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
 //   O (16 x 64) += P V     : P goes through a per-wave LDS tile to become an A operand; 4 d tiles x 16 k-steps
 // LDS row strides 68 (K, P: 16 rows x 4 k-columns per operand read hit 64 distinct banks) and 80 (V: 4 rows x 16 columns).
 // ------------------------------------------------------------------------------------------------
-constexpr int AP_KS = 68, AP_VS = 80;
+constexpr int AP_PS = 68;   // P tile row stride (16 rows x 64 keys)
+template <int HD>           // head dim 16 / 32 / 64
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
                                                                 float* __restrict__ Vc, const int* __restrict__ nval,
                                                                 float* __restrict__ y, int P, int D, int Lmax, float scale,
                                                                 const int* __restrict__ rowoff) {
-  __shared__ __attribute__((aligned(16))) float Ks[64 * AP_KS], Vs[64 * AP_VS], Ps[4][16 * AP_KS];
+  constexpr int AP_KS = HD + 4, AP_VS = HD + 16, KK = HD / 4, DT = HD / 16;
+  __shared__ __attribute__((aligned(16))) float Ks[64 * AP_KS], Vs[64 * AP_VS], Ps[4][16 * AP_PS];
   const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = min(P, max(nval[b], 0));
   const long long base = rowoff ? rowoff[b] : (long long)b * P;
@@ -664,30 +666,32 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
   if (q0 >= n) return;
   const int lr = lane & 15, lq = lane >> 4;
   // Q fragments (A operand: row lr, k = 4 kk + lq), pre-scaled
-  float qf[16];
+  float qf[KK];
   {
     const int tq = min(q0 + 16 * wave + lr, n - 1);
-    const float* qp = qkv + (base + tq) * 3 * D + h * 64 + lq;
+    const float* qp = qkv + (base + tq) * 3 * D + h * HD + lq;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) qf[kk] = qp[4 * kk] * scale;
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = qp[4 * kk] * scale;
   }
   float mrun[4], lrun[4];
-  f32x4 o[4];
+  f32x4 o[DT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; o[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int j = 0; j < 4; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int kend = min(n, q0 + 64);
   float* Pw = Ps[wave];
   for (int k0 = 0; k0 < kend; k0 += 64) {
     __syncthreads();
-    for (int i = tid; i < 64 * 16; i += 256) {
-      const int r = i >> 4, c = i & 15;
+    for (int i = tid; i < 64 * KK; i += 256) {
+      const int r = i / KK, c = i % KK;
       const int tk = min(k0 + r, n - 1);
-      const float* src = qkv + (base + tk) * 3 * D + h * 64 + 4 * c;
+      const float* src = qkv + (base + tk) * 3 * D + h * HD + 4 * c;
       const f32x4 kv = *reinterpret_cast<const f32x4*>(src + D), vv = *reinterpret_cast<const f32x4*>(src + 2 * D);
       *reinterpret_cast<f32x4*>(&Ks[r * AP_KS + 4 * c]) = kv;
       *reinterpret_cast<f32x4*>(&Vs[r * AP_VS + 4 * c]) = vv;
       if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
-        const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * 64 + 4 * c;  // (B,H,Lmax,64)
+        const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * HD + 4 * c;  // (B,H,Lmax,HD)
         *reinterpret_cast<f32x4*>(Kc + co) = kv;
         *reinterpret_cast<f32x4*>(Vc + co) = vv;
       }
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
       sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* kp = &Ks[(16 * t + lr) * AP_KS + lq];
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kk], kp[4 * kk], sacc[t], 0, 0, 0);
+      for (int kk = 0; kk < KK; ++kk) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kk], kp[4 * kk], sacc[t], 0, 0, 0);
     }
     // causal / length mask, online softmax per row (row of register j: q0 + 16 wave + 4 lq + j)
     float corr[4];
@@ -724,25 +728,25 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
       for (int t = 0; t < 4; ++t) {
         const float p = __expf(sacc[t][j] - ms);
         ps += p;
-        Pw[(4 * lq + j) * AP_KS + 16 * t + lr] = p;
+        Pw[(4 * lq + j) * AP_PS + 16 * t + lr] = p;
       }
       ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64); ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
       lrun[j] = lrun[j] * corr[j] + ps;
       mrun[j] = mnew;
     }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[dt][j] *= corr[j];
     __builtin_amdgcn_wave_barrier();   // P tile written and read by this wave only; LDS ops of a wave execute in order
     // O += P V
-    const float* pp = &Pw[lr * AP_KS + lq];
+    const float* pp = &Pw[lr * AP_PS + lq];
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const float pa = pp[4 * kk];
       const float* vp = &Vs[(4 * kk + lq) * AP_VS + lr];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vp[16 * dt], o[dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vp[16 * dt], o[dt], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -750,9 +754,9 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     const int tq = q0 + 16 * wave + 4 * lq + j;
     if (tq >= n) continue;
     const float inv = 1.0f / lrun[j];
-    float* yp = y + (base + tq) * D + h * 64 + lr;
+    float* yp = y + (base + tq) * D + h * HD + lr;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) yp[16 * dt] = o[dt][j] * inv;
+    for (int dt = 0; dt < DT; ++dt) yp[16 * dt] = o[dt][j] * inv;
   }
 }
 
@@ -784,6 +788,7 @@ struct SampleArgs {
   int S, M, V, ldv, Lmax, tuple_i, end0, end1, top_k, greedy_row0, mask_invalid, mask_completion, max_steps, advance;
   float top_p, temperature;
   unsigned seed;
+  const unsigned* seed_dev;     // optional: the seed lives in device memory (a captured hipGraph is reused across seeds)
   int row_offset, rows_total;   // micro-batching: global row = row_offset + blockIdx.x of rows_total (uniform stream, greedy row 0)
 };
 
@@ -945,7 +950,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         }
       }
       // inverse-CDF draw (oracle/tokens_oracle.py:sample_filtered convention)
-      const float u = sf_uniform(a.seed, (unsigned)((j * 2 + a.tuple_i) * a.rows_total + a.row_offset + b));
+      const float u = sf_uniform(a.seed_dev ? *a.seed_dev : a.seed, (unsigned)((j * 2 + a.tuple_i) * a.rows_total + a.row_offset + b));
       float tot2 = 0.f;
       for (int i = 0; i < keep; ++i) tot2 += cexp[i];
       const float thr = u * tot2;
@@ -1109,7 +1114,8 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
 #ifdef DG_FORCE_NW    // tuning hook of tools/ubench/dgemm_chain.hip
   const int NWv = DG_FORCE_NW;
 #else
-  const int NWv = (kslice >= 2048 && M <= 64) ? 16 : 8;
+  int NWv = (kslice >= 2048 && M <= 64) ? 16 : 8;
+  if (kslice % (16 * NWv)) NWv = kslice % 64 == 0 ? 4 : 1;   // narrow models (K-slice not a multiple of 128): fewer k-parts
 #endif
   if (kslice % (16 * NWv)) return SFMI_EINVAL;
   DGemmArgs a;
@@ -1127,6 +1133,9 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
 #define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
 #define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
   if (NWv == 16) { if (MT == 1) DGU(1, 16); else if (MT == 2) DGU(2, 16); else if (MT == 3) DGU(3, 16); else DGU(4, 16); }
+  // (the epilogue operands are prefetched for row tile == wave, so a narrow launch needs MT <= NW)
+  else if (NWv == 4) { if (MT == 1) DG(1, 4, 1); else if (MT == 2) DG(2, 4, 1); else if (MT == 3) DG(3, 4, 1); else if (MT == 4) DG(4, 4, 1); else return SFMI_EINVAL; }
+  else if (NWv == 1) { if (MT == 1) DG(1, 1, 1); else return SFMI_EINVAL; }
   else if (MT <= 4) { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
   else if (MT == 5) DG(5, 8, 1);   // 65..96 rows: still the co-residency-friendly 8-wave kernel (<= 128 VGPRs)
   else DG(6, 8, 1);
@@ -1184,9 +1193,14 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
 // causal self-attention over the conditioning prefix (positions 0..Lc[b]-2), also fills the KV caches
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                               int Lmax, const int* rowoff, void* stream) {
-  if (!qkv || !Kc || !Vc || !nval || !y || D / H != 64 || P <= 0) return SFMI_EINVAL;
-  hipLaunchKernelGGL(attn_prefill_mfma_kernel, dim3(B, H, (P + 63) / 64), dim3(256), 0, (hipStream_t)stream, qkv, Kc, Vc, nval, y, P,
-                     D, Lmax, 0.125f, rowoff);
+  const int HD = H > 0 ? D / H : 0;
+  if (!qkv || !Kc || !Vc || !nval || !y || H <= 0 || D % H || (HD != 16 && HD != 32 && HD != 64) || P <= 0) return SFMI_EINVAL;
+  const dim3 grid(B, H, (P + 63) / 64);
+  const float scale = 1.0f / sqrtf((float)HD);
+  hipStream_t st = (hipStream_t)stream;
+  if (HD == 64) hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff);
+  else if (HD == 32) hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff);
+  else hipLaunchKernelGGL(attn_prefill_mfma_kernel<16>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
@@ -1198,7 +1212,7 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
                         float* resid, const float* E0, const float* E1, const float* Ex, const float* pos_emb, int D,
                         int S, int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
                         float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
-                        unsigned seed, int advance, int row_offset, int rows_total, void* stream) {
+                        unsigned seed, const unsigned* seed_dev, int advance, int row_offset, int rows_total, void* stream) {
   if (!part || !seq || !len || !Lc || V > 4352 || temperature <= 0.f || rows_total < B + row_offset) return SFMI_EINVAL;
   if (resid && (!E0 || (tuple_i == 1 && (!E1 || !Ex || !pos_emb)) || D % 4)) return SFMI_EINVAL;
   SampleArgs a;
@@ -1206,7 +1220,7 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
   a.ldv = ldv; a.resid = resid; a.E0 = E0; a.E1 = E1; a.Ex = Ex; a.pos_emb = pos_emb; a.D = D;
   a.Lmax = Lmax; a.tuple_i = tuple_i; a.end0 = end0; a.end1 = end1; a.top_k = top_k; a.greedy_row0 = greedy_row0;
   a.mask_invalid = mask_invalid; a.mask_completion = mask_completion; a.max_steps = max_steps; a.advance = advance;
-  a.top_p = top_p; a.temperature = temperature; a.seed = seed; a.row_offset = row_offset; a.rows_total = rows_total;
+  a.top_p = top_p; a.temperature = temperature; a.seed = seed; a.seed_dev = seed_dev; a.row_offset = row_offset; a.rows_total = rows_total;
   const size_t dyn = (top_k <= 0 || top_k > SMP_MAXC) ? (size_t)SMP_BIG * 12 : 0;
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), dyn, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();

@@ -100,6 +100,30 @@ __global__ void sparse2dense_kernel(const int* __restrict__ tokens, const int* _
   }
 }
 
+// AR_N.get_extra_indices (representers.py:188-196) + get_next_cond (:432-442): condition tokens carry their own position,
+// generated tokens the first condition position > their own (searchsorted right=True over the ascending condition row, whose
+// last entry is the end token), end tokens map to the end token.  One thread per (b, t); pos tensors (B,Lc) / (B,Lz) int32.
+__global__ void ar_n_extra_kernel(const int* __restrict__ c_pos, const int* __restrict__ z_pos, int* __restrict__ extra, int B, int Lc,
+                                  int Lz, int end0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Lt = Lc + Lz;
+  if (i >= (long long)B * Lt) return;
+  const int b = (int)(i / Lt), t = (int)(i - (long long)b * Lt);
+  const int* cs = c_pos + (long long)b * Lc;
+  int e;
+  if (t < Lc) e = cs[t];
+  else {
+    const int z = z_pos[(long long)b * Lz + (t - Lc)];
+    if (z == end0) e = end0;
+    else {
+      int lo = 0, hi = Lc;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (cs[mid] > z) hi = mid; else lo = mid + 1; }
+      e = cs[lo < Lc ? lo : Lc - 1];
+    }
+  }
+  extra[i] = e;
+}
+
 extern "C" {
 
 // replaces pth_get_mode / torch.mode (common.py:20-23,155). hist: K ints of workspace.
@@ -142,6 +166,16 @@ int sfmi_sparse2dense_i32(const int* tokens, const int* start, const int* len, c
   if (!tokens || !empty || !dense || B <= 0 || ncell <= 0 || Lpad <= 0) return SFMI_EINVAL;
   hipLaunchKernelGGL(sparse2dense_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, start, len, empty, dense, ncell, Lpad,
                      end0, end1, empty_per_row ? 1 : 0);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// replaces AR_N.get_extra_indices / get_next_cond (representers.py:188-196, 432-442): extra (B, Lc+Lz) int32
+int sfmi_ar_n_extra_i32(const int* c_pos, const int* z_pos, int* extra, int B, int Lc, int Lz, int end0, void* stream) {
+  if (!c_pos || !extra || B <= 0 || Lc <= 0 || Lz < 0 || (Lz > 0 && !z_pos)) return SFMI_EINVAL;
+  const long long n = (long long)B * (Lc + Lz);
+  hipLaunchKernelGGL(ar_n_extra_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c_pos, z_pos, extra, B, Lc, Lz,
+                     end0);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

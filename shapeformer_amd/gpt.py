@@ -63,6 +63,8 @@ class CondTupleGPT:
         self.load_state_dict(sd)
         self._state = None
         self._states, self._graphs = {}, {}
+        import os
+        self._force_wide = os.environ.get("SFMI_DGEMM_WIDE") == "1"     # tuning hook: two-n-tiles-per-wave kernel for 17..96 rows too
 
     def get_block_size(self):
         return self.Lmax
@@ -181,7 +183,8 @@ class CondTupleGPT:
                   h=torch.zeros(Bp, 4 * D, device=dev), logit=f(B, self.Vpad),
                   slab=f(L.lib().sfmi_decode_gemm_slab_floats(Bp, 4 * D, 4)), cnt=torch.zeros(Bp // 16 * (max(4 * D, self.Vpad) // 16 + 1), device=dev, dtype=torch.int32),
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
-                  logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32))
+                  logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32),
+                  seed=torch.zeros(1, device=dev, dtype=torch.int32))   # sampler seed (device-resident: graphs are seed-independent)
         self._state = st
         self._states[slot] = st
         self._graphs.pop(slot, None)
@@ -192,6 +195,11 @@ class CondTupleGPT:
         st = st or self._state
         while S > 1 and (K // S) % 128:
             S //= 2
+        if self._force_wide and M > 16:
+            L.check(L.lib().sfmi_decode_gemm_wide_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
+                                                      ln, act, packed, S, L.ptr(st["slab"]) if S > 1 else None,
+                                                      L.ptr(st["cnt"]) if S > 1 else None, L.stream_ptr()), "sfmi_decode_gemm_wide_f32")
+            return
         L.check(L.lib().sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
                                              ln, act, packed, S, L.ptr(st["slab"]) if S > 1 else None,
                                              L.ptr(st["cnt"]) if S > 1 else None, L.stream_ptr()), "sfmi_decode_gemm_f32")
@@ -373,7 +381,7 @@ class CondTupleGPT:
         if "@" in skip:      # per-chain form "gemm@0,attn@1,attn@2": chain index = micro-batch slot
             skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
         # in-kernel split-K per GEMM: 64-row kernel (B <= 64) / wide kernel (one launch for up to 256 rows)
-        Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if B > 96 else (1, self.S_PROJ if B <= 16 else 4, 1, self.S_FC2, 1)
+        Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if (B > 96 or self._force_wide) else (1, self.S_PROJ if B <= 16 else 4, 1, self.S_FC2, 1)
         for li, ly in enumerate(self.layers):
             if "gemm" not in skip:
                 self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
@@ -396,7 +404,7 @@ class CondTupleGPT:
                                                 1, B, self.V, self.Vpad, self.Lmax + 1,
                                                 s, self.end[0], self.end[1], sp["top_k"], sp["top_p"], sp["temperature"],
                                                 int(sp["best_in_first"]), int(sp["mask_invalid"]),
-                                                int(sp["mask_invalid_completion"]), sp["max_steps"], sp["seed"], int(s == 1),
+                                                int(sp["mask_invalid_completion"]), sp["max_steps"], sp["seed"], L.ptr(st.get("seed")), int(s == 1),
                                                 sp.get("row_offset", 0), sp.get("rows_total", B), L.stream_ptr()), "sfmi_gpt_sample_f32")
 
     # ------------------------------------------------------------------ sample_indices
@@ -417,6 +425,7 @@ class CondTupleGPT:
         st["Lc"].copy_(Lc.to(self.dev, torch.int32))
         st["len"].copy_(st["Lc"])
         st["logp"].zero_()
+        st["seed"].copy_(torch.from_numpy(np.array([sp_kw["seed"]], np.uint32).view(np.int32)))
         hist = None
         if return_logits:
             hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
@@ -442,7 +451,7 @@ class CondTupleGPT:
                 "sfmi_gpt_embed_packed_f32")
         graph = None
         if use_graph and steps > 1:
-            gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force"))), return_logits)
+            gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force", "seed"))), return_logits)
             cached = self._graphs.get(slot)
             if cached is None or cached[0] != gkey or return_logits:
                 side = torch.cuda.Stream(device=self.dev)

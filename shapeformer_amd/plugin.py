@@ -105,7 +105,8 @@ class VQDIFModel:
         """HIP training state for this model: Adam(lr) over all parameters + EMA codebook (train_vqdif.VQDIFTrainer)."""
         from .train_vqdif import VQDIFTrainer
         oo = optim_opt or self.hparams.get("optim_opt") or {}
-        self.trainer = VQDIFTrainer(self.core.state_dict_np(), res=self.core.res, device=self.core.dev, lr=oo.get("lr", 1e-4),
+        self._lr0 = oo.get("lr", 1e-4)
+        self.trainer = VQDIFTrainer(self.core.state_dict_np(), res=self.core.res, device=self.core.dev, lr=self._lr0,
                                     beta=self.hparams.get("vq_beta", 1.0), dist=dist)
         return self.trainer
 
@@ -125,10 +126,17 @@ class VQDIFModel:
         ck = dict(state_dict={k: torch.as_tensor(v) for k, v in sd.items()}, hyper_parameters=dict(self.hparams), epoch=epoch,
                   global_step=getattr(getattr(self, "trainer", None), "step_count", 0))
         if hasattr(self, "trainer"):
-            ck["optimizer_states"] = [self.trainer.optimizer_state()]
+            ck["sfmi_optimizer_state"] = self.trainer.optimizer_state()     # flat Adam moments (not a torch.optim state dict)
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save(ck, path)
         return path
+
+    def on_epoch_end(self, epoch):
+        """StepLR of the shipped optim_opt (vqdif.py:127-133): lr = lr0 * gamma ** ((epoch + 1) // step_size)."""
+        oo = self.hparams.get("optim_opt") or {}
+        if hasattr(self, "trainer") and oo.get("scheduler") == "StepLR":
+            self.trainer.lr = self._lr0 * float(oo.get("gamma", 0.9)) ** ((int(epoch) + 1) // int(oo.get("step_size", 10)))
+        return getattr(getattr(self, "trainer", None), "lr", None)
 
     def resume(self, path):
         """Continue training from save_checkpoint's file: weights, EMA codebook buffers, Adam moments, step count."""
@@ -136,8 +144,8 @@ class VQDIFModel:
         self.core.load_state_dict(ck["state_dict"])
         lr = self.trainer.lr if hasattr(self, "trainer") else None
         self.make_trainer(dict(lr=lr) if lr else None, dist=getattr(getattr(self, "trainer", None), "dist", None))
-        if ck.get("optimizer_states"):
-            self.trainer.load_optimizer_state(ck["optimizer_states"][0])
+        if ck.get("sfmi_optimizer_state") is not None:
+            self.trainer.load_optimizer_state(ck["sfmi_optimizer_state"])
         return ck
 
     def sync_inference_weights(self):
@@ -164,66 +172,206 @@ class CondTupleGPTModel:
 
 
 class ARNRepresenter:
-    """`...representers.AR_N` ctor surface (representers.py:53-67): owns the frozen VQDIF named by `vqvae_opt`."""
+    """`...representers.AR_N` (representers.py:53-155,188-196): owns the frozen VQDIF named by `vqvae_opt` and exposes the
+    reference's method surface - `encode_cloud`, `get_indices`, `get_extra_indices`, `convert_input/output_indices`,
+    `sampling_masker` - as thin host calls onto the HIP kernels (tokens.hip, gpt.hip:sample_kernel)."""
 
-    def __init__(self, voxel_res=16, end_tokens=None, block_size=None, uncond=False, no_val_ind=False, vqvae_opt=None,
-                 random_cind_masking=False, mask_invalid=True, mask_invalid_completion=False, device=None, **_):
+    def __init__(self, voxel_res=16, end_tokens=None, input_end_tokens=None, block_size=None, uncond=False, no_val_ind=False,
+                 vqvae_opt=None, cloud_shrinkage=1., random_cind_masking=False, mask_invalid=True, mask_invalid_completion=False,
+                 device=None, allow_generated_weights=False, vqvae_state_dict=None, **_):
         self.voxel_res, self.end_tokens, self.block_size = voxel_res, tuple(end_tokens), block_size
+        self.input_end_tokens = tuple(input_end_tokens) if input_end_tokens is not None else self.end_tokens
+        self.uncond, self.no_val_ind, self.cloud_shrinkage = uncond, no_val_ind, cloud_shrinkage
+        self.random_cind_masking = random_cind_masking
         self.mask_invalid, self.mask_invalid_completion = mask_invalid, mask_invalid_completion
         self.max_length = block_size // 2
+        vqvae_opt = vqvae_opt or {}
         y = load_option(vqvae_opt["yaml_path"]) if os.path.exists(vqvae_opt.get("yaml_path", "")) else None
         kw = dict(y["pl_model_opt"]["kwargs"]) if y else default_vqdif_kwargs(voxel_res)
         ck = vqvae_opt.get("ckpt_path")
-        self.vqvae_model = VQDIFModel(**kw, ckpt_path=ck if ck and os.path.exists(ck) else None, device=device)
+        allow_generated_weights = allow_generated_weights or os.environ.get("SFMI_ALLOW_GENERATED_WEIGHTS") == "1"
+        if vqvae_state_dict is not None:
+            ck = None                    # weights come with the owning ShapeFormer checkpoint (`representer.vqvae_model.*`)
+        elif ck and not os.path.exists(ck):
+            # the reference raises here (representers.py:42-43: load_from_checkpoint of a missing file); hash-generated
+            # weights are for benchmarks / tests only and must be asked for
+            if not allow_generated_weights:
+                raise FileNotFoundError(f"vqvae_opt.ckpt_path {ck!r} does not exist (pass allow_generated_weights=True to run "
+                                        "the frozen VQDIF on hash-generated weights)")
+            ck = None
+        if vqvae_state_dict is None and not ck and not allow_generated_weights:
+            raise FileNotFoundError("AR_N: no VQDIF checkpoint configured (vqvae_opt.ckpt_path) and no weights handed in; pass "
+                                    "allow_generated_weights=True to run on hash-generated weights")
+        self.vqvae_model = VQDIFModel(**kw, ckpt_path=ck, state_dict=vqvae_state_dict, device=device)
+
+    @property
+    def dev(self):
+        return self.vqvae_model.core.dev
+
+    # ---- representers.py:69-77 ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_cloud(self, cloud):
+        """-> (quant_feat (B,d,R,R,R), quant_ind (B,R,R,R) int64, mode, sparse_unpacked (B,L,2) int64)."""
+        from . import tokens as T
+        cloud = torch.as_tensor(cloud).to(self.dev, torch.float32)
+        quant_ind, mode, encoded = self.vqvae_model.core.quantize_cloud(cloud * self.cloud_shrinkage)
+        sparse, mode = T.batch_dense2sparse(quant_ind, max_length=self.max_length, end_tokens=self.input_end_tokens)
+        if self.no_val_ind:
+            sparse[:, :, -1] *= 0
+        return encoded["quant_feat"], quant_ind, mode, sparse
+
+    # ---- representers.py:79-103 --------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_indices(self, Xct, Xbd=None, stage="train", **kwargs):
+        """-> (c_indices (B,L_c,2), z_indices (B,L_z,2), extra_indices (B,L_c+L_z,1), others{empty_index, origin_*}), int64."""
+        _, _, mode1, c_indices = self.encode_cloud(Xct)
+        z_indices = c_indices[:, :0, :] if Xbd is None else self.encode_cloud(Xbd)[3]
+        if self.uncond:
+            B = c_indices.shape[0]
+            c_indices = torch.tensor(self.input_end_tokens, device=c_indices.device, dtype=torch.int64)[None, None, :].repeat(B, 1, 1)
+        others = dict(empty_index=mode1, origin_c_indices=c_indices, origin_z_indices=z_indices)
+        if stage == "train" and self.random_cind_masking and c_indices.shape[1] >= 1:     # representers.py:93-99 (numpy RNG)
+            max_num = c_indices.shape[1] - 1
+            select_num = np.random.randint(0, max_num + 1)
+            selected = np.sort(np.random.choice(max_num, select_num, replace=False))
+            c_indices = torch.cat([c_indices[:, selected, :], c_indices[:, -1:, :]], 1)
+        extra_indices = self.get_extra_indices(c_indices, z_indices)
+        c_indices, z_indices = self.convert_input_indices(c_indices, z_indices)
+        return c_indices, z_indices, extra_indices, others
+
+    # ---- representers.py:188-196, 432-442 ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_extra_indices(self, c_indices, z_indices):
+        """AR_N: condition tokens -> own position, generated tokens -> next condition position; (B, L_c+L_z, 1) int64."""
+        from . import _lib as L
+        c = torch.as_tensor(c_indices).to(self.dev)
+        z = torch.as_tensor(z_indices).to(self.dev)
+        B, Lc, Lz = c.shape[0], c.shape[1], z.shape[1]
+        cp = c[..., 0].to(torch.int32).contiguous()
+        zp = z[..., 0].to(torch.int32).contiguous()
+        out = torch.empty(B, Lc + Lz, device=self.dev, dtype=torch.int32)
+        L.check(L.lib().sfmi_ar_n_extra_i32(L.ptr(cp), L.ptr(zp) if Lz else None, L.ptr(out), B, Lc, Lz, int(self.end_tokens[0]),
+                                            L.stream_ptr()), "sfmi_ar_n_extra_i32")
+        return out.long()[..., None]
+
+    def convert_input_indices(self, c_indices, z_indices):
+        return c_indices, z_indices      # representers.py:112-114
+
+    def convert_output_indices(self, indices):
+        return indices                   # representers.py:116-118
+
+    # ---- representers.py:120-155 -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sampling_masker(self, logits, idx, extra_idx=None, L_cond=None, step_j=None, tuple_i=None):
+        """logits (B,V) -> masked copy; idx (B,L+1,2): idx[:, -1] is the position being sampled.  Runs the masking stage of the
+        fused sampler kernel (csrc/gpt.hip:sample_kernel - the code the decode step uses) on a scratch copy of `idx`."""
+        from . import _lib as L
+        dev = self.dev
+        lg = torch.as_tensor(logits).to(dev, torch.float32).contiguous()
+        seq = torch.as_tensor(idx).to(dev, torch.int32).contiguous()
+        B, V = lg.shape
+        Lt = seq.shape[1]
+        if step_j is not None and L_cond is not None and tuple_i == 0 and step_j != Lt - 1 - L_cond:
+            raise ValueError("sampling_masker: step_j must equal idx.shape[1] - 1 - L_cond (shapeformer.py:86-93)")
+        seq = torch.cat([seq, torch.zeros(B, 1, 2, device=dev, dtype=torch.int32)], 1).contiguous()   # kernel writes the draw at [L]
+        ln = torch.full((B,), Lt - 1, device=dev, dtype=torch.int32)
+        lc = torch.full((B,), int(L_cond), device=dev, dtype=torch.int32)
+        j = Lt - 1 - int(L_cond)
+        out = torch.empty(B, V, device=dev, dtype=torch.float32)
+        hist_base = out.data_ptr() - j * V * 4          # kernel writes hist[(b*max_steps + j)*V + v] with max_steps = 1
+        L.check(L.lib().sfmi_gpt_sample_f32(L.ptr(lg), L.ptr(seq), L.ptr(ln), L.ptr(lc), None, hist_base, None,
+                                            None, None, None, None, None, 0, 1, B, V, V, Lt + 1, int(tuple_i),
+                                            int(self.end_tokens[0]), int(self.end_tokens[1]), 1, 0.0, 1.0, 0, int(self.mask_invalid),
+                                            int(self.mask_invalid_completion), 1, 0, None, 0, 0, B, L.stream_ptr()), "sfmi_gpt_sample_f32")
+        return out
 
 
 class ShapeFormerModel:
     """`shapeformer.models.shapeformer.shapeformer.ShapeFormer` ctor surface (shapeformer.py:17-24) + `sample` /
     the compute half of VisShapeFormer (`complete`)."""
 
+    _VQ = "representer.vqvae_model."
+
     def __init__(self, tuple_n=None, block_size=None, end_tokens=None, vocab_sizes=None, extra_vocab_sizes=None,
-                 voxel_res=16, transformer_opt=None, representer_opt=None, optim_opt=None, state_dict=None, device=None):
+                 voxel_res=16, transformer_opt=None, representer_opt=None, optim_opt=None, state_dict=None, device=None,
+                 allow_generated_weights=False):
         assert "TupleGPT" in transformer_opt["class"]  # shapeformer.py:24
         from .pipeline import ShapeCompletion
         dev = device or _device()
+        self.hparams = dict(tuple_n=tuple_n, block_size=block_size, end_tokens=end_tokens, vocab_sizes=vocab_sizes,
+                            extra_vocab_sizes=extra_vocab_sizes, voxel_res=voxel_res, transformer_opt=transformer_opt,
+                            representer_opt=representer_opt, optim_opt=optim_opt)       # save_hyperparameters() (shapeformer.py:21)
         tsd = {k[len("transformer."):]: v for k, v in state_dict.items() if k.startswith("transformer.")} if state_dict else None
-        self.transformer = CondTupleGPTModel(**transformer_opt["kwargs"], state_dict=tsd, device=dev, end_tokens=end_tokens)
-        self.representer = instantiate_from_opt(dict(representer_opt, kwargs=dict(representer_opt["kwargs"], device=dev)))
+        vsd = {k[len(self._VQ):]: v for k, v in state_dict.items() if k.startswith(self._VQ)} if state_dict else None
+        self.transformer = CondTupleGPTModel(**transformer_opt["kwargs"], state_dict=tsd or None, device=dev, end_tokens=end_tokens)
+        rkw = dict(representer_opt["kwargs"], device=dev)
+        if vsd:
+            rkw["vqvae_state_dict"] = vsd      # a ShapeFormer checkpoint carries its frozen VQDIF (the reference restores these keys)
+        if allow_generated_weights:
+            rkw["allow_generated_weights"] = True
+        self.representer = instantiate_from_opt(dict(representer_opt, kwargs=rkw))
+        self.optim_opt = optim_opt
         self.tuple_n, self.block_size, self.end_tokens, self.voxel_res = tuple_n, block_size, tuple(end_tokens), voxel_res
         self.pipe = ShapeCompletion(self.representer.vqvae_model.core, self.transformer, voxel_res, block_size, end_tokens)
 
-    def sample(self, c_indices, Lc=None, max_steps=512, temperature=1.0, best_in_first=False, top_k=100, top_p=0.8,
-               mask_invalid=True, mask_invalid_completion=False, **kw):
-        """shapeformer.py:125-130 -> dict(samples, log_prob, steps)."""
+    @classmethod
+    def load_from_checkpoint(cls, ckpt_path, **kw):
+        """LightningModule.load_from_checkpoint: hyper_parameters + state_dict (transformer.* and representer.vqvae_model.*)."""
+        ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        return cls(**ck["hyper_parameters"], state_dict=ck["state_dict"], **kw)
+
+    # ---- shapeformer.py:54-130 ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_indices(self, c_indices, z_indices, max_steps, sample=False, best_in_first=False, top_k=100, top_p=.8, temperature=1.0,
+                       mask_invalid=True, mask_invalid_completion=False, callback=lambda k: None, seed=0):
+        """ShapeFormer.sample_indices: c (B,L_c,2), z (B,0,2) -> (x (B,steps,2) int64 on the device, logits_history =
+        [ (B,steps,V) ] * 2 on the CPU: the masked logits every draw was made from).  Prefill + KV-cached hipGraph decode
+        instead of the reference's full re-forward per step; torch.multinomial is replaced by the counter-hash inverse CDF
+        (DESIGN.md §2), so only the greedy row (`best_in_first`) is token-comparable with the reference.  Stops at the step
+        where every row's newest token is an end token (shapeformer.py:110-115) or at the block size (no crop: DESIGN §2 D4).
+        `mask_invalid*` are taken from the representer, as the reference's sampling_masker does (the arguments are unused
+        there too); `sample`/`callback` are accepted and unused (as in the reference)."""
+        c = torch.as_tensor(c_indices)
+        z = torch.as_tensor(z_indices)
+        if z.shape[1] != 0:
+            raise NotImplementedError("sample_indices: continuing a non-empty z_indices is not supported (every caller of the "
+                                      "reference passes z_indices = c_indices[:, :0])")
+        B, L_c, _ = c.shape
+        rep = self.representer
+        res = self.transformer.sample(c.to(torch.int32), torch.full((B,), L_c, dtype=torch.int32), max_steps=int(max_steps), top_k=top_k,
+                                      top_p=top_p, temperature=temperature, best_in_first=best_in_first, mask_invalid=rep.mask_invalid,
+                                      mask_invalid_completion=rep.mask_invalid_completion, seed=seed, stop_early=True, check_every=8,
+                                      return_logits=True)
+        x = res["samples"]
+        end = torch.tensor(self.end_tokens)
+        ended = (x == end[None, None, :]).any(-1).all(0)          # step j: no row without a stop token
+        n = int(torch.nonzero(ended)[0]) + 1 if bool(ended.any()) else x.shape[1]
+        return x[:, :n].to(rep.dev), [h[:, :n] for h in res["logits_history"]]
+
+    @torch.no_grad()
+    def sample(self, **sampling_kwargs):
+        """ShapeFormer.sample (shapeformer.py:125-130) -> (out_x, x, logits_history)."""
+        x, logits_history = self.sample_indices(**sampling_kwargs)
+        return self.representer.convert_output_indices(x), x, logits_history
+
+    def sample_ragged(self, c_indices, Lc=None, max_steps=512, temperature=1.0, best_in_first=False, top_k=100, top_p=0.8, **kw):
+        """Ragged batch of DIFFERENT shapes (row b valid for Lc[b] tokens) -> dict(samples, log_prob, steps) (gpt.sample)."""
         B, Lp, _ = c_indices.shape
         Lc = Lc if Lc is not None else torch.full((B,), Lp, dtype=torch.int32)
+        kw.setdefault("mask_invalid", self.representer.mask_invalid)
+        kw.setdefault("mask_invalid_completion", self.representer.mask_invalid_completion)
         return self.transformer.sample(c_indices, Lc, max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature,
-                                       best_in_first=best_in_first, mask_invalid=mask_invalid,
-                                       mask_invalid_completion=mask_invalid_completion, **kw)
+                                       best_in_first=best_in_first, **kw)
 
     # ---- training (shapeformer.py:26-46,132-207) ------------------------------------------------------------------
-    def get_indices(self, Xct, Xbd, stage="train"):
-        """ShapeRepresenter.get_indices (representers.py:79-103): frozen VQDIF tokens of the partial and the complete
-        cloud (uniform (B,L,2) rows, end-token padded, whole-batch empty code as the reference does for a batch);
-        train stage: random subset of the condition tokens, keeping the terminating end token (:93-99, numpy RNG)."""
-        from . import tokens as T
-        vq = self.representer.vqvae_model.core
-        out = []
-        for cloud in (Xct, Xbd):
-            q, mode, *_ = vq.quantize_cloud_dev(cloud, per_shape_mode=False)
-            tok, _ = T.batch_dense2sparse(q, max_length=self.representer.max_length, end_tokens=self.end_tokens)
-            out.append(tok)
-        c, z = out
-        if stage == "train" and c.shape[1] >= 1:
-            import numpy as np
-            max_num = c.shape[1] - 1
-            sel = np.sort(np.random.choice(max_num, np.random.randint(0, max_num + 1), replace=False))
-            c = torch.cat([c[:, sel, :], c[:, -1:, :]], 1)
+    def get_indices(self, Xct, Xbd=None, stage="train"):
+        """(c_indices, z_indices) of representer.get_indices (representers.py:79-103)."""
+        c, z, _, _ = self.representer.get_indices(Xct, Xbd, stage=stage)
         return c, z
 
     def make_trainer(self, optim_opt=None, dist=None):
         from .train import GPTTrainer
-        lr = (optim_opt or {}).get("lr", 1e-5)
+        lr = (optim_opt or getattr(self, "optim_opt", None) or {}).get("lr", 1e-5)
         self.trainer = GPTTrainer(self.transformer, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, dist=dist)
         return self.trainer
 
@@ -242,24 +390,39 @@ class ShapeFormerModel:
         return sd
 
     def save_checkpoint(self, path, hyper_parameters=None, epoch=0):
-        ck = dict(state_dict=self.state_dict(), hyper_parameters=hyper_parameters or {}, epoch=epoch,
+        """Lightning-layout file: `state_dict` (reference key names), `hyper_parameters` (the ctor kwargs, so that
+        `load_from_checkpoint` of either code base can rebuild the module), `epoch`, `global_step`.  The AdamW moments of the
+        flat-buffer trainer are NOT a torch.optim state dict; they live under the private key `sfmi_optimizer_state`."""
+        ck = dict(state_dict=self.state_dict(), hyper_parameters=dict(hyper_parameters or self.hparams), epoch=epoch,
                   global_step=getattr(getattr(self, "trainer", None), "step_count", 0))
         if hasattr(self, "trainer"):
-            ck["optimizer_states"] = [self.trainer.optimizer_state()]
+            ck["sfmi_optimizer_state"] = self.trainer.optimizer_state()
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save(ck, path)
         return path
 
     def load_checkpoint(self, path, resume_optimizer=True):
-        """Weights (and, when present and asked for, the AdamW state) from a checkpoint written by save_checkpoint or by the
-        reference's Lightning trainer (its optimizer state is per-tensor and is not read)."""
+        """Weights from a checkpoint written by save_checkpoint or by the reference's Lightning trainer: `transformer.*` and,
+        when present, the frozen `representer.vqvae_model.*`; the AdamW state when the file carries ours and it is asked for
+        (a Lightning per-tensor optimizer state is not read).  An existing trainer is rebuilt on the NEW parameter tensors
+        (load_state_dict re-creates them) - otherwise the optimizer would keep updating the orphaned ones."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
         sd = ck.get("state_dict", ck)
-        self.transformer.load_state_dict({k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")})
-        if resume_optimizer and ck.get("optimizer_states") and "exp_avg" in ck["optimizer_states"][0]:
-            old = getattr(self, "trainer", None)       # parameter tensors were re-created by load_state_dict: new table
-            self.make_trainer(dict(lr=old.lr) if old else None, dist=old.dist if old else None)
-            self.trainer.load_optimizer_state(ck["optimizer_states"][0])
+        tsd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
+        if not tsd:
+            raise KeyError(f"{path}: no transformer.* keys in the checkpoint")
+        self.transformer.load_state_dict(tsd)
+        vsd = {k[len(self._VQ):]: v for k, v in sd.items() if k.startswith(self._VQ)}
+        if vsd:
+            self.representer.vqvae_model.core.load_state_dict(vsd)
+        old = getattr(self, "trainer", None)
+        if old is not None:
+            self.make_trainer(dict(lr=old.lr), dist=old.dist)
+        st = ck.get("sfmi_optimizer_state")
+        if resume_optimizer and st is not None:
+            if old is None:
+                self.make_trainer(self.optim_opt)
+            self.trainer.load_optimizer_state(st)
         return ck
 
     def complete(self, Xct, **kw):

@@ -177,7 +177,7 @@ class VQDIF:
     def encode(self, Xbd):
         """vqdif.py:35-37 -> (grid_feat (B,d,R,R,R) view, grid_mask (B,R,R,R) bool)."""
         lat, mask = self.encode_cl(Xbd)
-        return lat.permute(0, 4, 1, 2, 3), mask.bool()
+        return lat.permute(0, 4, 1, 2, 3).clone(), mask.bool()      # fresh tensors: the *_cl / *_dev paths return workspace views
 
     # ------------------------------------------------------------------ quantizer (a9, a10)
     def quantize_cl(self, latent):
@@ -218,7 +218,10 @@ class VQDIF:
     def quantize_cloud(self, cloud):
         """vqdif.py:50-58 -> (quant_ind (B,R,R,R) int64, mode, dict(quant_ind, grid_mask, quant_feat...))."""
         q, mode, raw, mask, latent = self.quantize_cloud_dev(cloud)
-        enc = dict(quant_ind=raw.long(), grid_mask=mask.bool(), grid_feat=latent.permute(0, 4, 1, 2, 3))
+        code = self.get_code_cl(raw)
+        # encode_quant's dict (vqdif.py:39-48); fresh tensors (the *_dev path returns views of a reused workspace)
+        enc = dict(quant_feat=code.permute(0, 4, 1, 2, 3).clone(), quant_ind=raw.long(), quant_diff=((latent - code) ** 2).mean(),
+                   grid_mask=mask.bool(), grid_feat=latent.permute(0, 4, 1, 2, 3).clone())
         return q.long(), mode.long()[0], enc
 
     # ------------------------------------------------------------------ decoder grid (a21, a22)
@@ -282,7 +285,7 @@ class VQDIF:
         raw = self.quantize_cl(latent)
         out = self.decode_index(raw, Xtg)
         q = self.get_code_cl(raw)
-        return dict(logits=out["logits"], quant_feat=q.permute(0, 4, 1, 2, 3), quant_ind=raw.long(),
-                    grid_mask=mask.bool())
+        return dict(logits=out["logits"], quant_feat=q.permute(0, 4, 1, 2, 3).clone(), quant_ind=raw.long(),
+                    quant_diff=((latent - q) ** 2).mean(), grid_mask=mask.bool())
 
     __call__ = forward

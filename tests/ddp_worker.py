@@ -1,0 +1,59 @@
+"""Worker of tests/test_ddp_gpu.py: one data-parallel rank of the REAL trainers (GPTTrainer / VQDIFTrainer with dist=...).
+
+Launched as `python tests/ddp_worker.py <out.npz>` with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment
+(what torchrun sets).  All ranks share cuda:0 and rendezvous over gloo - the collective path taken is the one RCCL takes on
+an 8-GPU node (dist.GradBuckets fired from the real backward order, flat-buffer all-reduce, EMA statistics all-reduce)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    import torch.distributed as dist
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    from shapeformer_amd.train import GPTTrainer
+    from shapeformer_amd.train_vqdif import VQDIFTrainer
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    out = {}
+    # ---- transformer: rank r trains on item r of the 2-item reference token fixture ------------------------------
+    kw = dict(n_embd=128, n_layers=(2, 1), block_size=96)
+    g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    t = np.load(os.path.join(G, "gpt_tiny.npz"))
+    c, z = torch.from_numpy(t["c_idx"])[rank::world], torch.from_numpy(t["z_idx"])[rank::world]
+    tr = GPTTrainer(g, lr=1e-3, dist=dist)
+    loss = tr.loss_and_grad(c, z, sync=True)          # buckets are launched from inside the backward pass
+    out["gpt_pending_before_finish"] = np.int64(len(tr.buckets.pending))
+    out["gpt_order"] = np.array(tr.all_reduce_grads())
+    out["gpt_loss"] = np.float64(loss.item())
+    out["gpt_grad"] = tr.flat_grad.detach().cpu().numpy().copy()
+    tr.optimizer_step()
+    loss2 = tr.training_step(c, z)                     # second full step through the public entry point
+    out["gpt_loss2"] = np.float64(loss2.item())
+    out["gpt_w"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr.params[:24]])
+    # ---- VQDIF autoencoder: item r of a 2-item batch; gradients averaged, EMA statistics summed over ranks ------
+    T = np.load(os.path.join(G, "vqdif_train.npz"))
+    Xbd = np.concatenate([T["Xbd"], T["Xbd"][:, ::-1] * np.float32(0.9)], 0)      # two different clouds
+    Xtg = np.concatenate([T["Xtg"], T["Xtg"][:, ::-1]], 0)
+    Ytg = np.concatenate([T["Ytg"], T["Ytg"][:, ::-1]], 0)
+    vt = VQDIFTrainer(W.make_state_dict(W.vqdif_spec(16)), res=16, device=dev, lr=1e-3, beta=float(T["beta"]), dist=dist)
+    o = vt.training_step(dict(Xbd=Xbd[rank::world], Xtg=Xtg[rank::world], Ytg=Ytg[rank::world]))
+    out["vq_loss"] = np.float64(float(o["loss"]))
+    out["vq_grad"] = vt.flat_g.detach().cpu().numpy().copy()      # after the in-place mean all-reduce of optimizer_step
+    out["vq_emb"], out["vq_N"] = vt.emb.detach().cpu().numpy().copy(), vt.N.detach().cpu().numpy().copy()
+    out["vq_p"] = vt.flat_p.detach().cpu().numpy().copy()
+    np.savez(sys.argv[1] + f".rank{rank}.npz", **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

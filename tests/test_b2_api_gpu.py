@@ -1,0 +1,143 @@
+"""GPU: boundary B2 - the reference's module-method contracts: `ShapeFormer.sample / sample_indices`
+(shapeformer.py:54-130) and the representer methods `get_indices / get_extra_indices / convert_output_indices /
+sampling_masker` (representers.py:79-155,188-196), called with the reference's argument names on the tiny-GPT fixture that the
+REAL reference produced (tests/golden/gpt_tiny.npz: its greedy row and its masked-logit history)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model(block=96, n_embd=64, n_head=4, **rep_kw):
+    from shapeformer_amd import plugin as P
+    PP = "shapeformer.models.shapeformer."
+    opt = {"class": PP + "shapeformer.ShapeFormer", "kwargs": dict(
+        voxel_res=16, end_tokens=[4096, 4096], vocab_sizes=[4097, 4097], extra_vocab_sizes=[4097], block_size=block, tuple_n=2,
+        representer_opt={"class": PP + "representers.AR_N", "kwargs": dict(
+            voxel_res=16, uncond=False, no_val_ind=False, block_size=block, end_tokens=[4096, 4096], random_cind_masking=True,
+            mask_invalid_completion=True, allow_generated_weights=True,
+            vqvae_opt={"class": "shapeformer.models.vqdif.vqdif.VQDIF", "ckpt_path": None, "yaml_path": "configs/vqdif/shapenet_res16.yaml"},
+            **rep_kw)},
+        transformer_opt={"class": PP + "transformer.mingpt.CondTupleGPT", "kwargs": dict(
+            tuple_n=2, vocab_sizes=[4097, 4097], extra_vocab_sizes=[4097], n_layers=[2, 1], block_size=block, n_head=n_head, n_embd=n_embd,
+            attn_pdrop=.01, resid_pdrop=.01, embd_pdrop=.01)},
+        optim_opt=dict(lr=1e-3))}
+    return P.instantiate_from_opt(opt)
+
+
+def test_sample_reproduces_the_reference_greedy_row_and_masked_logit_history(dev):
+    t = np.load(os.path.join(G, "gpt_tiny.npz"))
+    m = _model()
+    c1 = torch.from_numpy(t["c_idx"][:1]).expand(3, -1, -1).contiguous()
+    # the reference's own call (oracle/make_golden.py: sf.sample_indices(...)), through ShapeFormer.sample's kwargs route
+    out_x, x, hist = m.sample(c_indices=c1, z_indices=c1[:, :0], max_steps=int(t["steps"]), best_in_first=True, top_k=100, top_p=0.4,
+                              temperature=1.0, mask_invalid=True, mask_invalid_completion=True)
+    ref = t["ref_sampled"]
+    assert tuple(x.shape) == ref.shape and x.dtype == torch.int64 and x.device.type == "cuda" and out_x is x
+    assert np.array_equal(x[0].cpu().numpy(), ref[0]), "greedy row (best_in_first) must equal the reference token for token"
+    assert len(hist) == 2 and all(h.device.type == "cpu" and tuple(h.shape) == (3, ref.shape[1], 4097) for h in hist)
+    for i, key in enumerate(("ref_hist0_row0", "ref_hist1_row0")):
+        a, r = hist[i][0].numpy(), t[key]
+        fin = np.isfinite(r)
+        assert np.array_equal(np.isfinite(a), fin), "sampling_masker mask differs from the reference's"
+        assert np.abs(a[fin] - r[fin]).max() < 1e-3
+    # x, logits_history alone
+    x2, h2 = m.sample_indices(c1, c1[:, :0], int(t["steps"]), best_in_first=True, top_k=100, top_p=0.4)
+    assert torch.equal(x2, x) and torch.equal(h2[0], hist[0])
+    with pytest.raises(NotImplementedError):
+        m.sample_indices(c1, c1[:, :2], 4)
+
+
+def test_representer_methods_match_reference_vectors_and_oracle(dev):
+    from oracle import tokens_oracle as TO
+    t = np.load(os.path.join(G, "gpt_tiny.npz"))
+    k = np.load(os.path.join(G, "tokens_known.npz"))
+    m = _model()
+    rep = m.representer
+    # get_extra_indices: the reference's tensor for the fixture tokens + its get_next_cond known-answer case
+    c, z = torch.from_numpy(t["c_idx"]), torch.from_numpy(t["z_idx"])
+    ex = rep.get_extra_indices(c, z)
+    assert ex.dtype == torch.int64 and np.array_equal(ex.cpu().numpy(), t["extra"])
+    cp, zp = k["c_pos"], k["z_pos"]
+    ex2 = rep.get_extra_indices(torch.from_numpy(np.stack([cp, cp], -1)), torch.from_numpy(np.stack([zp, zp], -1)))
+    assert np.array_equal(ex2.cpu().numpy()[:, cp.shape[1]:, 0], k["next_cond"])
+    assert rep.get_extra_indices(c, z[:, :0]).shape == (2, c.shape[1], 1)
+    assert rep.convert_output_indices(z) is z
+    # sampling_masker == oracle restatement (pinned to the reference's masked history above), both tuple elements
+    rng = np.random.RandomState(3)
+    B, V, Lc = 4, 4097, 5
+    for j in (0, 3):
+        idx = np.zeros((B, Lc + j + 1, 2), np.int64)
+        for b in range(B):
+            idx[b, :Lc, 0] = [7 + b, 90 + 11 * b, 800, 2000 + b, 4096]; idx[b, :Lc, 1] = [1, 2, 3, 4, 4096]
+            for s in range(j):
+                idx[b, Lc + s] = [20 + 30 * s + b, 5]
+        idx[1, -1, 0] = 4096                           # row 1: the position just drawn is the end token (tuple 1 forces val = end)
+        if j:
+            idx[2, -2] = [4096, 4096]                  # row 2: already ended
+        logits = (rng.randn(B, V) * 2).astype(np.float32)
+        for ti in (0, 1):
+            got = rep.sampling_masker(torch.from_numpy(logits), torch.from_numpy(idx), None, L_cond=Lc, step_j=j, tuple_i=ti).cpu().numpy()
+            want = TO.sampling_masker(logits, idx, Lc, j, ti, (4096, 4096), True, True)
+            assert np.array_equal(got, want), (j, ti)
+    with pytest.raises(ValueError):
+        rep.sampling_masker(torch.from_numpy(logits), torch.from_numpy(idx), None, L_cond=Lc, step_j=1, tuple_i=0)
+
+
+def test_get_indices_contract_and_random_cind_masking_gate(dev):
+    from shapeformer_amd import synthetic
+    b = synthetic.make_batch(5, 2, n_full=8192, n_partial=4096)
+    Xct, Xbd = torch.from_numpy(b["Xct"]), torch.from_numpy(b["Xbd"])
+    m = _model(block=500)
+    rep = m.representer
+    c, z, extra, others = rep.get_indices(Xct, Xbd, stage="test")
+    assert c.dtype == torch.int64 and c.shape[0] == 2 and c.shape[2] == 2 and z.shape[1] >= c.shape[1] and extra.shape == (2, c.shape[1] + z.shape[1], 1)
+    assert set(others) == {"empty_index", "origin_c_indices", "origin_z_indices"} and torch.equal(others["origin_c_indices"], c)
+    assert bool((c[:, -1] == 4096).all()) and np.array_equal(extra.cpu().numpy(), rep.get_extra_indices(c, z).cpu().numpy())
+    feat, q, mode, sp = rep.encode_cloud(Xct)
+    assert feat.shape == (2, 128, 16, 16, 16) and q.shape == (2, 16, 16, 16) and torch.equal(sp, c) and int(mode) == int(others["empty_index"])
+    # Xbd omitted -> empty z (inference route, representers.py:81-82)
+    c2, z2, e2, _ = rep.get_indices(Xct, stage="test")
+    assert z2.shape[1] == 0 and e2.shape[1] == c2.shape[1]
+    # train stage: the numpy-seeded condition subset (representers.py:93-99) only when random_cind_masking is set
+    np.random.seed(4)
+    ct, _, et, ot = rep.get_indices(Xct, Xbd, stage="train")
+    np.random.seed(4)
+    n = np.random.randint(0, c.shape[1])
+    sel = np.sort(np.random.choice(c.shape[1] - 1, n, replace=False))
+    assert torch.equal(ct, torch.cat([c[:, sel], c[:, -1:]], 1)) and torch.equal(ot["origin_c_indices"], c)
+    rep.random_cind_masking = False
+    ct2, _, _, _ = rep.get_indices(Xct, Xbd, stage="train")
+    assert torch.equal(ct2, c)
+
+
+def test_missing_vqdif_checkpoint_raises_and_shapeformer_checkpoint_restores_the_frozen_vqdif(dev, tmp_path):
+    from shapeformer_amd import plugin as P, synthetic
+    with pytest.raises(FileNotFoundError):          # the reference raises too (representers.py:42-43)
+        P.ARNRepresenter(voxel_res=16, end_tokens=[4096, 4096], block_size=96,
+                         vqvae_opt={"class": "x", "ckpt_path": "experiments/none.ckpt", "yaml_path": "nope.yaml"})
+    m = _model(n_embd=128, n_head=2)          # head dim 64: the training kernels' configuration
+    # perturb the frozen VQDIF so that "restored from the checkpoint" is distinguishable from "regenerated from the hash"
+    core = m.representer.vqvae_model.core
+    sd = {k: v.copy() for k, v in core.state_dict_np().items()}
+    sd["encoder.fc_pos.bias"] = sd["encoder.fc_pos.bias"] + np.float32(0.05)
+    core.load_state_dict(sd)
+    X = torch.from_numpy(synthetic.make_batch(7, 1, n_partial=4096)["Xct"])
+    want = m.representer.get_indices(X, stage="test")[0]
+    path = m.save_checkpoint(str(tmp_path / "sf.ckpt"))
+    m2 = P.ShapeFormerModel.load_from_checkpoint(path)                     # hyper_parameters were saved by default
+    assert torch.equal(m2.representer.get_indices(X, stage="test")[0], want)
+    m3 = _model(n_embd=128, n_head=2)
+    m3.make_trainer(dict(lr=1e-2))
+    m3.load_checkpoint(path)                                               # weights-only file: the trainer must follow the NEW tensors
+    assert torch.equal(m3.representer.get_indices(X, stage="test")[0], want)
+    t = np.load(os.path.join(G, "gpt_tiny.npz"))
+    c, z = torch.from_numpy(t["c_idx"]), torch.from_numpy(t["z_idx"])
+    l0 = float(m3.trainer.training_step(c, z))
+    l1 = float(m3.trainer.training_step(c, z))
+    l2 = float(m3.trainer.training_step(c, z))
+    assert l2 < l0, (l0, l1, l2)                                           # the optimizer updates the tensors the forward reads

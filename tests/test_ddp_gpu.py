@@ -1,0 +1,108 @@
+"""GPU: data-parallel training of the REAL trainers with world_size 2 (BASELINE config 5; trainer.py:22,49-56,93 = Lightning
+DDP in the reference).  Two worker processes share cuda:0 and rendezvous over gloo (tests/ddp_worker.py); the parent runs the
+same two items as ONE batch of 2.  Checks: the bucketed all-reduce is fired from inside the backward pass in completion order;
+the averaged gradient of 2 ranks x batch 1 equals the single-process batch-2 gradient; both ranks end with identical
+weights; VQDIF: gradient mean and EMA codebook statistics (count, sum) are reduced over ranks -> identical codebooks."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def ranks(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("ddp") / "w")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return [np.load(out + f".rank{r}.npz") for r in range(2)]
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_gpt_trainer_two_ranks_equal_one_process_batch_two(dev, ranks):
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    from shapeformer_amd.train import GPTTrainer
+    kw = dict(n_embd=128, n_layers=(2, 1), block_size=96)
+    g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    t = np.load(os.path.join(G, "gpt_tiny.npz"))
+    c, z = torch.from_numpy(t["c_idx"]), torch.from_numpy(t["z_idx"])
+    tr = GPTTrainer(g, lr=1e-3)
+    w0 = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr.params[:24]])
+    loss = tr.loss_and_grad(c, z)
+    ref = tr.flat_grad.detach().cpu().numpy()
+    r0, r1 = ranks
+    # the collectives were launched by the backward pass itself (not by finish()), block by block in completion order
+    assert int(r0["gpt_pending_before_finish"]) == len(tr.buckets.ranges)
+    assert list(r0["gpt_order"]) == ["heads", "L2", "L1", "L0", "emb"] == list(r1["gpt_order"])
+    assert np.array_equal(r0["gpt_grad"], r1["gpt_grad"])                    # same averaged gradient on both ranks
+    assert abs(0.5 * (float(r0["gpt_loss"]) + float(r1["gpt_loss"])) - float(loss.item())) < 1e-5
+    # fp32: the batch-2 weight-gradient GEMMs sum 2x the rows in another order than (rank 0) + (rank 1)
+    e = _rel(r0["gpt_grad"], ref)
+    assert e < 2e-6, e
+    # after two optimizer steps both replicas hold the same weights
+    assert np.array_equal(r0["gpt_w"], r1["gpt_w"]) and np.isfinite(float(r0["gpt_loss2"]))
+    tr.optimizer_step()
+    tr.training_step(c, z)
+    w = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr.params[:24]])
+    # Adam divides by sqrt(v): where a gradient is ~0 its rounding noise decides the sign of a full lr-sized step, so the
+    # weights are compared through the update they received (direction), not element by element
+    d1, d2 = (r0["gpt_w"] - w0).astype(np.float64), (w - w0).astype(np.float64)
+    assert float((d1 * d2).sum() / (np.linalg.norm(d1) * np.linalg.norm(d2))) > 0.9999
+    assert float(np.abs(r0["gpt_w"] - w).max()) <= 2 * 2 * 1e-3 + 1e-6
+
+
+def test_vqdif_trainer_two_ranks_gradient_mean_and_shared_ema_codebook(dev, ranks):
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.train_vqdif import VQDIFTrainer
+    T = np.load(os.path.join(G, "vqdif_train.npz"))
+    Xbd = np.concatenate([T["Xbd"], T["Xbd"][:, ::-1] * np.float32(0.9)], 0)
+    Xtg = np.concatenate([T["Xtg"], T["Xtg"][:, ::-1]], 0)
+    Ytg = np.concatenate([T["Ytg"], T["Ytg"][:, ::-1]], 0)
+    vt = VQDIFTrainer(W.make_state_dict(W.vqdif_spec(16)), res=16, device=dev, lr=1e-3, beta=float(T["beta"]))
+    o = vt.training_step(dict(Xbd=Xbd, Xtg=Xtg, Ytg=Ytg))
+    r0, r1 = ranks
+    assert np.array_equal(r0["vq_grad"], r1["vq_grad"])
+    # EMA statistics are all-reduced: every rank keeps the SAME codebook, equal to the one-process batch-2 update
+    assert np.array_equal(r0["vq_emb"], r1["vq_emb"]) and np.array_equal(r0["vq_N"], r1["vq_N"])
+    assert np.abs(r0["vq_N"] - vt.N.cpu().numpy()).max() < 1e-5
+    assert _rel(r0["vq_emb"], vt.emb.cpu().numpy()) < 1e-5
+    assert abs(0.5 * (float(r0["vq_loss"]) + float(r1["vq_loss"])) - float(o["loss"])) < 1e-5
+    e = _rel(r0["vq_grad"], vt.flat_g.cpu().numpy())
+    assert e < 2e-5, e
+    assert np.array_equal(r0["vq_p"], r1["vq_p"])
+    assert float(np.abs(r0["vq_p"] - vt.flat_p.cpu().numpy()).max()) <= 2 * 1e-3 + 1e-6      # one Adam step of lr 1e-3 (see above)
+
+
+def test_bench_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` without a torchrun environment must start 2 ranks and report n_gpus 2 (on this 1-GPU box the
+    ranks share cuda:0 over gloo: --share-device).  Tiny workload; the value is not a measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "1", "--warmup", "0",
+                        "--batch", "4", "--ar-steps", "4", "--decode-res", "32", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and line[0]["n_gpus"] == 2 and line[0]["config"]["parallelism"] == "shard2"
+    # and the guard: asking for more ranks than GPUs is an error, never a silent 1-rank run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "only" in (r.stdout + r.stderr)

@@ -15,7 +15,7 @@ def _opt():
         voxel_res=16, end_tokens=[4096, 4096], vocab_sizes=[4097, 4097], extra_vocab_sizes=[4097], block_size=500, tuple_n=2,
         representer_opt={"class": P + "representers.AR_N", "kwargs": dict(
             voxel_res=16, uncond=False, no_val_ind=False, block_size=500, end_tokens=[4096, 4096], random_cind_masking=True,
-            mask_invalid_completion=True,
+            mask_invalid_completion=True, allow_generated_weights=True,   # no checkpoints ship: opt in to hash weights
             vqvae_opt={"class": "shapeformer.models.vqdif.vqdif.VQDIF", "ckpt_path": "experiments/none.ckpt",
                        "yaml_path": "configs/vqdif/shapenet_res16.yaml"})},
         transformer_opt={"class": P + "transformer.mingpt.CondTupleGPT", "kwargs": dict(
@@ -161,6 +161,7 @@ def test_checkpoint_resume_is_bit_exact_for_both_models(dev, tmp_path):
     path = m1.save_checkpoint(str(tmp_path / "ck" / "sf.ckpt"), hyper_parameters=opt["pl_model_opt"]["kwargs"])
     want = steps(m1, 2, 2)
     ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert "optimizer_states" not in ck and "sfmi_optimizer_state" in ck and ck["hyper_parameters"]["block_size"] == 500
     assert "transformer.blocks.0.1.attn.key.weight" in ck["state_dict"] and "transformer.blocks.1.0.attn.mask" in ck["state_dict"]
     assert "representer.vqvae_model.encoder.fc_pos.weight" in ck["state_dict"] and ck["global_step"] == 2
     m2 = P.instantiate_from_opt(opt["pl_model_opt"])

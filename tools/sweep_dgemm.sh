@@ -4,8 +4,10 @@ out=${1:-gpurun_out/r2/sweep.txt}; mkdir -p $(dirname $out); : > $out
 run() {  # name, env, extra args
   echo "== $1 [$2] $3" >> $out
   local sk=""; local ex="$3"
+  local wide=0
+  if [[ "$ex" == WIDE* ]]; then wide=1; ex="${ex#WIDE}"; fi
   if [[ "$ex" == SKIP=* ]]; then sk="${ex%% *}"; sk="${sk#SKIP=}"; ex="${ex#SKIP=$sk}"; fi
-  SFMI_DECODE_SKIP="$sk" SFMI_DGEMM_LDS="$2" timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernels $ex 2>/dev/null | python -c "
+  SFMI_DGEMM_WIDE=$wide SFMI_DECODE_SKIP="$sk" timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernels $ex 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
