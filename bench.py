@@ -144,7 +144,7 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
     def abody():
         for li in range(len(gpt.layers)):
             L_.check(L_.lib().sfmi_gpt_attn_decode_f32(L_.ptr(st["qkv"]), L_.ptr(gpt.zero_bqkv), L_.ptr(st["Kc"][li]), L_.ptr(st["Vc"][li]),
-                                                      L_.ptr(st["len"]), L_.ptr(st["y"]), 1, B, D, gpt.H, gpt.Lmax + 1, L_.stream_ptr()), "attn")
+                                                      L_.ptr(st["len"]), L_.ptr(st["y"]), 1, B, D, gpt.H, gpt.Lmax + 1, None, L_.stream_ptr()), "attn")
     abody(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):

@@ -117,9 +117,11 @@ int sfmi_decode_gemm_wide_f32(const float* x, const float* Wp16, const float* c1
 int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                               const int* seq, const int* len, const int* Lc, float* resid, int B, int D, int Lmax, int end0,
                               void* stream);
-/* CausalSelfAttention.forward for ONE new position per row against the KV cache (appends the new K,V row first) */
+/* CausalSelfAttention.forward for ONE new position per row against the KV cache (appends the new K,V row first).
+ * shared_len (optional, device int): positions < shared_len[0] are read from ROW 0's cache by every row - the `sample_n` copies
+ * of one condition (shapeformer.py:222-260) keep the condition's keys / values once */
 int sfmi_gpt_attn_decode_f32(const float* qkv_packed, const float* unused, float* Kc, float* Vc, const int* len, float* y_packed,
-                             int S, int B, int D, int H, int Lmax, void* stream);
+                             int S, int B, int D, int H, int Lmax, const int* shared_len, void* stream);
 /* one tuple element of one sampling step per row: sampling_masker (representers.py:120-155) + filter_sampling_logits /
  * sample_logits (models/common.py:260-299: temperature, top-k with ties, top-p) + inverse-CDF draw from counter-hash uniforms
  * indexed (step, tuple, row_offset + b) + best_in_first greedy row + log-prob + optional masked-logit history; writes the

@@ -536,13 +536,19 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
                                                            const float* __restrict__ bqkv /*unused*/, float* __restrict__ Kc,
                                                            float* __restrict__ Vc /*(B,H,Lmax,HD)*/, const int* __restrict__ len,
                                                            float* __restrict__ y /*(M,D)*/, int S, int M, int D, int Lmax,
-                                                           int HD, float scale) {
+                                                           int HD, float scale, const int* __restrict__ shared_len) {
   __shared__ __attribute__((aligned(16))) float qs[64], kn[64], vn[64], sc[1024], red[2 * ATT_WAVES], yacc[ATT_WAVES][64];
   const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = len[b] - 1;  // position being processed
   const int nq4 = HD / 4;
   float* Kb = Kc + ((long long)b * H + h) * Lmax * HD;
   float* Vb = Vc + ((long long)b * H + h) * Lmax * HD;
+  // shared prefix (sample_n copies of ONE condition, shapeformer.py:222-260): keys / values of positions < shared_len[0] were
+  // written once, by row 0's prefill, and every row reads them from row 0's cache (one HBM read, L2 / Infinity-Cache hits
+  // for the other rows); a row's own cache holds its tail only
+  const int nshared = shared_len ? shared_len[0] : 0;
+  const float* Kb0 = Kc + (long long)h * Lmax * HD;
+  const float* Vb0 = Vc + (long long)h * Lmax * HD;
   const int c4 = lane & 15, kk = lane >> 4;
   const bool cok = c4 < nq4;
   // the first 256 keys' loads are issued BEFORE the q/k/v hand-off barrier (they only need `t`): the HBM latency of the
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * 64 + wave * 4 + kk;
       kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Kb + (long long)i * HD + 4 * c4));
+      if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Kb0 : Kb) + (long long)i * HD + 4 * c4));
     }
   };
   f32x4 kf0[4];
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restri
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * 64 + wave * 4 + kk;
       vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vb + (long long)i * HD + 4 * c4));
+      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Vb0 : Vb) + (long long)i * HD + 4 * c4));
     }
   };
   f32x4 vf0[4];
@@ -1181,11 +1187,11 @@ int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* 
 
 // replaces CausalSelfAttention.forward for ONE new position per row with a KV cache (mingpt.py:73-91)
 int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc, float* Vc, const int* len, float* y,
-                             int S, int B, int D, int H, int Lmax, void* stream) {
+                             int S, int B, int D, int H, int Lmax, const int* shared_len, void* stream) {
   if (!qkv_part || !bqkv || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
   const int HD = D / H;
   hipLaunchKernelGGL(attn_decode_kernel, dim3(B, H), dim3(1024), 0, (hipStream_t)stream, qkv_part, bqkv, Kc, Vc, len, y, S, B, D,
-                     Lmax, HD, 1.0f / sqrtf((float)HD));
+                     Lmax, HD, 1.0f / sqrtf((float)HD), shared_len);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

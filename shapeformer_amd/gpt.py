@@ -184,6 +184,7 @@ class CondTupleGPT:
                   slab=f(L.lib().sfmi_decode_gemm_slab_floats(Bp, 4 * D, 4)), cnt=torch.zeros(Bp // 16 * (max(4 * D, self.Vpad) // 16 + 1), device=dev, dtype=torch.int32),
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32),
+                  shared=torch.zeros(1, device=dev, dtype=torch.int32),  # shared-prefix length of the sample_n mode (device-resident)
                   seed=torch.zeros(1, device=dev, dtype=torch.int32))   # sampler seed (device-resident: graphs are seed-independent)
         self._state = st
         self._states[slot] = st
@@ -388,6 +389,7 @@ class CondTupleGPT:
             if "attn" not in skip:
                 L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
                                                      L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
+                                                     L.ptr(st["shared"]) if sp.get("shared_prefix") else None,
                                                      L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
             if "gemm" not in skip:
                 self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st)
@@ -409,7 +411,7 @@ class CondTupleGPT:
 
     # ------------------------------------------------------------------ sample_indices
     def _prepare(self, c_tokens, Lc, max_steps, sp_kw, slot=0, row_offset=0, rows_total=None, return_logits=False,
-                 force_tokens=None, use_graph=True):
+                 force_tokens=None, use_graph=True, shared_prefix=False):
         """State + prefill + step-0 embedding + (cached) hipGraph of one decode step for one (micro-)batch."""
         B = c_tokens.shape[0]
         if B > 256:
@@ -430,7 +432,8 @@ class CondTupleGPT:
         if return_logits:
             hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
         sp = dict(sp_kw, max_steps=int(max_steps), hist=hist, row_offset=int(row_offset),
-                  rows_total=int(rows_total if rows_total is not None else B), chain=int(slot - 100 if slot >= 100 else 0))
+                  rows_total=int(rows_total if rows_total is not None else B), chain=int(slot - 100 if slot >= 100 else 0),
+                  shared_prefix=bool(shared_prefix))
         if force_tokens is not None:   # (B,max_steps,2) teacher forcing for stepwise parity tests
             ft = torch.zeros(B, max_steps, 2, dtype=torch.int32)
             ft[:, :force_tokens.shape[1]] = torch.as_tensor(force_tokens).to(torch.int32)
@@ -438,12 +441,24 @@ class CondTupleGPT:
             use_graph = False
         P = Lc_max - 1
         st["nval"], st["extra"] = None, None
-        # ragged condition prefixes are packed back to back: the prefill GEMMs / attention do no work on padding rows
-        nrow = [max(l - 1, 0) for l in Lc_host]
-        st["M_packed"] = sum(nrow)
-        st["rowoff"] = torch.tensor([0] + list(np.cumsum(nrow)), dtype=torch.int32).to(self.dev)
-        if P > 0 and st["M_packed"] > 0:
-            self.prefill(st, B, P)
+        if shared_prefix:
+            # all rows carry the SAME condition (the sample_n copies of one shape, shapeformer.py:222-260): prefill it ONCE,
+            # as row 0; its keys / values (positions < Lc-1) are then read from row 0's cache by every row's decode attention
+            assert len(set(Lc_host)) == 1 and bool((st["seq"][:, :Lc_max] == st["seq"][:1, :Lc_max]).all()), \
+                "shared_prefix needs identical condition rows"
+            st["shared"].fill_(P)
+            st["M_packed"] = P
+            st["rowoff"] = torch.tensor([0, P], dtype=torch.int32).to(self.dev)
+            if P > 0:
+                self.prefill(st, 1, P)
+        else:
+            st["shared"].zero_()
+            # ragged condition prefixes are packed back to back: the prefill GEMMs / attention do no work on padding rows
+            nrow = [max(l - 1, 0) for l in Lc_host]
+            st["M_packed"] = sum(nrow)
+            st["rowoff"] = torch.tensor([0] + list(np.cumsum(nrow)), dtype=torch.int32).to(self.dev)
+            if P > 0 and st["M_packed"] > 0:
+                self.prefill(st, B, P)
         # embedding of the last condition token (step-0 input) into the fragment-packed residual buffer
         L.check(L.lib().sfmi_gpt_embed_packed_f32(L.ptr(self.E[0]), L.ptr(self.E[1]), L.ptr(self.Ex), L.ptr(self.pos_emb),
                                                   L.ptr(self.cond_pos_emb), L.ptr(st["seq"]), L.ptr(st["len"]), L.ptr(st["Lc"]),
@@ -481,7 +496,7 @@ class CondTupleGPT:
     @torch.no_grad()
     def sample(self, c_tokens, Lc, max_steps=512, top_k=100, top_p=0.4, temperature=1.0, best_in_first=True,
                mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True, use_graph=True,
-               return_logits=False, check_every=32, force_tokens=None, to_host=True, after_prefill=None):
+               return_logits=False, check_every=32, force_tokens=None, to_host=True, after_prefill=None, shared_prefix=False):
         """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32.
 
         Returns dict(samples (B,steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
@@ -489,7 +504,7 @@ class CondTupleGPT:
         inverse-CDF draw on counter-hash uniforms (oracle/gpt_oracle.py:uniforms)."""
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
         ctx = self._prepare(c_tokens, Lc, max_steps, sp_kw, return_logits=return_logits, force_tokens=force_tokens,
-                            use_graph=use_graph)
+                            use_graph=use_graph, shared_prefix=shared_prefix)
         st, sp, B, steps, g, hist, Lc_host = (ctx[k] for k in ("st", "sp", "B", "steps", "graph", "hist", "Lc_host"))
         if after_prefill is not None:
             after_prefill()

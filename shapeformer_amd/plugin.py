@@ -341,7 +341,7 @@ class ShapeFormerModel:
         res = self.transformer.sample(c.to(torch.int32), torch.full((B,), L_c, dtype=torch.int32), max_steps=int(max_steps), top_k=top_k,
                                       top_p=top_p, temperature=temperature, best_in_first=best_in_first, mask_invalid=rep.mask_invalid,
                                       mask_invalid_completion=rep.mask_invalid_completion, seed=seed, stop_early=True, check_every=8,
-                                      return_logits=True)
+                                      return_logits=True, shared_prefix=bool(B > 1 and (c == c[:1]).all()))   # sample_n copies
         x = res["samples"]
         end = torch.tensor(self.end_tokens)
         ended = (x == end[None, None, :]).any(-1).all(0)          # step j: no row without a stop token

@@ -230,3 +230,24 @@ def test_wide_single_chain_decode_matches_64_row_kernels(dev, reps):
     d = g.sample(ct, Lt, max_steps=steps, seed=5, stop_early=False)
     assert d["samples"].shape == (3 * reps, steps, 2)
     assert (d["samples"][0] == a["samples"][0]).all()   # greedy row 0 (best_in_first) is batch-size independent here
+
+
+def test_shared_prefix_sampling_is_bit_identical_to_expanded_rows(dev):
+    """sample_n copies of ONE condition (VisShapeFormer.compute_batch, shapeformer.py:222-260): prefill once, the condition's
+    keys / values live once (row 0's cache) and every row's decode attention reads them from there - tokens, log-probs and
+    masked-logit history must equal the run that prefills and stores the condition S times."""
+    from shapeformer_amd.gpt import CondTupleGPT
+    sd, sd_t, cfg = _tiny()
+    g = CondTupleGPT(sd, n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    g.PREFILL_BLAS_ROWS = None            # same prefill kernel for 1 and S rows (the library GEMM picks kernels by size)
+    c3, Lc3 = _cond_rows()
+    for S in (5, 16, 40):
+        c = torch.from_numpy(c3[:1, :Lc3[0]]).expand(S, -1, -1).contiguous()
+        Lc = torch.full((S,), int(Lc3[0]), dtype=torch.int32)
+        a = g.sample(c, Lc, max_steps=30, seed=4, stop_early=False, return_logits=True)
+        b = g.sample(c, Lc, max_steps=30, seed=4, stop_early=False, return_logits=True, shared_prefix=True)
+        assert torch.equal(a["samples"], b["samples"]) and torch.equal(a["log_prob"], b["log_prob"])
+        assert all(torch.equal(x, y) for x, y in zip(a["logits_history"], b["logits_history"]))
+        assert len(set(map(tuple, a["samples"][1:, :, 0].tolist()))) > 1          # the stochastic rows do differ from each other
+    with pytest.raises(AssertionError):
+        g.sample(torch.from_numpy(c3), torch.from_numpy(Lc3), max_steps=4, shared_prefix=True)   # different rows: refused
