@@ -103,6 +103,14 @@ int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* 
 /* CausalSelfAttention.forward over the rows of a prefix (mingpt.py:73-91) on f32 MFMA; also writes the (B,H,Lmax,64) KV caches */
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                               int Lmax, const int* rowoff, void* stream);
+/* plain f32 GEMM on the matrix cores (csrc/sgemm.hip): row-major C (M,N;ldc) = op(A) op(B) (+C) (+bias[n]) -> act -> (+resid).
+ * transA == 0: A stored (M,K;lda), else (K,M;lda); transB != 0: B stored (N,K;ldb) (nn.Linear weight), else (K,N;ldb).
+ * Replaces the sgemm behind nn.Linear and its autograd (mingpt.py:46-111) in the prefill and the training step.
+ * ws (optional, >= splits*M*N floats): split-K scratch for outputs with too few tiles (weight gradients), summed in slice order */
+int sfmi_sgemm_mfma_splits(int M, int N, int K);
+int sfmi_sgemm_mfma_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                        int ldc, int accumulate, const float* bias, int act, const float* resid, float* ws, long long ws_floats,
+                        void* stream);
 int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream); /* shapeformer.py:132-140 */
 /* decode step (M = B <= 256 rows; packed x/out/resid must hold ceil(M/64)*64 rows when M > 96, ceil(M/16)*16 otherwise) */
 size_t sfmi_skinny16_pack_floats(int N, int K);

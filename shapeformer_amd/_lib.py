@@ -82,6 +82,8 @@ PROTOTYPES = {
     "sfmi_skinny16_pack_weight": (i32, [c_ptr, i32, i32, c_ptr]),
     "sfmi_gpt_embed_f32": (i32, [c_ptr] * 15 + [i32] * 5 + [c_ptr, i32, c_ptr]),
     "sfmi_gpt_rowprep_f32": (i32, [c_ptr] * 12 + [i32] * 5 + [c_ptr, i32, c_ptr]),
+    "sfmi_sgemm_mfma_splits": (i32, [i32, i32, i32]),
+    "sfmi_sgemm_mfma_f32": (i32, [i32] * 5 + [c_ptr, i32, c_ptr, i32, c_ptr, i32, i32, c_ptr, i32, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_ce_rows_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr]),
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr, c_ptr]),
     "sfmi_gpt_attn_prefill_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, c_ptr]),

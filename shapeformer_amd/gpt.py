@@ -41,7 +41,9 @@ class _Layer:
 
 class CondTupleGPT:
     S_PROJ, S_FC2 = 1, 4   # in-kernel split-K of the N = n_embd GEMMs (64 n-tiles -> 256 workgroups)
-    PREFILL_BLAS_ROWS = 2048   # prefill GEMMs with at least this many rows use the library sgemm (None: never)
+    import os as _os
+    # prefill GEMMs with at least this many rows go to the library sgemm; None (default): every GEMM is csrc/sgemm.hip
+    PREFILL_BLAS_ROWS = 2048 if _os.environ.get("SFMI_ROCBLAS") == "1" else None
 
     def _blas(self):
         if not hasattr(self, "_has_blas"):
@@ -223,12 +225,18 @@ class CondTupleGPT:
                                            self.end[0], L.ptr(st.get("rowoff")), int(st.get("M_packed") or 0), L.stream_ptr()), "sfmi_gpt_embed_f32")
 
     def _gemm(self, x, w, bias, resid, y, M, N, K, act=0, og=0, ogs=0):
-        # plain GEMMs of a long prefill go to rocBLAS (csrc/blas.hip; +2 % on the 192-shape pass).  Its kernel choice depends
-        # on M, so per-row results can differ in the last bits between different row counts; set PREFILL_BLAS_ROWS = None
-        # to keep every prefill on the tile kernel, whose per-row result is independent of the launch size.
+        """y (M,N) = act(x (M,K) w (N,K)^T + bias) + resid: the plain GEMMs of the prefill / teacher-forced forward
+        (mingpt.py:46-111 Linear layers).  csrc/sgemm.hip; its per-row result does not depend on how many rows are in the
+        launch, so sampled tokens are bit-identical however the rows are split into chains.  PREFILL_BLAS_ROWS (None by
+        default; SFMI_ROCBLAS=1 sets 2048) sends long prefills to the library sgemm instead - its kernel choice depends on M,
+        so that identity then holds only to fp32 rounding."""
         if self.PREFILL_BLAS_ROWS is not None and M >= self.PREFILL_BLAS_ROWS and not og and N % 4 == 0 and self._blas() \
                 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
             L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
+            return
+        if not og and N % 4 == 0 and K % 4 == 0:
+            L.check(L.lib().sfmi_sgemm_mfma_f32(0, 1, M, N, K, L.ptr(x), K, L.ptr(w), K, L.ptr(y), N, 0, L.ptr(bias), act, L.ptr(resid),
+                                                None, 0, L.stream_ptr()), "sfmi_sgemm_mfma_f32")
             return
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, og, ogs,
                                       L.stream_ptr()), "sfmi_gemm_f32")

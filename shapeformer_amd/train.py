@@ -50,7 +50,6 @@ class GPTTrainer:
             o += t.numel()
         self.flat_m = torch.zeros(n, device=self.dev)
         self.flat_v = torch.zeros(n, device=self.dev)
-        self._wT = {}
         # gradient buckets for the overlapped all-reduce: one per block, one for both heads, one for the embeddings
         # (flat order = backward-completion order reversed: blocks 0..n-1, heads, embeddings)
         off, o = {}, 0
@@ -71,24 +70,41 @@ class GPTTrainer:
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
 
     def _blas(self):
-        """Plain M-thousands-row GEMMs of the training step go through rocBLAS when it can be bound (csrc/blas.hip)."""
+        """The plain GEMMs of the step (forward, dX = dY W, dW = dY^T X) run on csrc/sgemm.hip; SFMI_ROCBLAS=1 opts into the
+        library sgemm (csrc/blas.hip, dlopen) where it can be bound."""
         if not hasattr(self, "_has_blas"):
-            self._has_blas = bool(L.lib().sfmi_blas_available())
+            import os
+            self._has_blas = os.environ.get("SFMI_ROCBLAS") == "1" and bool(L.lib().sfmi_blas_available())
         return self._has_blas
+
+    def _sgemm(self, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, accumulate=False, bias=None, act=0, resid=None):
+        """csrc/sgemm.hip with split-K scratch for outputs of few tiles (the weight gradients)."""
+        lib = L.lib()
+        need = lib.sfmi_sgemm_mfma_splits(M, N, K) * M * N
+        ws = None
+        if need > M * N:
+            if getattr(self, "_sg_ws", None) is None or self._sg_ws.numel() < need:
+                self._sg_ws = torch.empty(need, device=self.dev)
+            ws = self._sg_ws
+        L.check(lib.sfmi_sgemm_mfma_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(C), ldc, int(accumulate), L.ptr(bias),
+                                        act, L.ptr(resid), L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr()), "sgemm_mfma")
 
     def _gemm(self, x, w, bias, resid, y, M, N, K, act=0):
         if self._blas() and M >= 256 and N % 4 == 0 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
             L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
             return
+        if N % 4 == 0 and K % 4 == 0:
+            self._sgemm(0, 1, M, N, K, x, K, w, K, y, N, bias=bias, act=act, resid=resid)
+            return
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, 0, 0, L.stream_ptr()), "gemm")
 
     def _dx(self, dY, wname, w, M, N, K):
-        """dX (M,K) = dY (M,N) W (N,K): library NN product, or the tile kernel on a cached transposed weight copy."""
+        """dX (M,K) = dY (M,N) W (N,K)."""
         dx = self._f(M, K)
         if self._blas() and M >= 256:
             L.check(L.lib().sfmi_sgemm_f32(0, 0, M, K, N, 1.0, L.ptr(dY), N, L.ptr(w), K, 0.0, L.ptr(dx), K, L.stream_ptr()), "sgemm dx")
         else:
-            self._gemm(dY, self._wt(wname, w), None, None, dx, M, K, N)
+            self._sgemm(0, 0, M, K, N, dY, N, w, K, dx, K)      # W (N,K) is the (k,n)-stored right operand: no transposed copy
         return dx
 
     def _T(self, x, R, C, ld=None, Rpad=None):
@@ -97,15 +113,8 @@ class GPTTrainer:
         L.check(L.lib().sfmi_transpose_f32(L.ptr(x), L.ptr(out), R, C, ld or C, Rpad, L.stream_ptr()), "transpose")
         return out
 
-    def _wt(self, name, w):
-        """Transposed weight copy (refreshed after every optimizer step) for dX = dY W as an NT GEMM."""
-        if name not in self._wT:
-            N, K = w.shape
-            self._wT[name] = self._T(w, N, K, Rpad=_ru(N, 16))
-        return self._wT[name]
-
     def _dW(self, dY, X, M, N, K, gname):
-        """grad[gname] (N,K) += dY^T (N,M) X (M,K)  via NT GEMM on transposed activations (K-dim = M padded to 16)."""
+        """grad[gname] (N,K) (+)= dY^T (N,M) X (M,K)."""
         if self._blas() and M >= 256:      # dY^T X directly (transposed left operand), accumulating when asked to
             out = self.grad[gname]
             if N > K and not self._acc and M >= 1024:
@@ -118,12 +127,8 @@ class GPTTrainer:
             L.check(L.lib().sfmi_sgemm_f32(1, 0, N, K, M, 1.0, L.ptr(dY), N, L.ptr(X), K, 1.0 if self._acc else 0.0, L.ptr(out), K,
                                            L.stream_ptr()), "sgemm dW")
             return
-        Mp = _ru(M, 16)
-        dYT, XT = self._T(dY, M, N, Rpad=Mp), self._T(X, M, K, Rpad=Mp)
-        Np = _ru(N, 1)
         out = self.grad[gname]
-        assert K % 32 == 0
-        self._gemm(dYT, XT, None, out if self._acc else None, out, N, K, Mp)
+        self._sgemm(1, 0, N, K, M, dY, N, X, K, out, K, accumulate=self._acc)   # dY^T X with dY / X read in place (no transposes)
 
     def _colsum(self, x, M, N, gname):
         lib = L.lib()
@@ -317,7 +322,6 @@ class GPTTrainer:
         L.check(L.lib().sfmi_adamw_multi_f32(L.ptr(tb["p"]), L.ptr(tb["foff"]), L.ptr(tb["wd"]), L.ptr(tb["ct"]), L.ptr(tb["co"]), L.ptr(tb["cl"]),
                                              tb["n"], L.ptr(self.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), self.lr, self.betas[0],
                                              self.betas[1], self.eps, self.step_count, L.stream_ptr()), "adamw_multi")
-        self._wT.clear()                 # transposed copies are stale now
         self.g.mark_decode_weights_stale()  # LN-folded / fragment-packed decode weights are rebuilt at the next decode use
 
     def optimizer_state(self):

@@ -104,7 +104,7 @@ def test_adamw_step_matches_torch_optim_and_training_reduces_loss(dev):
     assert out["samples"].shape == (2, 4, 2)
 
 
-def test_library_gemm_binding_and_large_row_training_path(dev):
+def test_library_gemm_binding_and_large_row_training_path(dev, monkeypatch):
     """csrc/blas.hip: the lazily bound rocBLAS sgemm (row-major wrapper, all transpose forms, fused epilogue) against float64,
     and the training step at M = B*L >= 1024 rows, where the trainer routes its plain GEMMs through it."""
     from oracle import gpt_oracle as GO
@@ -147,13 +147,17 @@ def test_library_gemm_binding_and_large_row_training_path(dev):
             out[bb, :n, 1] = rs.randint(0, 4096, n)
         return torch.from_numpy(out)
     c, z = rows(150), rows(200)
-    tr = GPTTrainer(g)
-    assert tr._blas()
-    loss = tr.loss_and_grad(c, z).item()
     want_loss, og, _ = _oracle_grads(sd, cfg, c, z)
-    assert abs(loss - want_loss) < 1e-5 * max(1.0, abs(want_loss))
-    for name, keys in _map(tr, cfg).items():
-        want = torch.cat([og[k].reshape(-1, og[k].shape[-1]) if og[k].dim() > 1 else og[k] for k in keys], 0)
-        got = tr.grad[name].cpu().reshape(want.shape)
-        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
-        assert err < 2e-3, (name, err)
+    # default: every GEMM of the step on csrc/sgemm.hip (forward, dX = dY W, dW = dY^T X with split-K); SFMI_ROCBLAS=1: library
+    for use_lib in (False, True):
+        if use_lib:
+            monkeypatch.setenv("SFMI_ROCBLAS", "1")
+        tr = GPTTrainer(g)
+        assert tr._blas() == use_lib
+        loss = tr.loss_and_grad(c, z).item()
+        assert abs(loss - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+        for name, keys in _map(tr, cfg).items():
+            want = torch.cat([og[k].reshape(-1, og[k].shape[-1]) if og[k].dim() > 1 else og[k] for k in keys], 0)
+            got = tr.grad[name].cpu().reshape(want.shape)
+            err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+            assert err < 2e-3, (name, use_lib, err)
