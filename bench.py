@@ -205,7 +205,7 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
     nv = torch.full((Be,), P, device=dev, dtype=torch.int32)
     Kc, Vc = st["Kc"][0], st["Vc"][0]
     ms = ev_time(lambda: L_.check(lib.sfmi_gpt_attn_prefill_f32(L_.ptr(qkvp), L_.ptr(Kc), L_.ptr(Vc), L_.ptr(nv), L_.ptr(yp), Be, P, D, gpt.H,
-                                                                gpt.Lmax + 1, None, L_.stream_ptr()), "attn_prefill"), 10)
+                                                                gpt.Lmax + 1, None, 0.0, 0, L_.stream_ptr()), "attn_prefill"), 10)
     # causal: P(P+1)/2 (query, key) pairs x 2 GEMMs x 2 x 64 flops per head
     add("attn_prefill_mfma_kernel", ms, "mfma", Be * gpt.H * (P * (P + 1) / 2) * 4 * 64, 1e12, F32, "TFLOP/s",
         f"{Be} rows x {gpt.H} heads x {P} positions, causal (useful FLOPs only)")

@@ -157,7 +157,9 @@ int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, 
 int sfmi_ce_fwd_bwd_f32(const float* logits, const int* target, float* loss_rows, float* dlogits, int M, int V, int ld, int L,
                         int t0, float scale, void* stream);                                                    /* shapeformer.py:132-140 */
 int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* lse /*2*B*H*L floats scratch*/, float* dqkv,
-                      int B, int L, int D, int H, void* stream);                                                                           /* mingpt.py:73-91 */
+                      int B, int L, int D, int H, float attn_drop_p, unsigned attn_drop_seed /* the forward's mask */, void* stream);
+/* nn.Dropout(p) forward == backward on a flat tensor: y = x * mask / (1-p), mask_i = hash(seed, i) >= p (mingpt.py:90,105,218,292) */
+int sfmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned seed, void* stream);                                                                           /* mingpt.py:73-91 */
 int sfmi_embed_scatter_f32(const float* dx, const int* idx, long long* acc, long long M, int D, void* stream);
 int sfmi_fixed_to_float_f32(const long long* acc, float* out, long long n, int accumulate, void* stream);
 int sfmi_add_f32(const float* a, const float* b, float* out, long long n, void* stream);

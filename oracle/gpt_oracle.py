@@ -32,9 +32,20 @@ def embeddings(sd, idx, extra, L_cond):
     return x + pos
 
 
-def block(sd, p, x, n_head, kv=None):
-    """mingpt.py:46-111 (eval: dropout = identity).  With kv=(K,V) caches: x holds only the new
-    positions; returns the updated caches (used by the KV-cached baseline, equivalent by A11)."""
+def dropout_mask(key, site, shape, p):
+    """nn.Dropout(p) as an explicit multiplier tensor: element i (C order) is 0 iff hash_unit("dropout-<key>-<site>")[i] < p,
+    else 1/(1-p) - the counter-hash masks the HIP training kernels apply (csrc/sfmi_common.h:sfmi_dropout_mul).  torch's
+    own Philox stream cannot be reproduced on the device, so both sides use this one (same Bernoulli(1-p) distribution)."""
+    from shapeformer_amd.weights import hash_unit
+    n = int(np.prod(shape))
+    u = hash_unit(f"dropout-{key}-{site}", n).reshape(shape)
+    return torch.from_numpy(np.where(u < np.float32(p), np.float32(0.0), np.float32(1.0) / (np.float32(1.0) - np.float32(p))).astype(np.float32))
+
+
+def block(sd, p, x, n_head, kv=None, drop=None):
+    """mingpt.py:46-111.  drop=None: eval (dropout = identity); drop=(key, site_prefix, p_resid, p_attn): train mode with the
+    explicit masks of `dropout_mask`.  With kv=(K,V) caches: x holds only the new positions; returns the updated caches (used
+    by the KV-cached baseline, equivalent by A11)."""
     B, Tn, C = x.shape
     h = F.layer_norm(x, (C,), sd[p + "ln1.weight"], sd[p + "ln1.bias"], 1e-5)
     k = F.linear(h, sd[p + "attn.key.weight"], sd[p + "attn.key.bias"]).view(B, Tn, n_head, C // n_head).transpose(1, 2)
@@ -48,11 +59,19 @@ def block(sd, p, x, n_head, kv=None):
     causal = torch.tril(torch.ones(Tk, Tk, dtype=torch.bool))[Tk - Tn:, :]
     att = att.masked_fill(~causal, float("-inf"))
     att = F.softmax(att, dim=-1)
+    if drop is not None and drop[3] > 0:
+        att = att * dropout_mask(drop[0], drop[1] + ".attn", att.shape, drop[3])            # mingpt.py:85
     y = (att @ v).transpose(1, 2).contiguous().view(B, Tn, C)
-    x = x + F.linear(y, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    a = F.linear(y, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    if drop is not None and drop[2] > 0:
+        a = a * dropout_mask(drop[0], drop[1] + ".proj", a.shape, drop[2])                  # mingpt.py:90
+    x = x + a
     h = F.layer_norm(x, (C,), sd[p + "ln2.weight"], sd[p + "ln2.bias"], 1e-5)
     h = F.gelu(F.linear(h, sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"]))
-    x = x + F.linear(h, sd[p + "mlp.2.weight"], sd[p + "mlp.2.bias"])
+    m = F.linear(h, sd[p + "mlp.2.weight"], sd[p + "mlp.2.bias"])
+    if drop is not None and drop[2] > 0:
+        m = m * dropout_mask(drop[0], drop[1] + ".mlp", m.shape, drop[2])                   # mingpt.py:105
+    x = x + m
     return x, (k, v)
 
 
@@ -63,31 +82,38 @@ def head(sd, s, x):
     return F.linear(h, sd[f"heads.{s}.1.weight"])
 
 
-def stage(sd, cfg, s, x, caches=None):
+def stage(sd, cfg, s, x, caches=None, dropout=None):
     new = []
     for n in range(cfg.n_layers[s]):
-        x, kv = block(sd, f"blocks.{s}.{n}.", x, cfg.n_head, None if caches is None else caches[n])
+        li = n + (cfg.n_layers[0] if s else 0)          # site names use the flat layer index, as the HIP trainer does
+        drop = None if dropout is None else (dropout["key"], f"L{li}", dropout["p"][1], dropout["p"][2])
+        x, kv = block(sd, f"blocks.{s}.{n}.", x, cfg.n_head, None if caches is None else caches[n], drop)
         new.append(kv)
     return x, new
 
 
-def forward_logits(sd, cfg, idx, extra, L_cond, target_idx):
-    """CondTupleGPT.forward / compute_logits (mingpt.py:287-296,311-319): teacher-forced logits."""
+def forward_logits(sd, cfg, idx, extra, L_cond, target_idx, dropout=None):
+    """CondTupleGPT.forward / compute_logits (mingpt.py:287-296,311-319): teacher-forced logits.
+    dropout=dict(key=str, p=(embd_pdrop, resid_pdrop, attn_pdrop)): train mode (drops[i] on each stage input, :292)."""
     x = embeddings(sd, idx, extra, L_cond)
-    x, _ = stage(sd, cfg, 0, x)
+    if dropout is not None and dropout["p"][0] > 0:
+        x = x * dropout_mask(dropout["key"], "emb0", x.shape, dropout["p"][0])
+    x, _ = stage(sd, cfg, 0, x, dropout=dropout)
     l0 = head(sd, 0, x)
     x = x + F.embedding(target_idx[..., 0], sd["tok_embs.0.weight"])
-    x, _ = stage(sd, cfg, 1, x)
+    if dropout is not None and dropout["p"][0] > 0:
+        x = x * dropout_mask(dropout["key"], "emb1", x.shape, dropout["p"][0])
+    x, _ = stage(sd, cfg, 1, x, dropout=dropout)
     l1 = head(sd, 1, x)
     return [l0, l1]
 
 
-def training_loss(sd, cfg, c_indices, z_indices, extra):
+def training_loss(sd, cfg, c_indices, z_indices, extra, dropout=None):
     """ShapeFormer.forward + shared_step (shapeformer.py:26-46,132-140): mean of the two CEs over
     outputs from index L_c-1 on, end-token padding included."""
     cz = torch.cat([c_indices, z_indices], dim=1)
     L_c = c_indices.shape[1]
-    logits = forward_logits(sd, cfg, cz[:, :-1], extra[:, :-1], L_c, cz[:, 1:])
+    logits = forward_logits(sd, cfg, cz[:, :-1], extra[:, :-1], L_c, cz[:, 1:], dropout=dropout)
     loss = 0
     for i in range(2):
         lg = logits[i][:, L_c - 1:, :]

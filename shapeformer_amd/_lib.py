@@ -83,10 +83,10 @@ PROTOTYPES = {
     "sfmi_gpt_embed_f32": (i32, [c_ptr] * 15 + [i32] * 5 + [c_ptr, i32, c_ptr]),
     "sfmi_gpt_rowprep_f32": (i32, [c_ptr] * 12 + [i32] * 5 + [c_ptr, i32, c_ptr]),
     "sfmi_sgemm_mfma_splits": (i32, [i32, i32, i32]),
-    "sfmi_sgemm_mfma_f32": (i32, [i32] * 5 + [c_ptr, i32, c_ptr, i32, c_ptr, i32, i32, c_ptr, i32, c_ptr, c_ptr, i64, c_ptr]),
+    "sfmi_sgemm_mfma_f32": (i32, [i32] * 5 + [c_ptr, i32, c_ptr, i32, c_ptr, i32, i32, c_ptr, i32, c_ptr, c_ptr, i64, f32, C.c_uint, c_ptr]),
     "sfmi_ce_rows_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr]),
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr, c_ptr]),
-    "sfmi_gpt_attn_prefill_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, c_ptr]),
+    "sfmi_gpt_attn_prefill_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, f32, C.c_uint, c_ptr]),
     "sfmi_gpt_sample_f32": (i32, [c_ptr] * 12 + [i32] * 10 + [C.c_float, C.c_float] + [i32] * 4 + [C.c_uint, c_ptr, i32, i32, i32, c_ptr]),
     "sfmi_decode_gemm_f32": (i32, [c_ptr] * 6 + [i32] * 8 + [c_ptr, c_ptr, c_ptr]),
     "sfmi_decode_gemm_wide_f32": (i32, [c_ptr] * 6 + [i32] * 8 + [c_ptr, c_ptr, c_ptr]),
@@ -103,7 +103,8 @@ PROTOTYPES = {
     "sfmi_gelu_bwd_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_layernorm_bwd_f32": (i32, [c_ptr] * 8 + [i32, i32, c_ptr]),
     "sfmi_ce_fwd_bwd_f32": (i32, [c_ptr] * 4 + [i32] * 5 + [C.c_float, c_ptr]),
-    "sfmi_attn_bwd_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [c_ptr]),
+    "sfmi_attn_bwd_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [f32, C.c_uint, c_ptr]),
+    "sfmi_dropout_f32": (i32, [c_ptr, c_ptr, i64, f32, C.c_uint, c_ptr]),
     "sfmi_embed_scatter_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, c_ptr]),
     "sfmi_fixed_to_float_f32": (i32, [c_ptr, c_ptr, i64, i32, c_ptr]),
     "sfmi_add_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),

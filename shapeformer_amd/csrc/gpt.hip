@@ -662,7 +662,7 @@ template <int HD>           // head dim 16 / 32 / 64
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
                                                                 float* __restrict__ Vc, const int* __restrict__ nval,
                                                                 float* __restrict__ y, int P, int D, int Lmax, float scale,
-                                                                const int* __restrict__ rowoff) {
+                                                                const int* __restrict__ rowoff, float drop_p, unsigned drop_seed) {
   constexpr int AP_KS = HD + 4, AP_VS = HD + 16, KK = HD / 4, DT = HD / 16;
   __shared__ __attribute__((aligned(16))) float Ks[64 * AP_KS], Vs[64 * AP_VS], Ps[4][16 * AP_PS];
   const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -732,8 +732,10 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float p = __expf(sacc[t][j] - ms);
-        ps += p;
+        float p = __expf(sacc[t][j] - ms);
+        ps += p;                       // the softmax denominator is the undropped sum (att = softmax; att = attn_drop(att))
+        if (drop_p > 0.f)              // training: element (b, h, query, key) of the (B,H,P,P) attention-probability tensor
+          p *= sfmi_dropout_mul(drop_seed, (unsigned)(((b * gridDim.y + h) * P + qrow) * P + k0 + 16 * t + lr), drop_p, 1.0f / (1.0f - drop_p));
         Pw[(4 * lq + j) * AP_PS + 16 * t + lr] = p;
       }
       ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64); ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
@@ -774,11 +776,7 @@ __device__ __forceinline__ unsigned fkey_u(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__device__ __forceinline__ float sf_uniform(unsigned seed, unsigned idx) {  // == weights.hash_unit element idx
-  unsigned h = idx * 0x9E3779B1u + seed;
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  return (float)(h >> 8) * (1.0f / 16777216.0f);
-}
+__device__ __forceinline__ float sf_uniform(unsigned seed, unsigned idx) { return sfmi_hash_unit(seed, idx); }  // == weights.hash_unit
 
 struct SampleArgs {
   const float* part;  // (S,M,ldv) logits (S partial slabs summed in order; heads have no bias)
@@ -1198,15 +1196,15 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
 
 // causal self-attention over the conditioning prefix (positions 0..Lc[b]-2), also fills the KV caches
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
-                              int Lmax, const int* rowoff, void* stream) {
+                              int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, void* stream) {
   const int HD = H > 0 ? D / H : 0;
-  if (!qkv || !Kc || !Vc || !nval || !y || H <= 0 || D % H || (HD != 16 && HD != 32 && HD != 64) || P <= 0) return SFMI_EINVAL;
+  if (!qkv || !Kc || !Vc || !nval || !y || H <= 0 || D % H || (HD != 16 && HD != 32 && HD != 64) || P <= 0 || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   const dim3 grid(B, H, (P + 63) / 64);
   const float scale = 1.0f / sqrtf((float)HD);
   hipStream_t st = (hipStream_t)stream;
-  if (HD == 64) hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff);
-  else if (HD == 32) hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff);
-  else hipLaunchKernelGGL(attn_prefill_mfma_kernel<16>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff);
+  if (HD == 64) hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
+  else if (HD == 32) hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
+  else hipLaunchKernelGGL(attn_prefill_mfma_kernel<16>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -39,3 +39,15 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// counter-hash uniform in [0,1): element idx of weights.hash_unit(key) with seed = fnv1a32(key) (murmur3 finalizer).  Shared
+// by the sampler's inverse-CDF draws and the training dropout masks, so the CPU oracle reproduces both exactly.
+__device__ __forceinline__ float sfmi_hash_unit(unsigned seed, unsigned idx) {
+  unsigned h = idx * 0x9E3779B1u + seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+// nn.Dropout(p) multiplier of element idx: 0 with probability p, else 1/(1-p)  (mingpt.py:62-63,85,90,105,218)
+__device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, float p, float inv_keep) {
+  return sfmi_hash_unit(seed, idx) < p ? 0.0f : inv_keep;
+}

@@ -28,6 +28,7 @@ constexpr int SG_TILE = 128 * 36;     // floats per operand tile in either orien
 struct SgemmArgs {
   const float* A; const float* B; float* C; const float* bias; const float* resid;
   int M, N, K, lda, ldb, ldc, accumulate, act;
+  float drop_p; unsigned drop_seed;   // nn.Dropout on the product (after bias / activation, before the residual): mingpt.py:90,105
   float* ws;      // split-K (gridDim.y > 1): split s writes its partial product to ws + s*M*N (row stride N), no epilogue
 };
 
@@ -183,6 +184,10 @@ __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(SgemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
     }
+    if (a.drop_p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= sfmi_dropout_mul(a.drop_seed, (unsigned)(m * a.N + n + e), a.drop_p, 1.0f / (1.0f - a.drop_p));
+    }
     if (a.resid) v = v + *reinterpret_cast<const f32x4*>(a.resid + (long long)m * a.ldc + n);
     *reinterpret_cast<f32x4*>(cp) = v;
   };
@@ -221,6 +226,10 @@ __global__ void sgemm_splitk_reduce_kernel(SgemmArgs a, int S) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
   }
+  if (a.drop_p > 0.f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= sfmi_dropout_mul(a.drop_seed, (unsigned)(m * a.N + n + e), a.drop_p, 1.0f / (1.0f - a.drop_p));
+  }
   if (a.resid) v = v + *reinterpret_cast<const f32x4*>(a.resid + (long long)m * a.ldc + n);
   *reinterpret_cast<f32x4*>(cp) = v;
 }
@@ -245,7 +254,7 @@ int sfmi_sgemm_mfma_splits(int M, int N, int K) {
 }
 int sfmi_sgemm_mfma_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                         int ldc, int accumulate, const float* bias, int act, const float* resid, float* ws, long long ws_floats,
-                        void* stream) {
+                        float drop_p, unsigned drop_seed, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || N % 4 || lda % 4 || ldb % 4 || ldc % 4) return SFMI_EINVAL;
   if (!transA && K % 4) return SFMI_EINVAL;          // A K-contiguous: float4 along k
   if (transA && (M % 4 || M < 4)) return SFMI_EINVAL; // A row-contiguous: float4 along m
@@ -253,7 +262,8 @@ int sfmi_sgemm_mfma_f32(int transA, int transB, int M, int N, int K, const float
   if (N < 4) return SFMI_EINVAL;
   SgemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.resid = resid; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.accumulate = accumulate; a.act = act; a.ws = ws;
+  a.accumulate = accumulate; a.act = act; a.ws = ws; a.drop_p = drop_p; a.drop_seed = drop_seed;
+  if (drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   int S = ws ? sfmi_sgemm_mfma_splits(M, N, K) : 1;
   while (S > 1 && (long long)S * M * N > ws_floats) S /= 2;
   const long long blocks = (long long)((M + SG_BM - 1) / SG_BM) * ((N + SG_BN - 1) / SG_BN);

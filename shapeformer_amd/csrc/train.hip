@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void attn_stats_mfma_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               float* __restrict__ dqkv, int L, int D, float scale) {
+                                                               float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
+                                                               unsigned drop_seed) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * AB_S], Vs[64 * AB_S], Ts[4][16 * AB_S];
   const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4, q0 = qb * 64;
@@ -302,7 +303,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int qrow = q0 + 16 * wave + 4 * lq + j;
-        const float ds = (key > qrow || key >= L) ? 0.f : __expf(sa[j] - ls[j]) * (pa[j] - dl[j]);
+        // attention dropout (mingpt.py:85): O = (P o M) V  =>  dP = (dO V^T) o M ; delta = rowsum(dO o O) is unchanged
+        const float mk = drop_p > 0.f ? sfmi_dropout_mul(drop_seed, (unsigned)(((b * H + h) * L + qrow) * L + key), drop_p, 1.0f / (1.0f - drop_p)) : 1.0f;
+        const float ds = (key > qrow || key >= L) ? 0.f : __expf(sa[j] - ls[j]) * (pa[j] * mk - dl[j]);
         Tw[(4 * lq + j) * AB_S + 16 * t + lr] = ds;
       }
     }
@@ -329,7 +332,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dqkv, int L, int D, float scale) {
+                                                                float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
+                                                                unsigned drop_seed) {
   __shared__ __attribute__((aligned(16))) float Qs[64 * AB_S], Os[64 * AB_S], Pt[4][16 * AB_S], St[4][16 * AB_S];
   const int b = blockIdx.x, h = blockIdx.y, kb_ = blockIdx.z, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4, k0 = kb_ * 64;
@@ -366,8 +370,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
         const int key = k0 + 16 * wave + 4 * lq + j;
         const bool live = qcol < L && key <= qcol && key < L;
         const float pv = live ? __expf(sa[j] - lsq) : 0.f;
-        Pw[(4 * lq + j) * AB_S + 16 * t + lr] = pv;
-        Sw[(4 * lq + j) * AB_S + 16 * t + lr] = pv * (pa[j] - dlq);
+        const float mk = drop_p > 0.f ? sfmi_dropout_mul(drop_seed, (unsigned)(((b * H + h) * L + qc) * L + key), drop_p, 1.0f / (1.0f - drop_p)) : 1.0f;
+        Pw[(4 * lq + j) * AB_S + 16 * t + lr] = pv * mk;                 // dV += (P o M)^T dO
+        Sw[(4 * lq + j) * AB_S + 16 * t + lr] = pv * (pa[j] * mk - dlq);  // dS^T = P^T o (dP^T o M - delta)
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -448,6 +453,16 @@ __global__ void fixed_to_float_kernel(const long long* __restrict__ acc, float* 
   if (i >= n) return;
   const float v = (float)((double)acc[i] * (1.0 / 4294967296.0));
   out[i] = accumulate ? out[i] + v : v;
+}
+
+// nn.Dropout on a flat tensor, forward and backward alike: y[i] = x[i] * mask_i / (1 - p), mask from the counter hash
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p, float inv_keep, unsigned seed) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] *= sfmi_dropout_mul(seed, (unsigned)(4 * i + e), p, inv_keep);
+  reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, long long n) {
@@ -564,14 +579,14 @@ int sfmi_ce_fwd_bwd_f32(const float* logits, const int* target, float* loss_rows
 // causal self-attention backward (mingpt.py:73-91), head dim 64: dqkv (B*L,3D) from qkv, y, dy.  lse: 2*B*H*L floats of scratch
 // (row log-sum-exps, then row sums of dO*O).
 int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* lse, float* dqkv, int B, int L, int D, int H,
-                      void* stream) {
-  if (!qkv || !y || !dy || !lse || !dqkv || D / H != 64) return SFMI_EINVAL;
+                      float drop_p, unsigned drop_seed, void* stream) {
+  if (!qkv || !y || !dy || !lse || !dqkv || D / H != 64 || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(B, H, (L + 63) / 64);
   float* delta = lse + (size_t)B * H * L;
   hipLaunchKernelGGL(attn_stats_mfma_kernel, grid, dim3(256), 0, st, qkv, y, dy, lse, delta, L, D, 0.125f);
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f);
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f);
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
@@ -586,6 +601,14 @@ int sfmi_embed_scatter_f32(const float* dx, const int* idx, long long* acc, long
 int sfmi_fixed_to_float_f32(const long long* acc, float* out, long long n, int accumulate, void* stream) {
   if (!acc || !out || n <= 0) return SFMI_EINVAL;
   hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, out, n, accumulate);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// nn.Dropout(p) with the counter-hash mask of `seed` (embedding / residual dropouts and their backward: mingpt.py:90,105,218,292);
+// n a multiple of 4; y may alias x
+int sfmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned seed, void* stream) {
+  if (!x || !y || n <= 0 || n % 4 || p < 0.f || p >= 1.f) return SFMI_EINVAL;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4, p, 1.0f / (1.0f - p), seed);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

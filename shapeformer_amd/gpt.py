@@ -52,7 +52,7 @@ class CondTupleGPT:
 
     def __init__(self, state_dict=None, n_embd=1024, n_head=16, n_layers=(20, 4), block_size=812,
                  vocab_sizes=(4097, 4097), extra_vocab_sizes=(4097,), end_tokens=(4096, 4096), device="cuda:0",
-                 tuple_n=2, **_ignored):
+                 tuple_n=2, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0, **_ignored):
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise L.SfmiError("CondTupleGPT needs a HIP device (no CPU fallback)")
@@ -60,6 +60,7 @@ class CondTupleGPT:
         assert tuple_n == 2 and len(n_layers) == 2 and vocab_sizes[0] == vocab_sizes[1]
         self.D, self.H, self.n_layers, self.Lmax = n_embd, n_head, tuple(n_layers), block_size
         self.V, self.end = vocab_sizes[0], tuple(end_tokens)
+        self.pdrop = (float(embd_pdrop), float(resid_pdrop), float(attn_pdrop))   # training only (train.GPTTrainer); inference = eval
         self.Vpad = (self.V + 31) // 32 * 32
         sd = state_dict if state_dict is not None else self._hash_state_dict()
         self.load_state_dict(sd)
@@ -236,7 +237,7 @@ class CondTupleGPT:
             return
         if not og and N % 4 == 0 and K % 4 == 0:
             L.check(L.lib().sfmi_sgemm_mfma_f32(0, 1, M, N, K, L.ptr(x), K, L.ptr(w), K, L.ptr(y), N, 0, L.ptr(bias), act, L.ptr(resid),
-                                                None, 0, L.stream_ptr()), "sfmi_sgemm_mfma_f32")
+                                                None, 0, 0.0, 0, L.stream_ptr()), "sfmi_sgemm_mfma_f32")
             return
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, og, ogs,
                                       L.stream_ptr()), "sfmi_gemm_f32")
@@ -279,7 +280,7 @@ class CondTupleGPT:
         for li, ly in enumerate(self.layers):
             self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
             L.check(L.lib().sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]), L.ptr(st["nval"]),
-                                                      L.ptr(y), B, P, D, self.H, self.Lmax + 1, L.ptr(rowoff), L.stream_ptr()), "attn_prefill")
+                                                      L.ptr(y), B, P, D, self.H, self.Lmax + 1, L.ptr(rowoff), 0.0, 0, L.stream_ptr()), "attn_prefill")
             self._gemm(y, ly.wproj, ly.bproj, resid, resid, M, D, D)
             self._rowprep(resid, None, None, 0, M, None, xn, ly.ln2)
             self._gemm(xn, ly.wfc1, ly.bfc1, None, h, M, 4 * D, D, act=2)

@@ -168,7 +168,8 @@ class CondTupleGPTModel:
         from .gpt import CondTupleGPT
         return CondTupleGPT(state_dict, n_embd=n_embd, n_head=n_head, n_layers=tuple(n_layers), block_size=block_size,
                             vocab_sizes=tuple(vocab_sizes), extra_vocab_sizes=tuple(extra_vocab_sizes), tuple_n=tuple_n,
-                            end_tokens=tuple(end_tokens), device=device or _device())
+                            end_tokens=tuple(end_tokens), device=device or _device(), embd_pdrop=embd_pdrop,
+                            resid_pdrop=resid_pdrop, attn_pdrop=attn_pdrop)
 
 
 class ARNRepresenter:

@@ -7,8 +7,11 @@ Every arithmetic step is a libsfmi (HIP) call: GEMM-shaped gradients go through 
 operands, the rest through csrc/train.hip.  Gradients live in ONE flat buffer so data-parallel training is a single
 RCCL all-reduce (`torch.distributed`, backend "nccl" on ROCm) per step; the frozen VQDIF is replicated and excluded.
 
-The reference's dropout (p = 0.01, mingpt attn/resid/embd) is not applied: training here is the deterministic
-eval-mode graph (documented deviation; gradients are checked against the oracle's autograd in eval mode).
+Dropout (mingpt.py:62-63,85,90,105,218,292: embd_pdrop on both stage inputs, attn_pdrop on the attention probabilities,
+resid_pdrop after proj and after the MLP; 0.01 in shapenet_scale.yaml) is applied in `training_step` with counter-hash masks
+(csrc/sfmi_common.h: element i of site s at step t is dropped iff hash_unit("dropout-<seed>-<t>-<s>")[i] < p), fused into the
+producing kernels (attention forward / backward, GEMM epilogue); the CPU oracle builds the same masks, so train-mode
+gradients are checked against its autograd exactly like the eval-mode ones.  torch's Philox stream cannot be matched.
 """
 from __future__ import annotations
 
@@ -22,8 +25,11 @@ def _ru(x, m):
 
 
 class GPTTrainer:
-    def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None):
+    def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0):
         self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
+        # (embd_pdrop, resid_pdrop, attn_pdrop): the model's (CondTupleGPT ctor kwargs / YAML) unless given
+        self.pdrop = tuple(float(v) for v in (pdrop if pdrop is not None else getattr(gpt, "pdrop", (0.0, 0.0, 0.0))))
+        self.dropout_seed = dropout_seed
         self.lr, self.betas, self.wd, self.eps, self.dist = lr, betas, weight_decay, eps, dist
         self.step_count = 0
         g = gpt
@@ -77,7 +83,7 @@ class GPTTrainer:
             self._has_blas = os.environ.get("SFMI_ROCBLAS") == "1" and bool(L.lib().sfmi_blas_available())
         return self._has_blas
 
-    def _sgemm(self, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, accumulate=False, bias=None, act=0, resid=None):
+    def _sgemm(self, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, accumulate=False, bias=None, act=0, resid=None, drop=(0.0, 0)):
         """csrc/sgemm.hip with split-K scratch for outputs of few tiles (the weight gradients)."""
         lib = L.lib()
         need = lib.sfmi_sgemm_mfma_splits(M, N, K) * M * N
@@ -87,15 +93,16 @@ class GPTTrainer:
                 self._sg_ws = torch.empty(need, device=self.dev)
             ws = self._sg_ws
         L.check(lib.sfmi_sgemm_mfma_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(C), ldc, int(accumulate), L.ptr(bias),
-                                        act, L.ptr(resid), L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr()), "sgemm_mfma")
+                                        act, L.ptr(resid), L.ptr(ws), ws.numel() if ws is not None else 0, float(drop[0]), int(drop[1]), L.stream_ptr()), "sgemm_mfma")
 
-    def _gemm(self, x, w, bias, resid, y, M, N, K, act=0):
-        if self._blas() and M >= 256 and N % 4 == 0 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
+    def _gemm(self, x, w, bias, resid, y, M, N, K, act=0, drop=(0.0, 0)):
+        if drop[0] == 0.0 and self._blas() and M >= 256 and N % 4 == 0 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
             L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
             return
         if N % 4 == 0 and K % 4 == 0:
-            self._sgemm(0, 1, M, N, K, x, K, w, K, y, N, bias=bias, act=act, resid=resid)
+            self._sgemm(0, 1, M, N, K, x, K, w, K, y, N, bias=bias, act=act, resid=resid, drop=drop)
             return
+        assert drop[0] == 0.0
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, 0, 0, L.stream_ptr()), "gemm")
 
     def _dx(self, dY, wname, w, M, N, K):
@@ -157,8 +164,9 @@ class GPTTrainer:
         if self._sync:
             self.buckets.ready(name)
 
-    def loss_and_grad(self, c_indices, z_indices, accumulate=False, sync=False):
+    def loss_and_grad(self, c_indices, z_indices, accumulate=False, sync=False, dropout_key=None):
         """-> loss (0-dim tensor).  Gradients of every parameter are left in self.grad[name] (flat buffer).
+        dropout_key=None: eval-mode graph (no dropout); a string: train mode, the mask of site s is hash "dropout-<key>-<s>".
         sync=True (last micro-step of a data-parallel step): each block's gradient bucket is all-reduced as soon as it
         is final, under the backward kernels of the remaining blocks (dist.GradBuckets); finish with all_reduce_grads()."""
         g, D, dev, lib = self.g, self.D, self.dev, L.lib()
@@ -178,12 +186,28 @@ class GPTTrainer:
                   extra_out=torch.zeros(M, device=dev, dtype=torch.int32))
         st["seq"][:, :Lq + 1] = cz
         kv = self._f(2, B, g.Lmax + 1, D)   # prefill attention also fills a KV cache; scratch here
+        from .weights import _fnv1a32
+        p_embd, p_resid, p_attn = self.pdrop if dropout_key is not None else (0.0, 0.0, 0.0)
+
+        def site(p, name):          # (p, seed) of one dropout site
+            return (p, _fnv1a32(f"dropout-{dropout_key}-{name}")) if p > 0.0 else (0.0, 0)
+
+        def drop_(x, ps, out=None):  # elementwise nn.Dropout (forward == backward): out = x * mask / (1 - p)
+            if ps[0] == 0.0:
+                return x
+            out = out if out is not None else self._f(*x.shape)
+            L.check(lib.sfmi_dropout_f32(L.ptr(x), L.ptr(out), x.numel(), ps[0], ps[1], L.stream_ptr()), "dropout")
+            return out
         # ---- forward, keeping what the backward needs --------------------------------------------------------
         saved = []
         resid = self._f(M, D)
         xn = self._f(M, D)
-        g._embed(st, B, Lq, resid, xn, g.layers[0].ln1)
-        x0 = resid
+        if p_embd > 0.0:     # x = drops[0](embeddings) (mingpt.py:292)
+            g._embed(st, B, Lq, resid, None, None)
+            drop_(resid, site(p_embd, "emb0"), out=resid)
+            g._rowprep(resid, None, None, 0, M, None, xn, g.layers[0].ln1)
+        else:
+            g._embed(st, B, Lq, resid, xn, g.layers[0].ln1)
         head_in = {}
         for li, ly in enumerate(g.layers):
             s = dict(x_in=resid, xn1=xn)
@@ -191,9 +215,9 @@ class GPTTrainer:
             self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
             y = self._f(M, D)
             L.check(lib.sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
-                                                  g.H, g.Lmax + 1, None, L.stream_ptr()), "attn")
+                                                  g.H, g.Lmax + 1, None, *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn")
             r1 = self._f(M, D)
-            self._gemm(y, ly.wproj, ly.bproj, resid, r1, M, D, D)
+            self._gemm(y, ly.wproj, ly.bproj, resid, r1, M, D, D, drop=site(p_resid, f"L{li}.proj"))
             xn2 = self._f(M, D)
             g._rowprep(r1, None, None, 0, M, None, xn2, ly.ln2)
             hpre = self._f(M, 4 * D)
@@ -201,7 +225,7 @@ class GPTTrainer:
             h = self._f(M, 4 * D)
             L.check(lib.sfmi_gelu_f32(L.ptr(hpre), L.ptr(h), M * 4 * D, L.stream_ptr()), "gelu")
             r2 = self._f(M, D)
-            self._gemm(h, ly.wfc2, ly.bfc2, r1, r2, M, D, 4 * D)
+            self._gemm(h, ly.wfc2, ly.bfc2, r1, r2, M, D, 4 * D, drop=site(p_resid, f"L{li}.mlp"))
             s.update(qkv=qkv, y=y, r1=r1, xn2=xn2, hpre=hpre, h=h)
             saved.append(s)
             resid = r2
@@ -213,7 +237,12 @@ class GPTTrainer:
                 xn = self._f(M, D)
                 if nxt.stage != ly.stage:
                     r3 = self._f(M, D)
-                    g._rowprep(resid, None, None, 0, M, r3, xn, nxt.ln1, Eadd=g.E[0], P=Lq, st=st)
+                    if p_embd > 0.0:     # x = drops[1](h20 + tok_embs[0](target pos)) (mingpt.py:292,295)
+                        g._rowprep(resid, None, None, 0, M, r3, None, None, Eadd=g.E[0], P=Lq, st=st)
+                        drop_(r3, site(p_embd, "emb1"), out=r3)
+                        g._rowprep(r3, None, None, 0, M, None, xn, nxt.ln1)
+                    else:
+                        g._rowprep(resid, None, None, 0, M, r3, xn, nxt.ln1, Eadd=g.E[0], P=Lq, st=st)
                     resid = r3
                 else:
                     g._rowprep(resid, None, None, 0, M, None, xn, nxt.ln1)
@@ -249,14 +278,16 @@ class GPTTrainer:
             ly, s, p = g.layers[li], saved[li], f"L{li}."
             if li + 1 < len(g.layers) and g.layers[li + 1].stage != ly.stage:
                 # stage boundary (mingpt.py:294): x1 = h20 + E0[target pos]  ->  dE0 += scatter(dr) ; dh20 = dr + head-0 path
+                dr = drop_(dr, site(p_embd, "emb1"))          # through drops[1]
                 self._scatter(dr, tgt[..., 0].contiguous().view(-1), "E0", M, accumulate=True)
                 dsum = self._f(M, D)
                 L.check(lib.sfmi_add_f32(L.ptr(dr), L.ptr(d_head[0]), L.ptr(dsum), M * D, L.stream_ptr()), "add")
                 dr = dsum
             # fc2
-            self._colsum(dr, M, D, p + "bfc2")
-            self._dW(dr, s["h"], M, D, 4 * D, p + "wfc2")
-            dh = self._dx(dr, p + "wfc2", ly.wfc2, M, D, 4 * D)
+            dm = drop_(dr, site(p_resid, f"L{li}.mlp"))     # gradient of the MLP output before its dropout (residual path: dr)
+            self._colsum(dm, M, D, p + "bfc2")
+            self._dW(dm, s["h"], M, D, 4 * D, p + "wfc2")
+            dh = self._dx(dm, p + "wfc2", ly.wfc2, M, D, 4 * D)
             dhpre = self._f(M, 4 * D)
             L.check(lib.sfmi_gelu_bwd_f32(L.ptr(dh), L.ptr(s["hpre"]), L.ptr(dhpre), M * 4 * D, L.stream_ptr()), "gelu_bwd")
             # fc1
@@ -265,13 +296,14 @@ class GPTTrainer:
             dxn2 = self._dx(dhpre, p + "wfc1", ly.wfc1, M, 4 * D, D)
             dr1 = self._ln_bwd(dxn2, s["r1"], ly.ln2[0], dr, M, p + "ln2.w", p + "ln2.b")
             # proj
-            self._colsum(dr1, M, D, p + "bproj")
-            self._dW(dr1, s["y"], M, D, D, p + "wproj")
-            dy = self._dx(dr1, p + "wproj", ly.wproj, M, D, D)
+            dp = drop_(dr1, site(p_resid, f"L{li}.proj"))
+            self._colsum(dp, M, D, p + "bproj")
+            self._dW(dp, s["y"], M, D, D, p + "wproj")
+            dy = self._dx(dp, p + "wproj", ly.wproj, M, D, D)
             # attention
             dqkv = self._f(M, 3 * D)
             L.check(lib.sfmi_attn_bwd_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(lse), L.ptr(dqkv), B, Lq, D, g.H,
-                                          L.stream_ptr()), "attn_bwd")
+                                          *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn_bwd")
             # qkv
             self._colsum(dqkv, M, 3 * D, p + "bqkv")
             self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv")
@@ -281,6 +313,7 @@ class GPTTrainer:
             self._ready(f"L{li}")     # this block's 50 MB of gradients are final: all-reduce under the next blocks' backward
         # ---- embeddings (mingpt.py:256-286): E0[pos] + E1[val] + Ex[extra] + positional --------------------------------
         idx = cz[:, :Lq, :]
+        dr = drop_(dr, site(p_embd, "emb0"))                  # through drops[0]
         self._scatter(dr, idx[..., 0].contiguous().view(-1), "E0", M)
         self._scatter(dr, idx[..., 1].contiguous().view(-1), "E1", M, accumulate=accumulate)
         self._scatter(dr, st["extra_out"], "Ex", M, accumulate=accumulate)   # AR_N index as used by the forward
@@ -337,7 +370,10 @@ class GPTTrainer:
 
     @torch.no_grad()
     def training_step(self, c_indices, z_indices):
-        loss = self.loss_and_grad(c_indices, z_indices, sync=True)
+        """One optimizer step in TRAIN mode (dropout on when the model's pdrop > 0; every rank / step draws its own masks)."""
+        rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
+        key = f"{self.dropout_seed}-{rank}-{self.step_count}" if any(self.pdrop) else None
+        loss = self.loss_and_grad(c_indices, z_indices, sync=True, dropout_key=key)
         self.all_reduce_grads()
         self.optimizer_step()
         return loss

@@ -18,7 +18,7 @@ def _run(dev, tA, tB, M, N, K, accumulate=False, bias=False, act=0, resid=False,
     db, dr = torch.from_numpy(bv).to(dev), torch.from_numpy(rv).to(dev)
     ws = torch.empty(8 * M * N if use_ws else 4, device=dev)
     L.check(L.lib().sfmi_sgemm_mfma_f32(int(tA), int(tB), M, N, K, L.ptr(dA), A.shape[1], L.ptr(dB), B.shape[1], L.ptr(dC), N, int(accumulate),
-                                        L.ptr(db) if bias else None, act, L.ptr(dr) if resid else None, L.ptr(ws) if use_ws else None, ws.numel(), L.stream_ptr()), "sgemm_mfma")
+                                        L.ptr(db) if bias else None, act, L.ptr(dr) if resid else None, L.ptr(ws) if use_ws else None, ws.numel(), 0.0, 0, L.stream_ptr()), "sgemm_mfma")
     opA = A.T.astype(np.float64) if tA else A.astype(np.float64)
     opB = B.T.astype(np.float64) if tB else B.astype(np.float64)
     ref = opA @ opB

@@ -23,11 +23,11 @@ def _setup(dev):
     return sd, cfg, g, c, z
 
 
-def _oracle_grads(sd, cfg, c, z):
+def _oracle_grads(sd, cfg, c, z, dropout=None):
     from oracle import gpt_oracle as GO, tokens_oracle as TO, vqdif_oracle as VO
     sdt = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
     extra = torch.from_numpy(TO.extra_indices_AR_N(c.numpy(), z.numpy(), 4096))
-    loss = GO.training_loss(sdt, cfg, c, z, extra)
+    loss = GO.training_loss(sdt, cfg, c, z, extra, dropout=dropout)
     loss.backward()
     return loss.item(), {k: v.grad for k, v in sdt.items()}, sdt
 
@@ -74,6 +74,33 @@ def test_loss_and_every_gradient_vs_oracle_autograd(dev):
     g1 = tr.flat_grad.clone()
     tr.loss_and_grad(c, z)
     assert torch.equal(g1, tr.flat_grad)
+
+
+def test_train_mode_dropout_loss_and_every_gradient_vs_oracle_autograd(dev):
+    """The three dropouts of the reference (mingpt.py:62-63,85,90,105,218,292: embeddings of both stages, attention
+    probabilities, proj / MLP outputs) in TRAIN mode: fused counter-hash masks on the HIP side, the same masks as explicit
+    multipliers in the oracle's autograd.  p = 0.1 (the YAML's 0.01 would barely move the numbers)."""
+    from shapeformer_amd.train import GPTTrainer
+    sd, cfg, g, c, z = _setup(dev)
+    pd = (0.1, 0.15, 0.2)
+    tr = GPTTrainer(g, pdrop=pd)
+    l_eval = tr.loss_and_grad(c, z).item()
+    loss = tr.loss_and_grad(c, z, dropout_key="k7").item()
+    want_loss, og, _ = _oracle_grads(sd, cfg, c, z, dropout=dict(key="k7", p=pd))
+    assert abs(loss - want_loss) < 1e-5 * max(1.0, abs(want_loss)) and abs(loss - l_eval) > 1e-3      # the masks are live
+    worst = 0.0
+    for name, keys in _map(tr, cfg).items():
+        want = torch.cat([og[k].reshape(-1, og[k].shape[-1]) if og[k].dim() > 1 else og[k] for k in keys], 0)
+        got = tr.grad[name].cpu().reshape(want.shape)
+        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)
+    print(f"train mode (dropout {pd}): worst relative gradient error {worst:.2e}")
+    # another key -> other masks; training_step draws a fresh key per step and still trains
+    assert abs(tr.loss_and_grad(c, z, dropout_key="k8").item() - loss) > 1e-4
+    tr2 = GPTTrainer(g, lr=1e-3, pdrop=(0.01, 0.01, 0.01))
+    losses = [tr2.training_step(c, z).item() for _ in range(6)]
+    assert losses[-1] < losses[0] - 0.05, losses
 
 
 def test_adamw_step_matches_torch_optim_and_training_reduces_loss(dev):

@@ -10,7 +10,7 @@ print("forward y = x W^T (+bias):")
 for M, N, K in ((30144, 3072, 1024), (30144, 1024, 1024), (30144, 4096, 1024), (30144, 1024, 4096), (10048, 4096, 1024), (3992, 4096, 1024), (3992, 1024, 4096), (3992, 4128, 1024)):
     x, W, b = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.randn(N, device=dev)
     y = torch.empty(M, N, device=dev)
-    f0 = lambda: L.check(lib.sfmi_sgemm_mfma_f32(0, 1, M, N, K, L.ptr(x), K, L.ptr(W), K, L.ptr(y), N, 0, L.ptr(b), 0, None, None, 0, L.stream_ptr()), "sgemm_mfma")
+    f0 = lambda: L.check(lib.sfmi_sgemm_mfma_f32(0, 1, M, N, K, L.ptr(x), K, L.ptr(W), K, L.ptr(y), N, 0, L.ptr(b), 0, None, None, 0, 0.0, 0, L.stream_ptr()), "sgemm_mfma")
     f1 = lambda: L.check(lib.sfmi_gemm_f32(L.ptr(x), L.ptr(W), L.ptr(b), None, L.ptr(y), M, N, K, 0, 0, 0, L.stream_ptr()), "gemm")
     f3 = lambda: L.check(lib.sfmi_gemm_blas_f32(L.ptr(x), L.ptr(W), L.ptr(b), None, L.ptr(y), M, N, K, 0, L.stream_ptr()), "gemm_blas")
     fs = [f0, f1, f3] if N % 32 == 0 else [f0, f0, f3]
@@ -23,7 +23,7 @@ print("dX = dY W  (A (M,N) K-contiguous, B = W (N,K) stored (k,n)):")
 for M, N, K in ((3992, 3072, 1024), (3992, 4096, 1024), (3992, 1024, 4096), (3992, 1024, 1024)):
     dY, W = torch.randn(M, N, device=dev), torch.randn(N, K, device=dev)
     dx = torch.empty(M, K, device=dev)
-    f0 = lambda: L.check(lib.sfmi_sgemm_mfma_f32(0, 0, M, K, N, L.ptr(dY), N, L.ptr(W), K, L.ptr(dx), K, 0, None, 0, None, None, 0, L.stream_ptr()), "dx")
+    f0 = lambda: L.check(lib.sfmi_sgemm_mfma_f32(0, 0, M, K, N, L.ptr(dY), N, L.ptr(W), K, L.ptr(dx), K, 0, None, 0, None, None, 0, 0.0, 0, L.stream_ptr()), "dx")
     f3 = lambda: L.check(lib.sfmi_sgemm_f32(0, 0, M, K, N, 1.0, L.ptr(dY), N, L.ptr(W), K, 0.0, L.ptr(dx), K, L.stream_ptr()), "dx blas")
     for f in (f0, f3): f()
     torch.cuda.synchronize()
@@ -35,7 +35,7 @@ for M, N, K in ((3992, 1024, 1024), (3992, 3072, 1024), (3992, 4096, 1024), (399
     dY, X = torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
     out = torch.empty(N, K, device=dev)
     ws = torch.empty(lib.sfmi_sgemm_mfma_splits(N, K, M) * N * K, device=dev)
-    f0 = lambda: L.check(lib.sfmi_sgemm_mfma_f32(1, 0, N, K, M, L.ptr(dY), N, L.ptr(X), K, L.ptr(out), K, 0, None, 0, None, L.ptr(ws), ws.numel(), L.stream_ptr()), "dw")
+    f0 = lambda: L.check(lib.sfmi_sgemm_mfma_f32(1, 0, N, K, M, L.ptr(dY), N, L.ptr(X), K, L.ptr(out), K, 0, None, 0, None, L.ptr(ws), ws.numel(), 0.0, 0, L.stream_ptr()), "dw")
     f3 = lambda: L.check(lib.sfmi_sgemm_f32(1, 0, N, K, M, 1.0, L.ptr(dY), N, L.ptr(X), K, 0.0, L.ptr(out), K, L.stream_ptr()), "dw blas")
     for f in (f0, f3): f()
     torch.cuda.synchronize()
