@@ -213,9 +213,11 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
 
 
 def pmc_traffic(kernel, B):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic_B64.json: FETCH_SIZE
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic_B64.json: FETCH_SIZE
     doubled per the gfx950 correction + WRITE_SIZE); only valid for the configuration it was collected on."""
-    f = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_B{B}.json")     # collected at 64 and 96 rows (tools/pmc_traffic.py)
+    f = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_B{B}.json")     # collected at 64 rows (tools/pmc_run.sh)
+    if not os.path.exists(f):
+        f = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_B{B}.json")
     if not os.path.exists(f):
         return None
     key = "dgemm_kernel" if kernel.startswith("dgemm_kernel") else "attn_decode_kernel"

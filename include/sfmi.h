@@ -37,6 +37,9 @@ int sfmi_enc_pack_weights(const float* fc_pos_w, const float* fc_pos_b, const fl
                           const float* fc_c_b, float* out);
 size_t sfmi_enc_workspace_bytes(int B, int T);
 /* cloud (B,T,3) in [-1,1] -> per-cell mean grid (B,64,64,64,32) + latent occupancy mask (B,R,R,R) u8 [z][y][x] */
+/* same, with per-point taps for stage-wise parity tests: stage1 (B,T,32) = blocks[1] output, stage4c (B,T,64) = [blocks[4] | fc_c] */
+int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace,
+                               int B, int T, int R, float* tap_stage1, float* tap_stage4c, void* stream);
 int sfmi_encode_points_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out,
                            void* workspace, int B, int T, int R, void* stream);
 

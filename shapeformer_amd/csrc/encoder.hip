@@ -172,6 +172,14 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
       f32x16 c;
       bias_init(lds + ENC_BLK_FLOATS + 1024, hi, c);
       layer32<false>(reinterpret_cast<const f32x4*>(lds + ENC_BLK_FLOATS) + lane, o, c);
+      if (valid && net_out) {   // debug tap (sfmi_encode_points_tap_f32): row i = [block-4 output (32) | c = fc_c(net) (32)]
+        f32x4* tp = reinterpret_cast<f32x4*>(net_out + i * 64 + 4 * hi);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          tp[2 * g] = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+          tp[8 + 2 * g] = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+        }
+      }
       if (valid) {
         long long* sp = csum + seg * 32 + 4 * hi;
 #pragma unroll
@@ -249,8 +257,16 @@ size_t sfmi_enc_workspace_bytes(int B, int T) {
 
 // replaces LocalPoolPointnet.forward up to scatter_mean (enc.py:115-140 minus the Downsampler):
 // cloud (B,T,3) -> dense channels-last mean grid (B,64,64,64,32) + latent occupancy mask (B,R,R,R) u8.
+int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace,
+                               int B, int T, int R, float* tap_stage1, float* tap_stage4c, void* stream_);
 int sfmi_encode_points_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask,
                            int* cell_out /*optional (B,T)*/, void* workspace, int B, int T, int R, void* stream_) {
+  return sfmi_encode_points_tap_f32(cloud, wpack, grid_cl, mask, cell_out, workspace, B, T, R, nullptr, nullptr, stream_);
+}
+// the same pipeline with per-point taps for stage-wise parity tests: tap_stage1 (B,T,32) = output of blocks[1] (after the first
+// local max pool), tap_stage4c (B,T,64) = [output of blocks[4] | c = fc_c(net)] (enc.py:124-133); either may be NULL
+int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace,
+                               int B, int T, int R, float* tap_stage1, float* tap_stage4c, void* stream_) {
   if (!cloud || !wpack || !grid_cl || !mask || !workspace || B <= 0 || T <= 0 || R <= 0) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
   const size_t bt = (size_t)B * T;
@@ -277,13 +293,14 @@ int sfmi_encode_points_f32(const float* cloud, const float* wpack, float* grid_c
   hipMemsetAsync(sm[1], 0x80, bt * 128, st);
   hipLaunchKernelGGL(enc_block_kernel<1>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[0], sm[0], net[1],
                      sm[1], nullptr, nullptr, wpack, B, T);
+  if (tap_stage1) hipMemcpyAsync(tap_stage1, net[1], bt * 128, hipMemcpyDeviceToDevice, st);
   hipMemsetAsync(sm[0], 0x80, bt * 128, st);
   hipLaunchKernelGGL(enc_block_kernel<2>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[1], sm[1], net[0],
                      sm[0], nullptr, nullptr, wpack, B, T);
   hipMemsetAsync(sm[1], 0x80, bt * 128, st);
   hipLaunchKernelGGL(enc_block_kernel<3>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[0], sm[0], net[1],
                      sm[1], nullptr, nullptr, wpack, B, T);
-  hipLaunchKernelGGL(enc_block_kernel<4>, dim3(grid), dim3(256), lds4, st, cloud, cell, rep, net[1], sm[1], nullptr,
+  hipLaunchKernelGGL(enc_block_kernel<4>, dim3(grid), dim3(256), lds4, st, cloud, cell, rep, net[1], sm[1], tap_stage4c,
                      nullptr, csum, ccount, wpack, B, T);
   long long nthr = (long long)bt * 32;
   hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, cell, rep, csum,

@@ -52,7 +52,8 @@ def test_losses_and_every_gradient_match_oracle_and_reference_checksums(dev):
     # the composition (lost skip connection, wrong tap, missing term) shows up here as O(1).
     tsd = VO.to_torch_sd(sd)
     _, og = TO.loss_and_grads(tsd, *(torch.from_numpy(G[k]) for k in ("Xbd", "Xtg", "Ytg")), float(G["beta"]))
-    tol = {"decoder.blocks": 1e-4, "decoder.fc": 1e-4, "decoder.upsampler": 2e-2, "decoder.unet3d": 1.5e-1, "encoder.": 8e-2}
+    # gates = DESIGN.md §7 (f4): measured 3.4e-6 / 6.6e-6 / 3.1e-3 / 5.0e-2 / 1.1e-2 on MI355X
+    tol = {"decoder.blocks": 2e-5, "decoder.fc": 2e-5, "decoder.upsampler": 6e-3, "decoder.unet3d": 8e-2, "encoder.": 2e-2}
     worst = {}
     for k, ref in og.items():
         got = _to_ref_layout(tr, k, tr.g[k]).astype(np.float64)

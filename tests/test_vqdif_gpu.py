@@ -141,3 +141,30 @@ def test_conv_and_groupnorm_units(vq, dev):
     sc, sh = vq._gn(xd, gam.to(dev), bet.to(dev), "t")
     y = vq._affine(xd, sc, sh, "t_out")
     torch.testing.assert_close(y.cpu().permute(0, 4, 1, 2, 3), ref, atol=1e-5, rtol=1e-5)
+
+
+def test_per_point_encoder_stages_vs_reference_fixture(vq):
+    """Stage-wise pin of the per-point encoder (enc.py:115-133) through the debug taps of sfmi_encode_points_tap_f32: the output
+    of blocks[1] (after the first local max pool), of blocks[4] and c = fc_c(net), at the points the fixture sampled - until
+    now these were only pinned through the down-sampled latent."""
+    from shapeformer_amd import _lib as L
+    z = np.load(os.path.join(G, "vqdif16_small.npz"))
+    cloud = torch.from_numpy(z["cloud"]).to(vq.dev).contiguous()
+    B, T, _ = cloud.shape
+    lib = L.lib()
+    ws = torch.empty(lib.sfmi_enc_workspace_bytes(B, T), device=vq.dev, dtype=torch.uint8)
+    grid = torch.empty(B, 64, 64, 64, 32, device=vq.dev)
+    mask = torch.empty(B, 16, 16, 16, device=vq.dev, dtype=torch.uint8)
+    cell = torch.empty(B, T, device=vq.dev, dtype=torch.int32)
+    s1, s4c = torch.empty(B, T, 32, device=vq.dev), torch.empty(B, T, 64, device=vq.dev)
+    L.check(lib.sfmi_encode_points_tap_f32(L.ptr(cloud), L.ptr(vq.enc_w), L.ptr(grid), L.ptr(mask), L.ptr(cell), L.ptr(ws), B, T, 16,
+                                           L.ptr(s1), L.ptr(s4c), L.stream_ptr()), "encode_points_tap")
+    assert np.array_equal(cell.cpu().numpy(), z["cell"])
+    for name, got in (("enc_stage1_sel", s1), ("enc_stage4_sel", s4c[..., :32]), ("enc_c_sel", s4c[..., 32:])):
+        ref = z[name]
+        err = np.abs(got[:, ::64].cpu().numpy() - ref).max()
+        assert err < 2e-5 * np.abs(ref).max() + 1e-5, (name, err)
+    # the taps do not disturb the product outputs
+    grid2, mask2 = torch.empty_like(grid), torch.empty_like(mask)
+    L.check(lib.sfmi_encode_points_f32(L.ptr(cloud), L.ptr(vq.enc_w), L.ptr(grid2), L.ptr(mask2), None, L.ptr(ws), B, T, 16, L.stream_ptr()), "encode")
+    assert torch.equal(grid, grid2) and torch.equal(mask, mask2)

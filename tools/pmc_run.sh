@@ -1,21 +1,24 @@
 #!/bin/bash
-# rocprofv3 --pmc passes (counters only with --kernel-trace, one group per pass) -> gpurun_out/pmc_r01b.txt
+# rocprofv3 --pmc passes (counters only with --kernel-trace, one counter group per pass) -> gpurun_out/r2/pmc_r02.txt
 export TMPDIR=/tmp
 R=$PWD
-mkdir -p gpurun_out
-: > gpurun_out/pmc_r01b.txt
-pass() {  # name, counters, command...
-  name=$1; ctr=$2; shift 2
+OUT=$R/gpurun_out/r2/pmc_r02.txt
+mkdir -p $(dirname $OUT); : > $OUT
+pass() {  # name, counters, kernel patterns (comma separated), command...
+  name=$1; ctr=$2; pats=$3; shift 3
   rm -rf /tmp/pmc_$name
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$name -- "$@" > /tmp/pmc_$name.log 2>&1)
   DB=$(find /tmp/pmc_$name -name "*.db" | head -1)
-  echo "### pass $name: --pmc $ctr -- $*" >> gpurun_out/pmc_r01b.txt
-  python tools/pmc_summary.py $DB "%sdf_query%" >> gpurun_out/pmc_r01b.txt
-  python tools/pmc_summary.py $DB "%attn_%" >> gpurun_out/pmc_r01b.txt
-  python tools/pmc_summary.py $DB "%dgemm%" >> gpurun_out/pmc_r01b.txt
+  echo "### pass $name: --pmc $ctr -- $*" >> $OUT
+  IFS=',' read -ra PA <<< "$pats"
+  for p in "${PA[@]}"; do python $R/tools/pmc_summary.py $DB "$p" >> $OUT; done
 }
-pass sdf_fetch "FETCH_SIZE" python $R/tools/pmc_sdf.py
-pass sdf_write "WRITE_SIZE" python $R/tools/pmc_sdf.py
-pass sdf_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python $R/tools/pmc_sdf.py
-pass dec_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" env B=64 LC=300 STEPS=3 python $R/tools/pmc_decode.py
-tail -n 80 gpurun_out/pmc_r01b.txt
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+pass sdf_fetch "FETCH_SIZE" "%sdf_query%" python $R/tools/pmc_sdf.py
+pass sdf_write "WRITE_SIZE" "%sdf_query%" python $R/tools/pmc_sdf.py
+pass sdf_sq "$SQ" "%sdf_query%" python $R/tools/pmc_sdf.py
+pass train_sq "$SQ" "%attn_prefill_mfma%,%attn_bwd%,%attn_stats%,%sgemm_mfma%" python $R/tools/pmc_train.py
+pass dec_sq "$SQ" "%attn_decode%,%dgemm%,%attn_prefill_mfma%,%sgemm_mfma%" env B=64 LC=300 STEPS=3 python $R/tools/pmc_decode.py
+pass dec_fetch "FETCH_SIZE" "%attn_decode%,%dgemm%" env B=64 LC=400 STEPS=4 python $R/tools/pmc_decode.py
+pass dec_write "WRITE_SIZE" "%attn_decode%,%dgemm%" env B=64 LC=400 STEPS=4 python $R/tools/pmc_decode.py
+tail -n 120 $OUT
