@@ -3,11 +3,16 @@
 //
 // MI355X design (not the reference's dense-grid dataflow):
 //   * the 64^3 cell id is computed ONCE (it is identical for the 4 pooling passes and the mean);
-//   * a cell's "segment" is named by its lowest point index (atomicMin on a 1 MB/shape int map), so the
-//     per-pass pooled maxima live in a compact (B,T,32) buffer instead of a 33.5 MB/shape dense grid;
-//   * max is order-independent -> integer-ordered atomicMax gives bit-exact, deterministic results;
-//   * the grid mean accumulates in 2^-32 fixed point (int64 atomics): associative, hence deterministic
-//     and order-independent, and more accurate than an f32 running sum;
+//   * the points of a shape are GROUPED BY CELL once (counting sort: per-cell histogram on a 1 MB/shape int map, exclusive
+//     scan, scatter - two integer atomics per point in total); every later pass walks the points in that order, so the points
+//     of a cell are consecutive lanes of a wave: the local max pool and the mean are SEGMENTED WAVEFRONT REDUCTIONS (5 shuffle
+//     steps over the 32 points of a tile) and only the last lane of each run touches memory (one atomic per run and channel
+//     instead of one per point and channel: runs that cross a tile boundary are the only contended ones);
+//   * a cell's "segment" is named by the sorted position of its first point, so the per-pass pooled maxima live in a
+//     compact (B,T,32) buffer instead of a 33.5 MB/shape dense grid;
+//   * max is order-independent -> integer-ordered max gives bit-exact, deterministic results whatever the order inside a cell;
+//   * the grid mean accumulates in 2^-32 fixed point (int64): associative, hence deterministic and order-independent, and
+//     more accurate than an f32 running sum;
 //   * the per-point MLP blocks run on f32 MFMA (32x32x2) with activations in the C/D register layout
 //     (same chaining trick as sdf_query.hip), weights staged per workgroup in LDS.
 #include "sfmi_common.h"
@@ -33,11 +38,11 @@ __device__ __forceinline__ int fkey(float f) {
 __device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
 // ---------------------------------------------------------------------------------------------
-// E0: cell ids (a2,a3), per-cell representative (segment id), latent occupancy mask (enc.py:85-91)
+// E0: cell ids (a2,a3), per-cell point counts, latent occupancy mask (enc.py:85-91)
 // ---------------------------------------------------------------------------------------------
 __global__ void enc_cells_kernel(const float* __restrict__ cloud,  // (B,T,3) in [-1,1]
                                  int* __restrict__ cell,            // (B,T)
-                                 int* __restrict__ rep,             // (B,G^3) pre-filled with 0x7f7f7f7f
+                                 int* __restrict__ cnt,             // (B,G^3) pre-zeroed: points per cell
                                  unsigned char* __restrict__ mask,  // (B,R,R,R) pre-zeroed, [z][y][x]
                                  int B, int T, int R) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,9 +53,56 @@ __global__ void enc_cells_kernel(const float* __restrict__ cloud,  // (B,T,3) in
   int cx = (int)(ux * (float)ENC_G), cy = (int)(uy * (float)ENC_G), cz = (int)(uz * (float)ENC_G);
   int c = cx + ENC_G * (cy + ENC_G * cz);  // common.py:300-321 'original' order
   cell[i] = c;
-  atomicMin(&rep[(long long)b * ENC_G * ENC_G * ENC_G + c], t);
+  atomicAdd(&cnt[(long long)b * ENC_G * ENC_G * ENC_G + c], 1);
   int mx = (int)(ux * (float)R), my = (int)(uy * (float)R), mz = (int)(uz * (float)R);
   mask[(((long long)b * R + mz) * R + my) * R + mx] = 1;
+}
+
+// E0b: exclusive scan of one shape's 64^3 cell counts -> start[cell] (sorted position of the cell's first point), and a copy
+// `cursor` that the scatter advances.  One 1024-thread workgroup per shape, 256 cells per thread.
+__global__ __launch_bounds__(1024) void enc_scan_kernel(int* __restrict__ start /*in: counts*/, int* __restrict__ cursor) {
+  __shared__ int wsum[16];
+  constexpr int NC = ENC_G * ENC_G * ENC_G, PER = NC / 1024;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* sp = start + (long long)b * NC + tid * PER;
+  int* cp = cursor + (long long)b * NC + tid * PER;
+  int tot = 0;
+  for (int i = 0; i < PER; i += 4) { const int4 v = *reinterpret_cast<const int4*>(sp + i); tot += (v.x + v.y) + (v.z + v.w); }
+  int incl = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - tot;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  for (int i = 0; i < PER; i += 4) {
+    int4 v = *reinterpret_cast<const int4*>(sp + i);
+    int4 o;
+    o.x = base; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z; base = o.w + v.w;
+    *reinterpret_cast<int4*>(sp + i) = o;
+    *reinterpret_cast<int4*>(cp + i) = o;
+  }
+}
+
+// E0c: scatter the points into cell order: order[b][pos] = t, scell[b][pos] = cell (any order INSIDE a cell: max and the
+// fixed-point mean do not depend on it)
+__global__ void enc_scatter_kernel(const int* __restrict__ cell, int* __restrict__ cursor, int* __restrict__ order,
+                                   int* __restrict__ scell, int B, int T) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * T) return;
+  const int b = (int)(i / T), t = (int)(i - (long long)b * T), c = cell[i];
+  const int pos = atomicAdd(&cursor[(long long)b * ENC_G * ENC_G * ENC_G + c], 1);
+  order[(long long)b * T + pos] = t;
+  scell[(long long)b * T + pos] = c;
+}
+
+// debug taps only: rows of a (B,T,C) buffer from cell order back to the caller's point order
+__global__ void enc_unsort_kernel(const float* __restrict__ src, const int* __restrict__ order, float* __restrict__ dst, int B, int T, int C) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = gid / C;
+  if (i >= (long long)B * T) return;
+  const int b = (int)(i / T);
+  dst[((long long)b * T + order[i]) * C + gid % C] = src[gid];
 }
 
 // one 32x32 layer: acc += W * x  (x in C/D layout, optional ReLU on the fly)
@@ -78,12 +130,14 @@ __device__ __forceinline__ void bias_init(const float* __restrict__ b, int hi, f
 // E1..E5: one ResnetBlockFC stage per launch (the pooling between stages is a global dependency).
 //   STAGE 0 : x = fc_pos(p)                      (enc.py:125-127)
 //   STAGE k : x = cat[net_{k-1}, pooled_{k-1}]   (enc.py:128-131)
-//   out net_k ; atomicMax into segmax_k (k<4) ; k==4: c = fc_c(net) -> fixed-point mean accumulators
+//   out net_k ; segmented wavefront max -> segmax_k (k<4) ; k==4: c = fc_c(net) -> segmented fixed-point sums for the mean
+// Points are processed in CELL ORDER (order / scell): a tile = 32 consecutive sorted points, lane pl = point.
 // ---------------------------------------------------------------------------------------------
 template <int STAGE>
 __global__ __launch_bounds__(256) void enc_block_kernel(
-    const float* __restrict__ cloud, const int* __restrict__ cell, const int* __restrict__ rep,
-    const float* __restrict__ net_in,     // (B,T,32)
+    const float* __restrict__ cloud, const int* __restrict__ cell /*sorted*/, const int* __restrict__ rep /*start[cell]*/,
+    const int* __restrict__ order,        // (B,T) sorted position -> point index
+    const float* __restrict__ net_in,     // (B,T,32) in sorted order
     const int* __restrict__ segmax_in,    // (B,T,32) ordered-int keys
     float* __restrict__ net_out,          // (B,T,32)
     int* __restrict__ segmax_out,         // (B,T,32) pre-filled 0x80808080
@@ -120,11 +174,22 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
     const bool valid = i < total;
     if (!valid) i = total - 1;
     const int b = (int)(i / T);
-    const long long seg = (long long)b * T + rep[(long long)b * ENC_G * ENC_G * ENC_G + cell[i]];
+    // segment = sorted position of the cell's first point (b*T + start[cell] < 2^31); for the run tests a lane that is not
+    // valid gets a segment of its own
+    const int segi = (int)((long long)b * T) + rep[(long long)b * ENC_G * ENC_G * ENC_G + cell[i]];
+    const long long seg = segi;
+    const int segq = valid ? segi : -1 - pl;
+    // run structure of the tile (both halves of the wave hold the same 32 points): same run as the lane `off` below?
+    // (every shuffle is executed by ALL lanes - a short-circuited `&&` would read from lanes that skipped it)
+    bool same[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int o_ = __shfl_up(segq, 1 << k, 32); same[k] = pl >= (1 << k) && o_ == segq; }
+    const int nxt_ = __shfl_down(segq, 1, 32);
+    const bool run_last = pl == 31 || nxt_ != segq;
 
     f32x16 xlo, xhi;
     if (STAGE == 0) {
-      const float* p = cloud + i * 3;
+      const float* p = cloud + ((long long)b * T + order[i]) * 3;
       const float hx = p[0] * 0.5f, hy = p[1] * 0.5f, hz = p[2] * 0.5f;  // vqdif.py:36 Xbd/2
       const float* fp = lds + ENC_BLK_FLOATS;
 #pragma unroll
@@ -163,9 +228,22 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
         for (int g = 0; g < 4; ++g) {
           f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
           op[2 * g] = v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) atomicMax(sm + 8 * g + j, fkey(o[4 * g + j]));
         }
+      }
+      // local max pool (enc.py:95-112): segmented inclusive max over the points of the tile, then ONE atomic per run and channel
+      int key[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) key[t] = fkey(o[t]);
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const int u = __shfl_up(key[t], 1 << k, 32); if (same[k]) key[t] = max(key[t], u); }
+      if (valid && run_last) {
+        int* sm = segmax_out + seg * 32 + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicMax(sm + 8 * g + j, key[4 * g + j]);
       }
     } else {
       // c = fc_c(net) (enc.py:133) -> fixed-point accumulate for the per-cell mean (enc.py:70-74)
@@ -173,23 +251,35 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
       bias_init(lds + ENC_BLK_FLOATS + 1024, hi, c);
       layer32<false>(reinterpret_cast<const f32x4*>(lds + ENC_BLK_FLOATS) + lane, o, c);
       if (valid && net_out) {   // debug tap (sfmi_encode_points_tap_f32): row i = [block-4 output (32) | c = fc_c(net) (32)]
-        f32x4* tp = reinterpret_cast<f32x4*>(net_out + i * 64 + 4 * hi);
+        f32x4* tp = reinterpret_cast<f32x4*>(net_out + ((long long)b * T + order[i]) * 64 + 4 * hi);   // caller's point order
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           tp[2 * g] = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
           tp[8 + 2 * g] = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
         }
       }
-      if (valid) {
+      // scatter_mean numerator (enc.py:70-74): segmented inclusive SUM in 2^-32 fixed point, one atomic per run and channel
+      long long q[16];
+      int n = valid ? 1 : 0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) q[t] = valid ? __double2ll_rn((double)c[t] * 4294967296.0) : 0ll;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int lo = __shfl_up((int)(q[t] & 0xffffffffll), 1 << k, 32), hi32 = __shfl_up((int)(q[t] >> 32), 1 << k, 32);
+          if (same[k]) q[t] += ((long long)hi32 << 32) | (unsigned int)lo;
+        }
+        const int un = __shfl_up(n, 1 << k, 32);
+        if (same[k]) n += un;
+      }
+      if (valid && run_last) {
         long long* sp = csum + seg * 32 + 4 * hi;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            long long q = __double2ll_rn((double)c[4 * g + j] * 4294967296.0);
-            atomicAdd(reinterpret_cast<unsigned long long*>(sp + 8 * g + j), (unsigned long long)q);
-          }
-        if (hi == 0) atomicAdd(ccount + seg, 1);
+          for (int j = 0; j < 4; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(sp + 8 * g + j), (unsigned long long)q[4 * g + j]);
+        if (hi == 0) atomicAdd(ccount + seg, n);
       }
     }
   }
@@ -204,8 +294,8 @@ __global__ void enc_grid_mean_kernel(const int* __restrict__ cell, const int* __
   int ch = (int)(gid & 31);
   if (i >= (long long)B * T) return;
   int b = (int)(i / T), t = (int)(i - (long long)b * T);
-  int c = cell[i];
-  if (rep[(long long)b * ENC_G * ENC_G * ENC_G + c] != t) return;  // only the representative writes
+  int c = cell[i];                                                 // sorted cell array: position t is a run start iff ...
+  if (rep[(long long)b * ENC_G * ENC_G * ENC_G + c] != t) return;  // ... it is the cell's first sorted position
   double s = (double)csum[i * 32 + ch] * (1.0 / 4294967296.0);
   grid[((long long)b * ENC_G * ENC_G * ENC_G + c) * 32 + ch] = (float)(s / (double)ccount[i]);
 }
@@ -251,59 +341,66 @@ int sfmi_enc_pack_weights(const float* fc_pos_w /*64x3*/, const float* fc_pos_b 
 
 size_t sfmi_enc_workspace_bytes(int B, int T) {
   size_t bt = (size_t)B * T;
-  // cell(4) + rep map + 2 net buffers + 2 segmax buffers + csum + ccount
-  return bt * 4 + (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + 1024;
+  // cell + order + sorted cell (3 x 4) + start map + cursor map + 2 net buffers + 2 segmax buffers + csum + ccount
+  return bt * 12 + 2 * (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + 1024;
 }
 
-// replaces LocalPoolPointnet.forward up to scatter_mean (enc.py:115-140 minus the Downsampler):
-// cloud (B,T,3) -> dense channels-last mean grid (B,64,64,64,32) + latent occupancy mask (B,R,R,R) u8.
 int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace,
                                int B, int T, int R, float* tap_stage1, float* tap_stage4c, void* stream_);
+// replaces LocalPoolPointnet.forward up to scatter_mean (enc.py:115-140 minus the Downsampler):
+// cloud (B,T,3) -> dense channels-last mean grid (B,64,64,64,32) + latent occupancy mask (B,R,R,R) u8.
 int sfmi_encode_points_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask,
                            int* cell_out /*optional (B,T)*/, void* workspace, int B, int T, int R, void* stream_) {
   return sfmi_encode_points_tap_f32(cloud, wpack, grid_cl, mask, cell_out, workspace, B, T, R, nullptr, nullptr, stream_);
 }
-// the same pipeline with per-point taps for stage-wise parity tests: tap_stage1 (B,T,32) = output of blocks[1] (after the first
-// local max pool), tap_stage4c (B,T,64) = [output of blocks[4] | c = fc_c(net)] (enc.py:124-133); either may be NULL
+// the same pipeline with per-point taps for stage-wise parity tests (caller's point order): tap_stage1 (B,T,32) = output of
+// blocks[1] (after the first local max pool), tap_stage4c (B,T,64) = [output of blocks[4] | c = fc_c(net)] (enc.py:124-133)
 int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace,
                                int B, int T, int R, float* tap_stage1, float* tap_stage4c, void* stream_) {
   if (!cloud || !wpack || !grid_cl || !mask || !workspace || B <= 0 || T <= 0 || R <= 0) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
-  const size_t bt = (size_t)B * T;
+  const size_t bt = (size_t)B * T, nc = (size_t)B * ENC_G * ENC_G * ENC_G;
   char* w = (char*)workspace;
   int* cell = (int*)w; w += bt * 4;
-  int* rep = (int*)w; w += (size_t)B * ENC_G * ENC_G * ENC_G * 4;
+  int* order = (int*)w; w += bt * 4;
+  int* scell = (int*)w; w += bt * 4;
+  int* start = (int*)w; w += nc * 4;
+  int* cursor = (int*)w; w += nc * 4;
   float* net[2]; net[0] = (float*)w; w += bt * 128; net[1] = (float*)w; w += bt * 128;
   int* sm[2]; sm[0] = (int*)w; w += bt * 128; sm[1] = (int*)w; w += bt * 128;
   long long* csum = (long long*)w; w += bt * 256;
   int* ccount = (int*)w;
-  hipMemsetAsync(rep, 0x7f, (size_t)B * ENC_G * ENC_G * ENC_G * 4, st);
+  hipMemsetAsync(start, 0, nc * 4, st);
   hipMemsetAsync(mask, 0, (size_t)B * R * R * R, st);
   hipMemsetAsync(csum, 0, bt * 256 + bt * 4, st);
-  hipMemsetAsync(grid_cl, 0, (size_t)B * ENC_G * ENC_G * ENC_G * 32 * 4, st);
+  hipMemsetAsync(grid_cl, 0, nc * 32 * 4, st);
   int nb = (int)((bt + 255) / 256);
-  hipLaunchKernelGGL(enc_cells_kernel, dim3(nb), dim3(256), 0, st, cloud, cell, rep, mask, B, T, R);
+  // group the points of every shape by cell: histogram -> exclusive scan -> scatter (2 integer atomics per point)
+  hipLaunchKernelGGL(enc_cells_kernel, dim3(nb), dim3(256), 0, st, cloud, cell, start, mask, B, T, R);
+  hipLaunchKernelGGL(enc_scan_kernel, dim3(B), dim3(1024), 0, st, start, cursor);
+  hipLaunchKernelGGL(enc_scatter_kernel, dim3(nb), dim3(256), 0, st, cell, cursor, order, scell, B, T);
   const long long tiles = (long long)(bt + 31) / 32;
   int grid = (int)((tiles + 3) / 4);
   if (grid > 2048) grid = 2048;
   const size_t lds0 = (ENC_BLK_FLOATS + 256) * 4, ldsk = ENC_BLK_FLOATS * 4, lds4 = (ENC_BLK_FLOATS + 1056) * 4;
   hipMemsetAsync(sm[0], 0x80, bt * 128, st);
-  hipLaunchKernelGGL(enc_block_kernel<0>, dim3(grid), dim3(256), lds0, st, cloud, cell, rep, nullptr, nullptr, net[0],
+  hipLaunchKernelGGL(enc_block_kernel<0>, dim3(grid), dim3(256), lds0, st, cloud, scell, start, order, nullptr, nullptr, net[0],
                      sm[0], nullptr, nullptr, wpack, B, T);
   hipMemsetAsync(sm[1], 0x80, bt * 128, st);
-  hipLaunchKernelGGL(enc_block_kernel<1>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[0], sm[0], net[1],
+  hipLaunchKernelGGL(enc_block_kernel<1>, dim3(grid), dim3(256), ldsk, st, cloud, scell, start, order, net[0], sm[0], net[1],
                      sm[1], nullptr, nullptr, wpack, B, T);
-  if (tap_stage1) hipMemcpyAsync(tap_stage1, net[1], bt * 128, hipMemcpyDeviceToDevice, st);
+  if (tap_stage1)
+    hipLaunchKernelGGL(enc_unsort_kernel, dim3((unsigned)((bt * 32 + 255) / 256)), dim3(256), 0, st, net[1], order, tap_stage1, B, T, 32);
   hipMemsetAsync(sm[0], 0x80, bt * 128, st);
-  hipLaunchKernelGGL(enc_block_kernel<2>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[1], sm[1], net[0],
+  hipLaunchKernelGGL(enc_block_kernel<2>, dim3(grid), dim3(256), ldsk, st, cloud, scell, start, order, net[1], sm[1], net[0],
                      sm[0], nullptr, nullptr, wpack, B, T);
   hipMemsetAsync(sm[1], 0x80, bt * 128, st);
-  hipLaunchKernelGGL(enc_block_kernel<3>, dim3(grid), dim3(256), ldsk, st, cloud, cell, rep, net[0], sm[0], net[1],
+  hipLaunchKernelGGL(enc_block_kernel<3>, dim3(grid), dim3(256), ldsk, st, cloud, scell, start, order, net[0], sm[0], net[1],
                      sm[1], nullptr, nullptr, wpack, B, T);
-  hipLaunchKernelGGL(enc_block_kernel<4>, dim3(grid), dim3(256), lds4, st, cloud, cell, rep, net[1], sm[1], tap_stage4c,
+  hipLaunchKernelGGL(enc_block_kernel<4>, dim3(grid), dim3(256), lds4, st, cloud, scell, start, order, net[1], sm[1], tap_stage4c,
                      nullptr, csum, ccount, wpack, B, T);
   long long nthr = (long long)bt * 32;
-  hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, cell, rep, csum,
+  hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, scell, start, csum,
                      ccount, grid_cl, B, T);
   if (cell_out) hipMemcpyAsync(cell_out, cell, bt * 4, hipMemcpyDeviceToDevice, st);
   SFMI_CHECK_LAUNCH();

@@ -1,0 +1,20 @@
+"""Per-point encoder (sfmi_encode_points_f32: cell grouping + 5 ResnetBlockFC stages with 4 local max pools + scatter_mean) timing."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from shapeformer_amd import _lib as L, synthetic
+from shapeformer_amd.vqdif import VQDIF
+from bench import ev_time
+dev = torch.device("cuda:0")
+vq = VQDIF(res=16, device=dev)
+lib = L.lib()
+for B, T in ((64, 16384), (32, 32768), (8, 16384)):
+    X = torch.from_numpy(synthetic.make_batch(99, B, n_partial=T, n_full=T)["Xct" if T == 16384 else "Xbd"]).to(dev)
+    ws = torch.empty(lib.sfmi_enc_workspace_bytes(B, T), device=dev, dtype=torch.uint8)
+    g64 = torch.empty(B, 64, 64, 64, 32, device=dev)
+    msk = torch.empty(B, 16, 16, 16, device=dev, dtype=torch.uint8)
+    f = lambda: L.check(lib.sfmi_encode_points_f32(L.ptr(X), L.ptr(vq.enc_w), L.ptr(g64), L.ptr(msk), None, L.ptr(ws), B, T, 16, L.stream_ptr()), "enc")
+    ms = ev_time(f, 10)
+    alg = B * (4 * (2 * T * 128 + T * 4) + T * 128 + 64 ** 3 * 128)
+    print(f"B={B} T={T}: {ms:.3f} ms  ({ms / B * 1e3:.1f} us/shape, algorithmic {alg / ms / 1e6:.0f} GB/s = {alg / ms / 1e6 / 8000:.3f} of HBM peak; "
+          f"{B * T * 53.6e3 / ms / 1e9:.1f} TFLOP/s)")
