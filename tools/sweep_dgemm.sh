@@ -1,5 +1,7 @@
 #!/bin/bash
-# end-to-end A/B of decode-GEMM workgroup shapes: bench.py (2 timed passes) per SFMI_DGEMM_LDS setting; prints value + AR-loop ms/step
+# end-to-end A/B of decode-step settings: bench.py (2 timed passes) per stdin line `name _ [WIDE] [SKIP=<spec>] [bench args]`;
+# WIDE = two-n-tiles-per-wave decode GEMM for 17..96 rows, SKIP = SFMI_DECODE_SKIP timing ablation (gemm | attn | gemm@0,attn@1,...);
+# prints value + stage times + AR-loop ms/step.  (profiles/r02_sweep_*.txt)
 out=${1:-gpurun_out/r2/sweep.txt}; mkdir -p $(dirname $out); : > $out
 run() {  # name, env, extra args
   echo "== $1 [$2] $3" >> $out
