@@ -12,6 +12,9 @@
 //   K-contiguous operand -> [row][32 + 4] floats, fragments read as ds_read_b128 (row stride 36: the 16-lane groups of a
 //   b128 read hit 16 distinct bank quads);  row-contiguous operand -> [k][128 + 4] floats, fragments read as ds_read_b32
 //   (32 consecutive floats per half-wave).
+// (Tried and dropped, round 2: the same tiles brought in by LDS-DMA `global_load_lds_dwordx4` with an XOR-swizzled unpadded
+//  layout, all fragments of a chunk read before the next chunk's DMA is issued - correct, but 105-115 TFLOP/s against 113-128
+//  for the register-staged loop below: the fragment burst no longer overlaps the MFMAs.)
 // Block order is XCD-aware (block b runs on XCD b % 8): the N-tiles of one M-tile are consecutive on ONE XCD, so the A tile is
 // fetched from HBM once per XCD L2 instead of once per N-tile.
 #include "sfmi_common.h"
