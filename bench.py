@@ -459,6 +459,8 @@ def main():
                            + sum(w.numel() for w in gpt.head_w))
             ms_step = tm["ar_loop"] / a.ar_steps
             line["stages_ms"] = {k: round(v, 1) for k, v in tm.items()}
+            if getattr(gpt, "_chain_probe", None):   # stream-pair probe times of gpt._chain_streams (0.2 ms = concurrent)
+                line["chain_stream_probe_ms"] = gpt._chain_probe
             alg, streamed = kv_bytes + w_one, kv_bytes + n_chain * w_one
             line["ar_loop"] = {"ms_per_step": round(ms_step, 3),
                                "algorithmic_bytes_per_step": int(alg), "algorithmic_TBps": round(alg / ms_step / 1e9, 3),

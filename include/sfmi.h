@@ -27,6 +27,9 @@ extern "C" {
 #define SFMI_ENOBLAS (-3) /* rocBLAS could not be bound (csrc/blas.hip); callers fall back to the tile kernels */
 
 int sfmi_version(void);
+/* one wavefront busy for `ticks` of the 100 MHz wall clock (<= 1 s) on `stream`: the stream-concurrency probe of the interleaved
+ * decode chains (no reference counterpart: the reference runs one chain on one stream, shapeformer.py:85-132) */
+int sfmi_stream_spin(long long ticks, void* stream);
 
 /* ---- VQDIF encoder, per-point path: enc.py:95-140 (LocalPoolPointnet.forward up to scatter_mean), layers.py:39-48,
  *      vqdif/common.py:260-321, torch_scatter.scatter_max / scatter_mean call sites enc.py:70-74,103-110 ---------- */

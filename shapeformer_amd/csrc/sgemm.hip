@@ -24,6 +24,11 @@
 namespace {
 
 constexpr int SG_BM = 128, SG_BN = 128, SG_KC = 32;
+#ifndef SG_GM_OVERRIDE
+constexpr int SG_GM = 8;                // M-tiles per panel of the block order
+#else
+constexpr int SG_GM = SG_GM_OVERRIDE;
+#endif
 constexpr int SG_KS = SG_KC + 4;      // row stride of a K-contiguous LDS tile
 constexpr int SG_RS = SG_BM + 4;      // row stride of a row-contiguous LDS tile ([k][rows])
 constexpr int SG_TILE = 128 * 36;     // floats per operand tile in either orientation (32 * 132 = 4224 <= 4608)
@@ -49,7 +54,20 @@ __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(SgemmArgs a) {
     const long long q = nb / 8, r = nb % 8, xcd = lid % 8, k = lid / 8;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective for any nb
   }
-  const int m0 = (int)(lid / nbn) * SG_BM, n0 = (int)(lid % nbn) * SG_BN;
+  // within the XCD's contiguous range the blocks walk PANELS of SG_GM M-tiles: for every N-tile the panel's M-tiles are
+  // consecutive, so the ~64 blocks resident on an XCD at a time cover ~8 M-tiles x ~8 N-tiles (each A and each B tile is
+  // shared by 8 resident blocks through the XCD's L2) instead of 2 M-tiles x all N-tiles
+  int mt, ntl;
+  {
+    const int nbm = (a.M + SG_BM - 1) / SG_BM;
+    const long long per_panel = (long long)SG_GM * nbn;
+    const int panel = (int)(lid / per_panel);
+    const int rows_in_panel = min(SG_GM, nbm - panel * SG_GM);
+    const long long r = lid - panel * per_panel;
+    ntl = (int)(r / rows_in_panel);
+    mt = panel * SG_GM + (int)(r % rows_in_panel);
+  }
+  const int m0 = mt * SG_BM, n0 = ntl * SG_BN;
 
   // ---- staging: 4 float4 of A and 4 float4 of B per thread and chunk ---------------------------------------------------
   f32x4 ra[2][4], rb[2][4];      // two prefetch sets: the loads of chunk c+2 are issued while chunk c computes

@@ -12,6 +12,7 @@ shapeformer.py:227).  No CPU fallback.
 """
 from __future__ import annotations
 
+import os
 import numpy as np
 import torch
 
@@ -43,6 +44,7 @@ class CondTupleGPT:
     S_PROJ, S_FC2 = 1, 4   # in-kernel split-K of the N = n_embd GEMMs (64 n-tiles -> 256 workgroups)
     import os as _os
     # prefill GEMMs with at least this many rows go to the library sgemm; None (default): every GEMM is csrc/sgemm.hip
+    PREFILL_ON_CHAIN_STREAMS = True   # tools/probe_chain_streams.py switches it off for the A/B
     PREFILL_BLAS_ROWS = 2048 if _os.environ.get("SFMI_ROCBLAS") == "1" else None
 
     def _blas(self):
@@ -546,6 +548,52 @@ class CondTupleGPT:
         return res
 
     @torch.no_grad()
+    def _chain_streams(self, n):
+        """n HIP streams that really run concurrently, for the interleaved decode chains.  The runtime multiplexes streams
+        onto a few hardware queues (assigned at a stream's first use, least-loaded queue first), and two chains whose streams
+        share a queue run back to back instead of overlapping (measured: 5.2 instead of 4.2 ms per decode step when two of the
+        three chains share one).  Which streams collide depends on every stream the process used before, so candidates are
+        probed: two 200 us single-wavefront spins (csrc/capi.hip) take ~200 us on distinct queues, ~400 us on a shared one."""
+        chosen = list(getattr(self, "_mb_streams", []))
+        if len(chosen) >= n:
+            return chosen[:n]
+        ticks = 20000                       # x 10 ns
+        self._chain_probe = getattr(self, "_chain_probe", [])   # probe times in ms, kept for diagnostics
+        spin = lambda s, t: L.check(L.lib().sfmi_stream_spin(t, s.cuda_stream), "sfmi_stream_spin")
+        cur = torch.cuda.current_stream()
+
+        def overlap(a, b):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for s in (a, b):
+                s.wait_event(e0)
+                spin(s, ticks)
+            for s in (a, b):
+                cur.wait_stream(s)
+            e1.record(cur)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            self._chain_probe.append(round(ms, 3))
+            return ms < 1.5 * ticks * 1e-5
+
+        spare = []
+        for _ in range(16):
+            if len(chosen) >= n:
+                break
+            c = torch.cuda.Stream(device=self.dev)
+            spin(c, 1)                       # first use: the runtime binds the stream to a hardware queue here
+            c.synchronize()
+            if all(overlap(c, x) for x in chosen):
+                chosen.append(c)
+            else:
+                spare.append(c)
+        if len(chosen) < n:
+            import warnings
+            warnings.warn(f"only {len(chosen)} of {n} decode chains get a hardware queue of their own; the others share one")
+            chosen += spare[:n - len(chosen)]
+        self._mb_streams = chosen
+        return chosen[:n]
+
     def sample_microbatched(self, c_tokens, Lc, n_micro=2, max_steps=512, top_k=100, top_p=0.4, temperature=1.0,
                             best_in_first=True, mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True,
                             check_every=32, after_prefill=None):
@@ -557,22 +605,28 @@ class CondTupleGPT:
         bounds = [round(i * B / n_micro) for i in range(n_micro + 1)]
         groups = [(bounds[i], bounds[i + 1]) for i in range(n_micro) if bounds[i + 1] > bounds[i]]
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
+        streams = self._chain_streams(len(groups))
+        cur = torch.cuda.current_stream()
         ctxs = []
+        # every chain's prefill is issued on that chain's own stream: the chains' GEMMs / attention launches then fill each
+        # other's last partial round of workgroups (a 10k-row x 1024-column GEMM is 632 tiles for 512 resident slots), and the
+        # chain's decode graph follows on the same stream
         for i, (lo, hi) in enumerate(groups):
-            ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B))
+            streams[i].wait_stream(cur)
+            with torch.cuda.stream(streams[i] if self.PREFILL_ON_CHAIN_STREAMS else cur):
+                ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B))
         steps = min(c["steps"] for c in ctxs)
         if after_prefill is not None:
+            for s in streams:
+                cur.wait_stream(s)
             after_prefill()
-        if not hasattr(self, "_mb_streams") or len(self._mb_streams) < len(ctxs):
-            self._mb_streams = [torch.cuda.Stream(device=self.dev) for _ in ctxs]
-        cur = torch.cuda.current_stream()
-        for s in self._mb_streams[:len(ctxs)]:
-            s.wait_stream(cur)
+            for s in streams:
+                s.wait_stream(cur)
         done = 0
         while done < steps:
             n = min(check_every, steps - done) if stop_early else steps - done
             for _ in range(n):
-                for c, s in zip(ctxs, self._mb_streams):
+                for c, s in zip(ctxs, streams):
                     with torch.cuda.stream(s):
                         if c["graph"] is not None:
                             c["graph"].replay()
@@ -580,11 +634,11 @@ class CondTupleGPT:
                             self.decode_step(c["st"], c["B"], c["sp"])
             done += n
             if stop_early:
-                for s in self._mb_streams[:len(ctxs)]:
+                for s in streams:
                     cur.wait_stream(s)
                 if all(self._all_ended(c["st"], c["B"]) for c in ctxs):
                     break
-        for s in self._mb_streams[:len(ctxs)]:
+        for s in streams:
             cur.wait_stream(s)
         merged = {k: torch.cat([c["st"][k] for c in ctxs], 0) for k in ("seq", "len", "Lc", "logp")}
         return dict(state=merged, steps=done)

@@ -180,6 +180,36 @@ def test_microbatched_two_stream_decode_is_bit_identical(dev):
         assert torch.equal(lp_a, b["state"]["logp"])
 
 
+def test_chain_streams_run_concurrently(dev):
+    """The decode chains' streams are probed to sit on different hardware queues (gpt._chain_streams): every pair of the
+    chosen streams overlaps two 200 us spins (two streams on one queue take 400 us and cost the 3-chain loop 25 %), also
+    when other streams have bound the queues first."""
+    from shapeformer_amd import _lib as L
+    from shapeformer_amd.gpt import CondTupleGPT
+    sd, sd_t, cfg = _tiny()
+    g = CondTupleGPT(sd, n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    decoys = [torch.cuda.Stream(device=dev) for _ in range(5)]      # whatever the process used before
+    for s in decoys:
+        L.check(L.lib().sfmi_stream_spin(1, s.cuda_stream), "spin")
+    torch.cuda.synchronize()
+    S = g._chain_streams(3)
+    assert len(S) == 3 and len({s.cuda_stream for s in S}) == 3
+    assert g._chain_streams(2)[0] is S[0]                            # cached
+    cur = torch.cuda.current_stream()
+    for i in range(3):
+        for j in range(i + 1, 3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for s in (S[i], S[j]):
+                s.wait_event(e0)
+                L.check(L.lib().sfmi_stream_spin(20000, s.cuda_stream), "spin")
+                cur.wait_stream(s)
+            e1.record(cur)
+            e1.synchronize()
+            assert 0.19 < e0.elapsed_time(e1) < 0.32, (i, j, e0.elapsed_time(e1))
+    assert L.lib().sfmi_stream_spin(-1, None) == -1            # SFMI_EINVAL
+
+
 def test_sample_next_tuple_generator_protocol(dev):
     """mingpt.py:297-310 protocol: next(gen) -> position logits, gen.send(target_pos) -> value logits; must equal the
     teacher-forced forward on the same inputs."""

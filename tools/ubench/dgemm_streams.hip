@@ -22,6 +22,9 @@ int main(int argc, char** argv) {
       {"lds: qkv 3,4,S4  proj r1  fc1 2,4,S2  fc2 r1", 1, {3, 4, 4}, {0, 0, 4}, {2, 4, 2}, {0, 0, 4}},
   };
   for (auto& cf : cfgs) {
+#ifdef DGS_R1_ONLY
+    if (cf.lds) continue;
+#endif
     std::vector<hipStream_t> st(NS);
     std::vector<hipGraphExec_t> ge(NS);
     std::vector<float*> x(NS), qkv(NS), y(NS), r(NS), h(NS), slab(NS);
