@@ -29,8 +29,8 @@ struct ConvArgs {
   int sp_on, spz, spy, spx, padz, pady, padx;
 };
 
-template <int CO_TILES, int WM, int WN>
-__global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
+template <int CO_TILES, int WM, int WN, bool UPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES == 1 ? 3 : 2))) void conv3d_igemm_kernel(ConvArgs a) {
   constexpr int N_T = 32 * CO_TILES * WM;
   constexpr int M_T = 64 * WN;
   constexpr int W_ROWS = (N_T * 4 + 255) / 256;  // weight float4 rows per thread
@@ -74,40 +74,95 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
   const int cpt = a.Cin / KC;                 // chunks per tap
   const int nchunks = a.KS * a.KS * a.KS * cpt;
 
-  f32x4 ra[WN], rw[W_ROWS];
-  auto load_chunk = [&](int c) {
-    const int tap = c / cpt, c0 = (c - tap * cpt) * KC + seg * 4;
-    const int dz = tap / (a.KS * a.KS), dy = (tap / a.KS) % a.KS, dx = tap % a.KS;
+  // Per-chunk work kept off the vector unit (with one 32-column tile per wave the MFMAs of a chunk take ~1000 cycles, and
+  // the old per-chunk tap decode + bounds tests + 64-bit address chains of 4 voxels took about as long): per voxel ONE base
+  // offset and three 3-bit per-axis validity masks are computed here; inside the loop the tap walks (dz,dy,dx,chunk) as
+  // wave-uniform scalars and a voxel costs a shift-and-test plus one 64-bit add.  UPS (nearest-x2 folded into the address,
+  // only the direct form of an up-sampling conv) keeps the general arithmetic.
+  long long vbase[WN];
+  int vmask[WN];
 #pragma unroll
-    for (int i = 0; i < WN; ++i) {
-      const int iz = vz[i] + dz, iy = vy[i] + dy, ix = vx[i] + dx;
-      const bool ok = vok[i] && iz >= 0 && iz < Dv && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const long long off = ((((long long)vb[i] * a.Di + (iz >> a.up)) * a.Hi + (iy >> a.up)) * a.Wi + (ix >> a.up)) * a.Cin + c0;
-        v = *reinterpret_cast<const f32x4*>(a.x + off);
-        if (a.in_scale) {
-          const f32x4 s = *reinterpret_cast<const f32x4*>(a.in_scale + (long long)vb[i] * a.Cin + c0);
-          const f32x4 t = *reinterpret_cast<const f32x4*>(a.in_shift + (long long)vb[i] * a.Cin + c0);
-          v = v * s + t;
-        }
-      }
-      ra[i] = v;
+  for (int i = 0; i < WN; ++i) {
+    int mk = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (d < a.KS && vz[i] + d >= 0 && vz[i] + d < Dv) mk |= 1 << d;
+      if (d < a.KS && vy[i] + d >= 0 && vy[i] + d < Hv) mk |= 8 << d;
+      if (d < a.KS && vx[i] + d >= 0 && vx[i] + d < Wv) mk |= 64 << d;
     }
+    vmask[i] = vok[i] ? mk : 0;
+    vbase[i] = ((((long long)vb[i] * a.Di + vz[i]) * a.Hi + vy[i]) * a.Wi + vx[i]) * a.Cin + seg * 4;
+  }
+  const bool one_b = (vb[0] == vb[WN - 1]);   // the tile lies inside one shape: its GroupNorm affine is loaded once per chunk
+  long long wbase[W_ROWS];
+#pragma unroll
+  for (int i = 0; i < W_ROWS; ++i) wbase[i] = (long long)(n0 + srow + 64 * i) * a.Cin + seg * 4;
+  int t_dz = 0, t_dy = 0, t_dx = 0, t_cc = 0, t_tap = 0;   // wave-uniform walk over (tap, channel chunk)
+
+  // two register sets: the global loads of chunk c+2 are issued while chunk c is multiplied (one set gave the loads only the
+  // ~1000 MFMA cycles of a single chunk to land).  The GroupNorm affine and the zero padding are applied when a set is
+  // written to LDS (x*scale+shift needs the loaded value: done at load time it would stall on the load it was meant to hide).
+  f32x4 ra[2][WN], rw[2][W_ROWS], rs[2], rt[2];
+  int rok[2];
+  auto load_chunk = [&](const int S) {
+    const int c0 = t_cc * KC + seg * 4;
+    rs[S] = f32x4{1.f, 1.f, 1.f, 1.f};
+    rt[S] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rok[S] = 0;
+    if (UPS || !one_b) {   // general arithmetic (address-folded up-sampling, tiles that straddle shapes): affine applied here
+#pragma unroll
+      for (int i = 0; i < WN; ++i) {
+        const int iz = vz[i] + t_dz, iy = vy[i] + t_dy, ix = vx[i] + t_dx;
+        const bool ok = vok[i] && iz >= 0 && iz < Dv && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const long long off = ((((long long)vb[i] * a.Di + (iz >> a.up)) * a.Hi + (iy >> a.up)) * a.Wi + (ix >> a.up)) * a.Cin + c0;
+          v = *reinterpret_cast<const f32x4*>(a.x + off);
+          if (a.in_scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale + (long long)vb[i] * a.Cin + c0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift + (long long)vb[i] * a.Cin + c0);
+            v = v * sc + sh;
+          }
+        }
+        ra[S][i] = v;
+        rok[S] |= 1 << i;
+      }
+    } else {
+      const long long toff = (((long long)t_dz * a.Hi + t_dy) * a.Wi + t_dx) * a.Cin + t_cc * KC;
+      if (a.in_scale) {
+        rs[S] = *reinterpret_cast<const f32x4*>(a.in_scale + (long long)vb[0] * a.Cin + c0);
+        rt[S] = *reinterpret_cast<const f32x4*>(a.in_shift + (long long)vb[0] * a.Cin + c0);
+      }
+#pragma unroll
+      for (int i = 0; i < WN; ++i) {
+        const bool ok = ((vmask[i] >> t_dz) & (vmask[i] >> (3 + t_dy)) & (vmask[i] >> (6 + t_dx)) & 1) != 0;
+        ra[S][i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? vbase[i] + toff : (long long)(seg * 4)));   // unconditional load
+        rok[S] |= (ok ? 1 : 0) << i;
+      }
+    }
+    const long long woff = (long long)t_tap * a.Cout * a.Cin + t_cc * KC;
 #pragma unroll
     for (int i = 0; i < W_ROWS; ++i) {
       const int row = srow + 64 * i;
-      if (row < N_T) rw[i] = *reinterpret_cast<const f32x4*>(a.wT + ((long long)tap * a.Cout + n0 + row) * a.Cin + c0);
+      if (row < N_T) rw[S][i] = *reinterpret_cast<const f32x4*>(a.wT + wbase[i] + woff);
+    }
+    if (++t_cc == cpt) {
+      t_cc = 0; ++t_tap;
+      if (++t_dx == a.KS) { t_dx = 0; if (++t_dy == a.KS) { t_dy = 0; ++t_dz; } }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](const int S) {   // register set S -> LDS buffer S
 #pragma unroll
-    for (int i = 0; i < WN; ++i)
-      *reinterpret_cast<f32x4*>(act_lds + ((buf * M_T) + srow + 64 * i) * LDS_STRIDE + seg * 4) = ra[i];
+    for (int i = 0; i < WN; ++i) {
+      f32x4 v = ra[S][i];
+      if (a.in_scale) v = v * rs[S] + rt[S];
+      if (!((rok[S] >> i) & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(act_lds + ((S * M_T) + srow + 64 * i) * LDS_STRIDE + seg * 4) = v;
+    }
 #pragma unroll
     for (int i = 0; i < W_ROWS; ++i) {
       const int row = srow + 64 * i;
-      if (row < N_T) *reinterpret_cast<f32x4*>(wgt_lds + ((buf * N_T) + row) * LDS_STRIDE + seg * 4) = rw[i];
+      if (row < N_T) *reinterpret_cast<f32x4*>(wgt_lds + ((S * N_T) + row) * LDS_STRIDE + seg * 4) = rw[S][i];
     }
   };
 
@@ -119,14 +174,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
 
-  load_chunk(0);
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    store_chunk(buf);
-    __syncthreads();
-    if (c + 1 < nchunks) load_chunk(c + 1);
-    const float* ab = act_lds + (buf * M_T + wn * 64 + pl) * LDS_STRIDE + 4 * hi;
-    const float* wb = wgt_lds + (buf * N_T + wm * CO_TILES * 32 + pl) * LDS_STRIDE + 4 * hi;
+  auto multiply = [&](const int S) {
+    const float* ab = act_lds + (S * M_T + wn * 64 + pl) * LDS_STRIDE + 4 * hi;
+    const float* wb = wgt_lds + (S * N_T + wm * CO_TILES * 32 + pl) * LDS_STRIDE + 4 * hi;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x4 bf[2], af[CO_TILES];
@@ -140,6 +190,20 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < CO_TILES; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = MFMA(af[i][q], bf[j][q], acc[i][j]);
+    }
+  };
+  load_chunk(0);
+  if (nchunks > 1) load_chunk(1);
+  for (int c = 0; c < nchunks; c += 2) {
+    store_chunk(0);
+    __syncthreads();
+    if (c + 2 < nchunks) load_chunk(0);
+    multiply(0);
+    if (c + 1 < nchunks) {
+      store_chunk(1);
+      __syncthreads();
+      if (c + 3 < nchunks) load_chunk(1);
+      multiply(1);
     }
   }
 
@@ -292,15 +356,18 @@ static int conv_dispatch(const ConvArgs& a, void* stream) {
   if (Cout % 128 == 0) {
     constexpr int M_T = 128, N_T = 128;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, true>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    else hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, false>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
   } else if (Cout % 64 == 0) {
     constexpr int M_T = 256, N_T = 64;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, true>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    else hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, false>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
   } else {
     constexpr int M_T = 256, N_T = 32;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, true>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    else hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, false>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
   }
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;

@@ -1,0 +1,49 @@
+"""Per-layer timing of the VQDIF decoder's feature-grid path (UNet3D + Upsampler) at B shapes: every conv launch group,
+GroupNorm statistics, pooling / concat, final affine.  FLOPs as executed (sub-pixel up-sampling convs: 8 taps).
+GPU box only:  python tools/kbench_conv.py [--batch 64]"""
+import argparse, collections, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from shapeformer_amd.vqdif import VQDIF
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+vq = VQDIF(res=16, device=dev)
+code = vq.get_code_cl(torch.randint(0, vq.K, (a.batch, 16, 16, 16), device=dev)).clone()
+rec = collections.OrderedDict()
+
+
+def timed(fn, label, flops_of):
+    def w(*args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args, **kw)
+        e1.record()
+        rec.setdefault(label(*args, **kw), []).append((e0, e1, flops_of(out, *args, **kw)))
+        return out
+    return w
+
+
+def conv_flops(y, x, cv, name, scale=None, shift=None, up=0, relu=True, bias=None):
+    taps = 8 if (up and cv.w_up is not None) else cv.ks ** 3
+    return 2.0 * y.numel() // cv.cout * cv.cout * cv.cin * taps
+
+
+vq._conv = timed(vq._conv, lambda x, cv, name, *r, **k: f"conv {name:16s} {tuple(x.shape[1:4])}x{cv.cin}->{cv.cout} k{cv.ks}" + (" up2" if k.get("up") else ""), conv_flops)
+vq._gn = timed(vq._gn, lambda x, g, b, name: f"gn   {name}", lambda *r, **k: 0.0)
+vq._pool = timed(vq._pool, lambda x, name: f"pool {name}", lambda *r, **k: 0.0)
+vq._upcat = timed(vq._upcat, lambda s, l, name: f"cat  {name}", lambda *r, **k: 0.0)
+vq._affine = timed(vq._affine, lambda x, sc, sh, name: f"aff  {name}", lambda *r, **k: 0.0)
+for _ in range(2 + a.reps):
+    vq.decoder_grid_cl(code)
+torch.cuda.synchronize()
+tot = 0.0
+for k, v in rec.items():
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in v[2:]) / len(v[2:])
+    tot += ms
+    fl = v[-1][2]
+    print(f"{k:60s} {ms:8.3f} ms" + (f"  {fl / ms / 1e9:7.1f} TFLOP/s  ({fl / 1e9 / a.batch:6.2f} GF/shape)" if fl else ""))
+print(f"total {tot:.2f} ms for {a.batch} shapes")
