@@ -385,7 +385,7 @@ def main():
 
     from shapeformer_amd import synthetic
     from shapeformer_amd.gpt import CondTupleGPT
-    from shapeformer_amd.pipeline import ShapeCompletion
+    from shapeformer_amd.pipeline import ShapeCompletion, default_chains
     from shapeformer_amd.vqdif import VQDIF
 
     vq = VQDIF(res=16, device=dev)
@@ -441,7 +441,7 @@ def main():
             "config": {"workload": (f"shape completion, {B} shapes/GPU/step: VQDIF-16 encode of {a.points}-pt partial cloud -> "
                                     f"tokens -> CondTupleGPT 20+4 layers d1024 prefill + {a.ar_steps} KV-cached decode steps "
                                     f"(top_k 100, top_p 0.4, early exit off) -> UNet3D+Upsampler -> {a.decode_res}^3 SDF query"),
-                       "batch_per_gpu": B, "micro_batches": a.micro or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1)), "ar_steps": a.ar_steps, "decode_res": a.decode_res, "parallelism": f"shard{world}",
+                       "batch_per_gpu": B, "micro_batches": a.micro or default_chains(B), "ar_steps": a.ar_steps, "decode_res": a.decode_res, "parallelism": f"shard{world}",
                        "weights": "hash-generated (no checkpoints ship)",
                        "input_selection": (f"synthetic partial clouds whose condition length L_c <= {gpt.Lmax - a.ar_steps} (so that all {a.ar_steps} steps fit "
                                            "the 812-token block; biases the cached length down)"),
@@ -454,7 +454,7 @@ def main():
             step(a.warmup + a.steps, timings=tm)
             lc = r["Lc"].float()
             kv_bytes = float((2 * (lc + (a.ar_steps - 1) / 2.0) * gpt.D * 4 * len(gpt.layers)).sum().item())   # mean over the steps
-            n_chain = a.micro or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
+            n_chain = a.micro or default_chains(B)
             w_one = 4.0 * (sum(l.wqkv.numel() + l.wproj.numel() + l.wfc1.numel() + l.wfc2.numel() for l in gpt.layers)
                            + sum(w.numel() for w in gpt.head_w))
             ms_step = tm["ar_loop"] / a.ar_steps
@@ -488,7 +488,7 @@ def main():
                 line["ar_loop"]["split_note"] = ("all chains interleaved, one kernel family disabled at a time (each still runs the head GEMMs + samplers): "
                                                  "the KV stream alone runs at the achievable HBM rate; the two families time-share the chip "
                                                  "(sum ~ real), profiles/r02_decode_step_experiments.md")
-            nm = a.micro or (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
+            nm = a.micro or default_chains(B)
             Bk = -(-B // nm)     # rows per decode launch (micro-batch)
             if a.no_kernels:
                 print(json.dumps(line), flush=True)

@@ -12,6 +12,15 @@ import torch
 from . import tokens as T
 
 
+def default_chains(B):
+    """Number of interleaved hipGraph decode chains (gpt.py:sample_microbatched) for B rows: <= 64 rows per chain, 2 chains
+    already for 32..64 rows, and 4 chains from 192 rows on (4 x 48 rows: 4.19 ms/step against 4.29 for 3 x 64 - one chain per
+    hardware queue; more queues than 4 (GPU_MAX_HW_QUEUES=8) or 6 chains are slower, profiles/r02_decode_step_experiments.md)."""
+    if B >= 192:
+        return max(-(-B // 64), 4)
+    return -(-B // 64) if B > 64 else (2 if B >= 32 else 1)
+
+
 class ShapeCompletion:
     def __init__(self, vq, gpt, voxel_res=16, block_size=812, end_tokens=(4096, 4096)):
         self.vq, self.gpt = vq, gpt
@@ -46,8 +55,7 @@ class ShapeCompletion:
         mark("encode")
         g = self.gpt
         B = Xct.shape[0]
-        # interleaved hipGraph chains (gpt.py:sample_microbatched): <= 64 rows each; 2 chains already for 32..64 rows
-        n_micro = n_micro if n_micro is not None else (-(-B // 64) if B > 64 else (2 if B >= 32 else 1))
+        n_micro = n_micro if n_micro is not None else default_chains(B)
         kw = dict(max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature, best_in_first=best_in_first,
                   mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion, seed=seed, stop_early=stop_early)
         if n_micro > 1:
