@@ -18,6 +18,39 @@ import torch
 import torch.nn.functional as F
 
 PAD = 0.1
+# Frozen-activation hook for gradient parity tests: two fp32 implementations of a ReLU network take different branches on units
+# whose pre-activation is within rounding error of zero, which changes those units' whole gradient contribution.  When a list
+# of boolean masks is installed here (tests only; oracle.vqdif_train_oracle.loss_and_grads(relu_masks=...)), every ReLU of the
+# forward - consumed in call order - becomes x * mask, i.e. both implementations differentiate the SAME piecewise-linear
+# function and their gradients must then agree to rounding error.  Masks of conv outputs arrive channels-last.
+RELU_MASKS = None
+
+
+def _relu(x):
+    if RELU_MASKS is None:
+        return F.relu(x)
+    m = RELU_MASKS.pop(0)
+    if x.dim() == 5:
+        m = m.permute(0, 4, 1, 2, 3)
+    assert m.numel() == x.numel(), (tuple(m.shape), tuple(x.shape))
+    return x * m.reshape(x.shape).to(x.dtype)
+
+
+POOL_INDEX = None   # same idea for the UNet's 2^3 max-pools: which of the 8 window elements (4 dz + 2 dy + dx) is taken, channels-last
+
+
+def _max_pool2(x):
+    """F.max_pool3d(x, 2), or - with POOL_INDEX installed - the window element another implementation's forward selected (a
+    post-ReLU window whose only live unit is within rounding error of zero has its arg-max on that unit in one implementation
+    and on a dead neighbour in the other: the same kind of branch flip as a ReLU's)."""
+    if POOL_INDEX is None:
+        return F.max_pool3d(x, 2)
+    idx = POOL_INDEX.pop(0).permute(0, 4, 1, 2, 3).long()                      # (B,C,Do,Ho,Wo)
+    B, C, D, H, W = x.shape
+    win = x.view(B, C, D // 2, 2, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(B, C, D // 2, H // 2, W // 2, 8)
+    return win.gather(-1, idx.unsqueeze(-1)).squeeze(-1)
+
+
 G = 64  # encoder / decoder feature grid (configs/vqdif/*.yaml grid_resolution)
 
 
@@ -43,8 +76,8 @@ def cell_index(u, reso=G):
 # ---- a4 --------------------------------------------------------------------
 def resblock(sd, prefix, x):
     """vqdif/layers.py:39-48: x_s + fc_1(relu(fc_0(relu(x))))."""
-    h = F.linear(F.relu(x), sd[prefix + "fc_0.weight"], sd[prefix + "fc_0.bias"])
-    dx = F.linear(F.relu(h), sd[prefix + "fc_1.weight"], sd[prefix + "fc_1.bias"])
+    h = F.linear(_relu(x), sd[prefix + "fc_0.weight"], sd[prefix + "fc_0.bias"])
+    dx = F.linear(_relu(h), sd[prefix + "fc_1.weight"], sd[prefix + "fc_1.bias"])
     sk = prefix + "shortcut.weight"
     xs = F.linear(x, sd[sk]) if sk in sd else x
     return xs + dx
@@ -63,7 +96,7 @@ def local_max_pool(net, cell, ncell=G ** 3):
 def conv_relu_gn(sd, prefix, x, stride, padding):
     """updown.py:79-99 order 'crg': conv(no bias) -> ReLU -> GroupNorm(8)."""
     x = F.conv3d(x, sd[prefix + "conv.weight"], None, stride=stride, padding=padding)
-    x = F.relu(x)
+    x = _relu(x)
     return F.group_norm(x, 8, sd[prefix + "groupnorm.weight"], sd[prefix + "groupnorm.bias"], 1e-5)
 
 
@@ -161,7 +194,7 @@ def quantize_cloud(sd, cloud):
 def single_gcr(sd, prefix, x):
     """unet3d.py:79-101 order 'gcr': GroupNorm(8) -> conv3^3(no bias, pad 1) -> ReLU."""
     x = F.group_norm(x, 8, sd[prefix + "groupnorm.weight"], sd[prefix + "groupnorm.bias"], 1e-5)
-    return F.relu(F.conv3d(x, sd[prefix + "conv.weight"], None, padding=1))
+    return _relu(F.conv3d(x, sd[prefix + "conv.weight"], None, padding=1))
 
 
 def double_conv(sd, prefix, x):
@@ -171,8 +204,8 @@ def double_conv(sd, prefix, x):
 def unet3d(sd, x, prefix="decoder.unet3d."):
     """unet3d.py:449-474 (3 levels, DoubleConv, nearest upsample + concat(skip, x), final 1x1+bias)."""
     e0 = double_conv(sd, prefix + "encoders.0.basic_module.", x)
-    e1 = double_conv(sd, prefix + "encoders.1.basic_module.", F.max_pool3d(e0, 2))
-    e2 = double_conv(sd, prefix + "encoders.2.basic_module.", F.max_pool3d(e1, 2))
+    e1 = double_conv(sd, prefix + "encoders.1.basic_module.", _max_pool2(e0))
+    e2 = double_conv(sd, prefix + "encoders.2.basic_module.", _max_pool2(e1))
     y = torch.cat([e1, F.interpolate(e2, size=e1.shape[2:], mode="nearest")], dim=1)
     y = double_conv(sd, prefix + "decoders.0.basic_module.", y)
     y = torch.cat([e0, F.interpolate(y, size=e0.shape[2:], mode="nearest")], dim=1)
@@ -214,7 +247,7 @@ def sdf_mlp(sd, p, c):
     for i in range(5):
         net = net + F.linear(c, sd[f"decoder.fc_c.{i}.weight"], sd[f"decoder.fc_c.{i}.bias"])
         net = resblock(sd, f"decoder.blocks.{i}.", net)
-    return F.linear(F.relu(net), sd["decoder.fc_out.weight"], sd["decoder.fc_out.bias"])
+    return F.linear(_relu(net), sd["decoder.fc_out.weight"], sd["decoder.fc_out.bias"])
 
 
 def sdf_query(sd, grid, Xtg, chunk=1 << 18):

@@ -45,12 +45,25 @@ def trainable_keys(sd):
     return [k for k in sd if not k.startswith("quantizer.")]
 
 
-def loss_and_grads(sd, Xbd, Xtg, Ytg, beta):
+def loss_and_grads(sd, Xbd, Xtg, Ytg, beta, relu_masks=None, pool_index=None):
+    """relu_masks: optional list of boolean tensors, one per ReLU of the forward in call order (conv outputs channels-last):
+    the forward then uses x * mask instead of relu(x) (vqdif_oracle.RELU_MASKS) - the activation pattern of ANOTHER
+    implementation's forward, so that both differentiate the same piecewise-linear function.  pool_index: likewise the selected
+    window element (0..7, channels-last) of every 2^3 max-pool (vqdif_oracle.POOL_INDEX)."""
     keys = trainable_keys(sd)
     leaf = dict(sd)
     for k in keys:
         leaf[k] = sd[k].clone().requires_grad_(True)
-    out = training_losses(leaf, Xbd, Xtg, Ytg, beta)
+    if relu_masks is not None:
+        VO.RELU_MASKS = [torch.as_tensor(m) for m in relu_masks]
+    if pool_index is not None:
+        VO.POOL_INDEX = [torch.as_tensor(m) for m in pool_index]
+    try:
+        out = training_losses(leaf, Xbd, Xtg, Ytg, beta)
+        assert not VO.RELU_MASKS, f"{len(VO.RELU_MASKS)} ReLU masks were not consumed"
+        assert not VO.POOL_INDEX, f"{len(VO.POOL_INDEX)} pool index tensors were not consumed"
+    finally:
+        VO.RELU_MASKS = VO.POOL_INDEX = None
     grads = torch.autograd.grad(out["loss"], [leaf[k] for k in keys], allow_unused=True)
     return out, {k: g for k, g in zip(keys, grads)}
 

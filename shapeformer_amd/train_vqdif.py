@@ -106,7 +106,14 @@ class VQDIFTrainer:
     def _relu(self, x):
         y = self._f(*x.shape)       # relu(x) == relu_bwd(dy = x, y = x)
         _ck(self.lib.sfmi_relu_bwd_f32(L.ptr(x), L.ptr(x), L.ptr(y), x.numel(), L.stream_ptr()), "relu")
+        self._tap_relu(y)
         return y
+
+    def _tap_relu(self, y):
+        """Debug tap (tests/test_train_vqdif_gpu.py): with `self.relu_tap = []` set, the activation pattern (y > 0) of every
+        ReLU of the forward is recorded in call order, for a frozen-mask gradient comparison against the oracle."""
+        if getattr(self, "relu_tap", None) is not None:
+            self.relu_tap.append((y > 0).cpu())
 
     def _relu_bwd(self, dy, y):
         dx = self._f(*dy.shape)
@@ -144,6 +151,8 @@ class VQDIFTrainer:
             Wk = torch.zeros(N, K, device=self.dev)
             Wk[:, :W.shape[1]] = W
         y = self._gemm(x, Wk, b, resid, M, N, K, act)
+        if act == 1:
+            self._tap_relu(y)
 
         def bwd(dy):
             if act == 1:
@@ -174,6 +183,8 @@ class VQDIFTrainer:
         y = self._f(B, Do, Do, Do, Cout)
         _ck(self.lib.sfmi_conv3d_cl_f32(L.ptr(x), L.ptr(w), None, None, L.ptr(self.p[bias]) if bias else None, L.ptr(y), B, Di, Di, Di,
                                         Cin, Cout, KS, stride, pad, 0, int(relu), L.stream_ptr()), "conv")
+        if relu:
+            self._tap_relu(y)
 
         def bwd(dy):
             if relu:
@@ -242,6 +253,10 @@ class VQDIFTrainer:
     def maxpool(self, x, B, Do, C):
         y = self._f(B, Do, Do, Do, C)
         _ck(self.lib.sfmi_maxpool2_cl_f32(L.ptr(x), L.ptr(y), B, Do, Do, Do, C, L.stream_ptr()), "maxpool")
+        if getattr(self, "pool_tap", None) is not None:   # debug tap: the selected window element (first maximum, 4 dz + 2 dy + dx)
+            win = x.view(B, Do, 2, Do, 2, Do, 2, C).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(B, Do, Do, Do, C, 8)
+            first = (win == y.unsqueeze(-1)).int() * torch.arange(8, 0, -1, device=self.dev, dtype=torch.int32)
+            self.pool_tap.append(first.argmax(-1).cpu())
 
         def bwd(dy):
             dx = self._f(*x.shape)
