@@ -1149,6 +1149,10 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   const int NWv = DG_FORCE_NW;
 #else
   int NWv = (kslice >= 2048 && M <= 64) ? 16 : 8;
+  // run-time tuning hooks (tools/sweep_dgemm.sh): waves per workgroup (4 / 8 / 16 k-parts) and k16-steps of loads in flight
+  static const int env_nw = getenv("SFMI_DGEMM_NW") ? atoi(getenv("SFMI_DGEMM_NW")) : 0;
+  static const int env_un = getenv("SFMI_DGEMM_UN") ? atoi(getenv("SFMI_DGEMM_UN")) : 0;
+  if ((env_nw == 4 || env_nw == 8 || env_nw == 16) && kslice % (16 * env_nw) == 0 && (M + 15) / 16 <= (env_nw == 4 ? 4 : 6)) NWv = env_nw;
   if (kslice % (16 * NWv)) NWv = kslice % 64 == 0 ? 4 : 1;   // narrow models (K-slice not a multiple of 128): fewer k-parts
 #endif
   if (kslice % (16 * NWv)) return SFMI_EINVAL;
@@ -1162,13 +1166,20 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 4 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave
 #ifdef DG_FORCE_UN
   un = DG_FORCE_UN;
+#else
+  if (env_un > 0) un = env_un;
 #endif
   while (un > 1 && steps % un) un >>= 1;
 #define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
 #define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
   if (NWv == 16) { if (MT == 1) DGU(1, 16); else if (MT == 2) DGU(2, 16); else if (MT == 3) DGU(3, 16); else DGU(4, 16); }
   // (the epilogue operands are prefetched for row tile == wave, so a narrow launch needs MT <= NW)
-  else if (NWv == 4) { if (MT == 1) DG(1, 4, 1); else if (MT == 2) DG(2, 4, 1); else if (MT == 3) DG(3, 4, 1); else if (MT == 4) DG(4, 4, 1); else return SFMI_EINVAL; }
+  else if (NWv == 4) {
+    if (MT == 1) DG(1, 4, 1); else if (MT == 2) DG(2, 4, 1);
+    else if (MT == 3) { if (un >= 2) DG(3, 4, 2); else DG(3, 4, 1); }
+    else if (MT == 4) { if (un >= 2) DG(4, 4, 2); else DG(4, 4, 1); }
+    else return SFMI_EINVAL;
+  }
   else if (NWv == 1) { if (MT == 1) DG(1, 1, 1); else return SFMI_EINVAL; }
   else if (MT <= 4) { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
   else if (MT == 5) DG(5, 8, 1);   // 65..96 rows: still the co-residency-friendly 8-wave kernel (<= 128 VGPRs)
