@@ -45,6 +45,9 @@ def parse():
                     help="complete: the shapes/s metric (default); train: DDP training step of the transformer (BASELINE config 5)")
     ap.add_argument("--share-device", action="store_true",
                     help="TEST ONLY: all ranks use cuda:0 and rendezvous over gloo (exercises the N-rank path on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="TEST ONLY: initialise the RCCL process group even for one rank (exercises init / barrier / all-reduce of the "
+                         "N-rank path on a 1-GPU box; run under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--train-batch", type=int, default=1, help="--mode train: sequences per GPU per step (shapenet_scale.yaml: 1)")
     ap.add_argument("--train-lc", type=int, default=200)
     ap.add_argument("--train-lz", type=int, default=300)
@@ -372,7 +375,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.share_device:

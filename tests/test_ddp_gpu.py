@@ -106,3 +106,22 @@ def test_bench_launches_its_own_ranks(dev):
     # and the guard: asking for more ranks than GPUs is an error, never a silent 1-rank run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "only" in (r.stdout + r.stderr)
+
+
+def test_bench_rccl_path_with_one_rank(dev):
+    """The RCCL calls of the N-rank bench path (init_process_group("nccl", device_id), barrier, all-reduce MAX of the step time)
+    on this 1-GPU box: one rank under torch.distributed.run with --force-dist.  Tiny workload; the value is not a measurement."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1",
+                        "--warmup", "0", "--batch", "4", "--ar-steps", "4", "--decode-res", "32", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and line[0]["n_gpus"] == 1 and line[0]["value"] > 0
