@@ -220,8 +220,13 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     for (int j = 0; j < MT; ++j) {
       const f32x4 xv = xs[j];
       // LayerNorm statistics (a few VALU ops; computed unconditionally, only used when a.ln)
-      s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
-      s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
+#ifdef DG_STATS_IF_LN   // ablation (tools/ubench/run_streams_ablation.sh): skip them in the launches without a fused LayerNorm
+      if (a.ln)
+#endif
+      {
+        s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
+        s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
         acc[j][e & 1] = DG_MFMA(wv[e], xv[e], acc[j][e & 1]);
@@ -1182,8 +1187,8 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   }
   else if (NWv == 1) { if (MT == 1) DG(1, 1, 1); else return SFMI_EINVAL; }
   else if (MT <= 4) { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
-  else if (MT == 5) DG(5, 8, 1);   // 65..96 rows: still the co-residency-friendly 8-wave kernel (<= 128 VGPRs)
-  else DG(6, 8, 1);
+  else if (MT == 5) { if (un >= 2) DG(5, 8, 2); else DG(5, 8, 1); }   // 65..96 rows: still the 8-wave kernel
+  else { if (un >= 2) DG(6, 8, 2); else DG(6, 8, 1); }
 #undef DGU
 #undef DG
   SFMI_CHECK_LAUNCH();
