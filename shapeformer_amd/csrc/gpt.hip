@@ -223,6 +223,9 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 #ifdef DG_STATS_IF_LN   // ablation (tools/ubench/run_streams_ablation.sh): skip them in the launches without a fused LayerNorm
       if (a.ln)
 #endif
+#ifdef DG_NO_STATS      // ablation: never (results of the LayerNorm-fused launches are then wrong; timing only)
+      if (false)
+#endif
       {
         s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
         s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
@@ -246,6 +249,15 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) mfma_step(w[u], xb[u]);
   }
+#ifdef DG_SKIP_EPI   // ablation: main loop only (one store per lane keeps the accumulators alive)
+  {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MT; ++j) t = t + acc[j][0] + acc[j][1];
+    if (t[0] == 1.2345f) a.out[tid] = t[1] + s1[0] + s2[0] + pc1[0] + pc2[0] + pres[0];
+    return;
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const f32x4 t = acc[j][0] + acc[j][1];
