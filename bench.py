@@ -115,7 +115,7 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
             ("dgemm fc1 (LN+1024->4096+GELU)", "pfc1", "c1fc1", "c2fc1", r, None, st["h"], 4 * D, D, 4 * D, 1, 1, 1),
             ("dgemm fc2 (4096->1024+resid)", "pfc2", None, "bfc2", st["h"], r, r, D, 4 * D, D, 0, 0, gpt.S_FC2),
             ("dgemm qkv (LN+1024->3072)", "pqkv", "c1qkv", "c2qkv", r, None, st["qkv"], 3 * D, D, 3 * D, 1, 0, 1),
-            ("dgemm proj (1024->1024+resid)", "pproj", None, "bproj", st["y"], r, r, D, D, D, 0, 0, gpt.S_PROJ if B <= 16 else 4)):
+            ("dgemm proj (1024->1024+resid)", "pproj", None, "bproj", st["y"], r, r, D, D, D, 0, 0, gpt.S_PROJ if B <= 16 else gpt.S_PROJ_M)):
         def body():
             for l in gpt.layers:
                 gpt._dgemm(xin, getattr(l, attr), getattr(l, c1a) if c1a else None, getattr(l, c2a), res, outb, B, N, K, ldo, ln, act, 1, S)

@@ -42,6 +42,10 @@ class _Layer:
 
 class CondTupleGPT:
     S_PROJ, S_FC2 = 1, 4   # in-kernel split-K of the N = n_embd GEMMs (64 n-tiles -> 256 workgroups)
+    S_PROJ_M = 1           # proj above 16 rows: with four chains in flight 1 beats 2 beats 4 (4.13 / 4.17 / 4.18 ms per step); fc2: 4 beats 2 and 8
+    import os as _os2
+    if _os2.environ.get("SFMI_SPLITK"):   # tuning hook: "proj,fc2" split-K of the 17..96-row decode step (tools/sweep_dgemm.sh)
+        S_PROJ_M, S_FC2 = (int(v) for v in _os2.environ["SFMI_SPLITK"].split(","))
     import os as _os
     # prefill GEMMs with at least this many rows go to the library sgemm; None (default): every GEMM is csrc/sgemm.hip
     PREFILL_ON_CHAIN_STREAMS = True   # tools/probe_chain_streams.py switches it off for the A/B
@@ -393,7 +397,7 @@ class CondTupleGPT:
         if "@" in skip:      # per-chain form "gemm@0,attn@1,attn@2": chain index = micro-batch slot
             skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
         # in-kernel split-K per GEMM: 64-row kernel (B <= 64) / wide kernel (one launch for up to 256 rows)
-        Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if (B > 96 or self._force_wide) else (1, self.S_PROJ if B <= 16 else 4, 1, self.S_FC2, 1)
+        Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if (B > 96 or self._force_wide) else (1, self.S_PROJ if B <= 16 else self.S_PROJ_M, 1, self.S_FC2, 1)
         for li, ly in enumerate(self.layers):
             if "gemm" not in skip:
                 self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
