@@ -187,15 +187,18 @@ template <int MT, int NW, int UN>
 __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float red[NW][MT][4][64];
   __shared__ float st1[NW][MT][16], st2[NW][MT][16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, ml = lane & 15;
   const int nt = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
   const int kslice = a.K / S;
   const int kw = kslice / NW;
   const int k0 = sp * kslice + wave * kw;
-  const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)nt * (a.K / 16) + k0 / 16) * 64 + lane;
+  // operand addresses = wave-uniform base (scalar registers) + one 32-bit per-lane offset: the six activation pointers of a
+  // 96-row launch would otherwise cost 12 vector registers, the difference between one and two resident workgroups
+  const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)nt * (a.K / 16) + k0 / 16) * 64;
   const f32x4* xr[MT];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) xr[j] = reinterpret_cast<const f32x4*>(a.x) + ((long long)j * (a.K / 16) + k0 / 16) * 64 + lane;
+  for (int j = 0; j < MT; ++j) xr[j] = reinterpret_cast<const f32x4*>(a.x) + ((long long)j * (a.K / 16) + k0 / 16) * 64;
+  const unsigned lo = (unsigned)lane;
   f32x4 acc[MT][2];
   float s1[MT], s2[MT];
 #pragma unroll
@@ -241,9 +244,9 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     f32x4 w[UN], xb[UN][MT];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      w[u] = DG_WLOAD(wp + (s0 + u) * 64);
+      w[u] = DG_WLOAD(wp + (s0 + u) * 64 + lo);
 #pragma unroll
-      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][XIDX((s0 + u) * 64)];
+      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][XIDX((s0 + u) * 64) + lo];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1180,7 +1183,7 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   dim3 grid((N + 15) / 16, S);
   const int MT = (M + 15) / 16;
   const int steps = kslice / NWv / 16;
-  int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 4 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave
+  int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 5 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave (5 row tiles: 128 VGPRs; 6: 138 with two)
 #ifdef DG_FORCE_UN
   un = DG_FORCE_UN;
 #else

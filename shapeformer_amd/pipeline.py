@@ -13,11 +13,12 @@ from . import tokens as T
 
 
 def default_chains(B):
-    """Number of interleaved hipGraph decode chains (gpt.py:sample_microbatched) for B rows: <= 64 rows per chain, 2 chains
-    already for 32..64 rows, and 4 chains from 192 rows on (4 x 48 rows: 4.19 ms/step against 4.29 for 3 x 64 - one chain per
-    hardware queue; more queues than 4 (GPU_MAX_HW_QUEUES=8) or 6 chains are slower, profiles/r02_decode_step_experiments.md)."""
+    """Number of interleaved hipGraph decode chains (gpt.py:sample_microbatched) for B rows: <= 64 rows per chain below 192 rows
+    (2 chains already for 32..64 rows); from 192 rows on FOUR chains - one per hardware queue of the runtime (more queues than 4,
+    GPU_MAX_HW_QUEUES=8, or 6 chains are slower; profiles/r02_decode_step_experiments.md).  4 x 48 rows: 4.19 ms/step against 4.29
+    for 3 x 64; 4 x 80 rows (320 shapes) is the best rows-per-launch trade measured: 78.8 shapes/s against 76.0 at 192."""
     if B >= 192:
-        return max(-(-B // 64), 4)
+        return max(4, -(-B // 256))     # a chain holds up to 256 rows
     return -(-B // 64) if B > 64 else (2 if B >= 32 else 1)
 
 
