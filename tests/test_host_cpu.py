@@ -174,3 +174,71 @@ def test_reference_dotted_paths_become_importable():
         "print('OK')\n") % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr
+
+
+def test_default_chain_count_rule():
+    """pipeline.default_chains: <= 64 rows per chain below 192 rows, four chains (one per hardware queue) from 192 rows on."""
+    from shapeformer_amd.pipeline import default_chains
+    assert [default_chains(b) for b in (1, 16, 31, 32, 64, 65, 128, 191)] == [1, 1, 1, 2, 2, 2, 2, 3]
+    assert [default_chains(b) for b in (192, 256, 320, 384, 1024)] == [4, 4, 4, 4, 4]
+    assert default_chains(1025) == 5                                     # a chain holds at most 256 rows
+    for b in (192, 320, 1024, 2000):
+        assert -(-b // default_chains(b)) <= 256
+
+
+def test_bench_refuses_inconsistent_rank_environment(monkeypatch):
+    """bench.launch_ranks: a WORLD_SIZE that disagrees with --gpus is an error, never a silent 1-rank run (no GPU needed)."""
+    import argparse
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(argparse.Namespace(gpus=2, share_device=False))
+    assert "WORLD_SIZE=4" in str(e.value)
+    bench.launch_ranks(argparse.Namespace(gpus=4, share_device=False))   # consistent: returns (we are a torchrun rank)
+    monkeypatch.delenv("WORLD_SIZE")
+    bench.launch_ranks(argparse.Namespace(gpus=1, share_device=False))   # one rank: nothing to launch
+    with pytest.raises(SystemExit) as e:                                 # this container has no GPU at all
+        bench.launch_ranks(argparse.Namespace(gpus=2, share_device=False))
+    assert "only 0 GPU" in str(e.value)
+
+
+def test_oracle_frozen_branch_hooks_reproduce_the_natural_forward():
+    """oracle.vqdif_oracle.RELU_MASKS / POOL_INDEX (the frozen-branch gradient comparison of tests/test_train_vqdif_gpu.py): with
+    the masks / selections of the oracle's OWN forward installed, the UNet gives the same output and input gradient."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import vqdif_oracle as VO
+    from shapeformer_amd import weights as W
+    sd = VO.to_torch_sd(W.make_state_dict(W.vqdif_spec(16)))
+    x = torch.randn(1, 128, 8, 8, 8)
+    rec_m, rec_p = [], []
+    relu0, pool0 = VO._relu, VO._max_pool2
+
+    def relu_tap(t):
+        y = F.relu(t)
+        rec_m.append((y > 0).permute(0, 2, 3, 4, 1).contiguous() if t.dim() == 5 else (y > 0))
+        return y
+
+    def pool_tap(t):
+        y, ind = F.max_pool3d(t, 2, return_indices=True)
+        D = t.shape[-1]
+        k = ((ind // (D * D)) % 2) * 4 + (((ind // D) % D) % 2) * 2 + (ind % D) % 2
+        rec_p.append(k.permute(0, 2, 3, 4, 1).contiguous())
+        return y
+    VO._relu, VO._max_pool2 = relu_tap, pool_tap
+    try:
+        xa = x.clone().requires_grad_(True)
+        ya = VO.unet3d(sd, xa)
+        ga, = torch.autograd.grad(ya.square().sum(), xa)
+    finally:
+        VO._relu, VO._max_pool2 = relu0, pool0
+    assert len(rec_m) == 10 and len(rec_p) == 2
+    VO.RELU_MASKS, VO.POOL_INDEX = list(rec_m), list(rec_p)
+    try:
+        xb = x.clone().requires_grad_(True)
+        yb = VO.unet3d(sd, xb)
+        gb, = torch.autograd.grad(yb.square().sum(), xb)
+        assert not VO.RELU_MASKS and not VO.POOL_INDEX
+    finally:
+        VO.RELU_MASKS = VO.POOL_INDEX = None
+    assert torch.equal(ya, yb) and torch.allclose(ga, gb, rtol=0, atol=1e-6 * float(ga.abs().max()))
