@@ -10,8 +10,9 @@
 //   * nearest x2 upsampling is an address shift (>>1) on the input coordinate, never materialised;
 //   * bias / ReLU in the epilogue.
 // GEMM view: D[co][voxel] = sum_{tap,cin} W[tap][co][cin] * X[voxel+tap][cin]; A = weights, B = activations,
-// 32x32x2 f32 MFMA (exact f32).  Workgroup = 4 waves, LDS double-buffered K-chunks of 16 input channels,
-// global->register prefetch of chunk c+1 overlapped with the MFMAs of chunk c, one barrier per chunk.
+// 32x32x2 f32 MFMA (exact f32).  Workgroup = 4 waves, LDS double-buffered K-chunks of 16 input channels, two register sets
+// (the global loads of chunk c+2 are in flight during the MFMAs of chunk c), one barrier per chunk; the tap walk and the bounds
+// tests are wave-uniform scalars + per-voxel bit masks, the GroupNorm affine is applied when a register set is written to LDS.
 #include "sfmi_common.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
