@@ -476,13 +476,11 @@ def main():
             if not a.no_kernels:
                 split = {}
                 for fam in ("gemm", "attn"):
-                    os.environ["SFMI_DECODE_SKIP"] = fam
-                    gpt._graphs = {}
+                    gpt._ablate = fam          # timing-only ablation (part of the graph cache key)
                     t2 = {}
                     step(a.warmup + a.steps + 1, timings=t2)
                     split[fam] = t2["ar_loop"] / a.ar_steps
-                os.environ.pop("SFMI_DECODE_SKIP", None)
-                gpt._graphs = {}
+                gpt._ablate = ""
                 flops_step = 2.0 * B * (w_one / 4.0)
                 line["ar_loop"]["attention_only_ms_per_step"] = round(split["gemm"], 3)
                 line["ar_loop"]["attention_only_KV_TBps"] = round(kv_bytes / split["gemm"] / 1e9, 3)

@@ -10,7 +10,7 @@
  *   - all pointers are DEVICE pointers unless the function is marked [host];
  *   - `stream` is a hipStream_t (passed as void*); launches are asynchronous on it, no internal sync;
  *   - returns 0 on success, a negative SFMI_E* code for bad arguments, or a positive hipError_t;
- *   - no global mutable state (apart from immutable, once-initialised tables: the rocBLAS function pointers and one
+ *   - no global mutable state (apart from the launch-shape knobs of sfmi_tune_set and immutable, once-initialised tables: the rocBLAS function pointers and one
  *     rocblas_handle per host thread, csrc/blas.hip); re-entrant for distinct streams and buffers;
  *   - layouts: feature grids are channels-last (B,D,H,W,C) f32; token buffers are int32; decode activations of the
  *     transformer are "fragment-packed" [ceil(M/16)][N/16][64][4] (see sfmi_decode_gemm_f32).
@@ -30,6 +30,11 @@ int sfmi_version(void);
 /* one wavefront busy for `ticks` of the 100 MHz wall clock (<= 1 s) on `stream`: the stream-concurrency probe of the interleaved
  * decode chains (no reference counterpart: the reference runs one chain on one stream, shapeformer.py:85-132) */
 int sfmi_stream_spin(long long ticks, void* stream);
+/* [host] launch-shape tuning knobs of the decode step (performance only - no knob changes a result bit unless its comment in
+ * csrc/gpt.hip says so); read at launch time, so a captured hipGraph keeps the values it was captured with.  No reference
+ * counterpart.  sfmi_tune_get returns -1 for an unknown name. */
+int sfmi_tune_set(const char* name, int value);
+int sfmi_tune_get(const char* name);
 
 /* ---- VQDIF encoder, per-point path: enc.py:95-140 (LocalPoolPointnet.forward up to scatter_mean), layers.py:39-48,
  *      vqdif/common.py:260-321, torch_scatter.scatter_max / scatter_mean call sites enc.py:70-74,103-110 ---------- */

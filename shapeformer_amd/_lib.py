@@ -21,6 +21,8 @@ i32, i64, sz, f32 = C.c_int, C.c_longlong, C.c_size_t, C.c_float
 PROTOTYPES = {
     "sfmi_version": (i32, []),
     "sfmi_stream_spin": (i32, [i64, c_ptr]),
+    "sfmi_tune_set": (i32, [C.c_char_p, i32]),
+    "sfmi_tune_get": (i32, [C.c_char_p]),
     # SDF query
     "sfmi_relu_bwd_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_lincomb_f32": (i32, [f32, c_ptr, f32, c_ptr, c_ptr, i64, c_ptr]),

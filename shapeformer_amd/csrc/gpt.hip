@@ -16,6 +16,8 @@
 //             top-p cut, counter-hash uniforms (no host RNG, no per-step D2H of (B,4097) logits)
 #include "sfmi_common.h"
 #include <stdlib.h>
+#include <mutex>
+#include <string>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -546,123 +548,151 @@ __global__ __launch_bounds__(256) void dgemm_wide_kernel(DGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode attention: grid (B, H), 1024 threads (16 waves); head dim HD <= 64, multiple of 4.
+// decode attention: one work item per (row, head), NWV waves per workgroup; head dim HD <= 64, multiple of 4.
 // KV cache layout is (B, H, Lmax, HD): one (row, head)'s keys are CONTIGUOUS, so a wave-instruction reads
-// 4 keys x 256 B = 1 KiB coalesced; 16 lanes share a key (float4 each), 4 independent loads are in
-// flight per lane (unrolled), all 16 waves of the workgroup stream disjoint keys.
+// 4 keys x 256 B = 1 KiB coalesced; 16 lanes share a key (float4 each), U independent loads are in
+// flight per lane (unrolled), all waves of the workgroup stream disjoint keys.  A lane meets its keys in
+// ascending order whatever U is, so U changes the loads in flight, never the result.
+// The launch is either one workgroup per item (grid = B*H, item = row + B*head: the block -> XCD map of a
+// (B, H) grid) or PERSISTENT: a fixed number of workgroups stride over the items, so that the whole grid is
+// dispatched in one round and workgroups of OTHER kernels (the decode GEMMs of the other chains) can be
+// placed beside it for its whole duration (profiles/r03_ar_overlap.md).
 // ------------------------------------------------------------------------------------------------
-#define ATT_WAVES 16
-__global__ __launch_bounds__(1024) void attn_decode_kernel(const float* __restrict__ qkv_part /*packed (M x 3D) q|k|v*/,
-                                                           const float* __restrict__ bqkv /*unused*/, float* __restrict__ Kc,
-                                                           float* __restrict__ Vc /*(B,H,Lmax,HD)*/, const int* __restrict__ len,
-                                                           float* __restrict__ y /*(M,D)*/, int S, int M, int D, int Lmax,
-                                                           int HD, float scale, const int* __restrict__ shared_len) {
-  __shared__ __attribute__((aligned(16))) float qs[64], kn[64], vn[64], sc[1024], red[2 * ATT_WAVES], yacc[ATT_WAVES][64];
-  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = len[b] - 1;  // position being processed
+struct AttnArgs {
+  const float* qkv;      // fragment-packed (M x 3D) q|k|v of the fused LN+QKV GEMM (bias included)
+  float* Kc; float* Vc;  // (B,H,Lmax,HD)
+  const int* len; float* y /*fragment-packed (M x D)*/;
+  const int* shared_len;
+  int B, H, D, Lmax, HD; float scale;
+};
+template <int NWV>
+struct AttnLds {
+  __attribute__((aligned(16))) float qs[64];
+  __attribute__((aligned(16))) float kn[64];
+  __attribute__((aligned(16))) float vn[64];
+  __attribute__((aligned(16))) float sc[1024];
+  float red[2 * NWV];
+  __attribute__((aligned(16))) float yacc[NWV][64];
+};
+
+template <int NWV, int U>
+__device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs& a, const int b, const int h) {
+  constexpr int KB = NWV * 4 * U;   // keys per batch of loads
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, HD = a.HD, D = a.D, Lmax = a.Lmax;
+  const int t = __builtin_amdgcn_readfirstlane(a.len[b] - 1);  // position being processed
   const int nq4 = HD / 4;
-  float* Kb = Kc + ((long long)b * H + h) * Lmax * HD;
-  float* Vb = Vc + ((long long)b * H + h) * Lmax * HD;
+  float* Kb = a.Kc + ((long long)b * H + h) * Lmax * HD;
+  float* Vb = a.Vc + ((long long)b * H + h) * Lmax * HD;
   // shared prefix (sample_n copies of ONE condition, shapeformer.py:222-260): keys / values of positions < shared_len[0] were
   // written once, by row 0's prefill, and every row reads them from row 0's cache (one HBM read, L2 / Infinity-Cache hits
   // for the other rows); a row's own cache holds its tail only
-  const int nshared = shared_len ? shared_len[0] : 0;
-  const float* Kb0 = Kc + (long long)h * Lmax * HD;
-  const float* Vb0 = Vc + (long long)h * Lmax * HD;
+  const int nshared = a.shared_len ? a.shared_len[0] : 0;
+  const float* Kb0 = a.Kc + (long long)h * Lmax * HD;
+  const float* Vb0 = a.Vc + (long long)h * Lmax * HD;
   const int c4 = lane & 15, kk = lane >> 4;
   const bool cok = c4 < nq4;
-  // the first 256 keys' loads are issued BEFORE the q/k/v hand-off barrier (they only need `t`): the HBM latency of the
+  // the first batch of keys is requested BEFORE the q/k/v hand-off barrier (the loads only need `t`): the HBM latency of the
   // first batch overlaps the LDS round trip instead of following it
-  auto load_k = [&](int i0, f32x4 (&kf)[4]) {
+  auto load_k = [&](int i0, f32x4 (&kf)[U]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 64 + wave * 4 + kk;
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
       kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Kb0 : Kb) + (long long)i * HD + 4 * c4));
     }
   };
-  f32x4 kf0[4];
+  f32x4 kf0[U];
   load_k(0, kf0);
   if (tid < HD) {
-    // qkv is the fragment-packed (M x 3D) output of the fused LN+QKV GEMM (bias already included)
-    const float q = qkv_part[pk_off(b, h * HD + tid, 3 * D)];
-    const float k = qkv_part[pk_off(b, D + h * HD + tid, 3 * D)];
-    const float v = qkv_part[pk_off(b, 2 * D + h * HD + tid, 3 * D)];
-    qs[tid] = q * scale; kn[tid] = k; vn[tid] = v;
+    const float q = a.qkv[pk_off(b, h * HD + tid, 3 * D)];
+    const float k = a.qkv[pk_off(b, D + h * HD + tid, 3 * D)];
+    const float v = a.qkv[pk_off(b, 2 * D + h * HD + tid, 3 * D)];
+    s.qs[tid] = q * a.scale; s.kn[tid] = k; s.vn[tid] = v;
     Kb[(long long)t * HD + tid] = k;
     Vb[(long long)t * HD + tid] = v;
   }
   __syncthreads();
   f32x4 qf = {0.f, 0.f, 0.f, 0.f};
-  if (cok) qf = *reinterpret_cast<const f32x4*>(qs + 4 * c4);
+  if (cok) qf = *reinterpret_cast<const f32x4*>(s.qs + 4 * c4);
   float lmax = -INFINITY;
-  // keys i = it*64 + wave*4 + kk ; 4 iterations in flight
-  auto score = [&](int i0, f32x4 (&kf)[4]) {
+  auto score = [&](int i0, f32x4 (&kf)[U]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 64 + wave * 4 + kk;
-      if (i == t && cok) kf[u] = *reinterpret_cast<const f32x4*>(kn + 4 * c4);     // the new token's key comes from LDS
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
+      if (i == t && cok) kf[u] = *reinterpret_cast<const f32x4*>(s.kn + 4 * c4);     // the new token's key comes from LDS
       float d = (qf[0] * kf[u][0] + qf[1] * kf[u][1]) + (qf[2] * kf[u][2] + qf[3] * kf[u][3]);
       d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
       if (i <= t) {
-        if (c4 == 0) sc[i] = d;
+        if (c4 == 0) s.sc[i] = d;
         lmax = fmaxf(lmax, d);
       }
     }
   };
   score(0, kf0);
-  for (int i0 = 256; i0 <= t; i0 += 256) {
-    f32x4 kf[4];
+  for (int i0 = KB; i0 <= t; i0 += KB) {
+    f32x4 kf[U];
     load_k(i0, kf);
     score(i0, kf);
   }
-  // same for the values: the first 256 rows are requested before the softmax barrier
-  auto load_v = [&](int i0, f32x4 (&vf)[4]) {
+  // same for the values: the first batch is requested before the softmax barrier
+  auto load_v = [&](int i0, f32x4 (&vf)[U]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 64 + wave * 4 + kk;
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
       vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Vb0 : Vb) + (long long)i * HD + 4 * c4));
     }
   };
-  f32x4 vf0[4];
+  f32x4 vf0[U];
   load_v(0, vf0);
   lmax = wave_max(lmax);
-  if (lane == 0) red[wave] = lmax;
+  if (lane == 0) s.red[wave] = lmax;
   __syncthreads();
-  float gmax = red[0];
+  float gmax = s.red[0];
 #pragma unroll
-  for (int w = 1; w < ATT_WAVES; ++w) gmax = fmaxf(gmax, red[w]);
+  for (int w = 1; w < NWV; ++w) gmax = fmaxf(gmax, s.red[w]);
   // y = sum_i p_i V[i], p_i = exp(s_i - gmax); the 1/sum is applied at the end
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float ls = 0.f;
-  auto accum = [&](int i0, f32x4 (&vf)[4]) {
+  auto accum = [&](int i0, f32x4 (&vf)[U]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 64 + wave * 4 + kk;
-      if (i == t && cok) vf[u] = *reinterpret_cast<const f32x4*>(vn + 4 * c4);
-      const float pr = i <= t ? __expf(sc[i] - gmax) : 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
+      if (i == t && cok) vf[u] = *reinterpret_cast<const f32x4*>(s.vn + 4 * c4);
+      const float pr = i <= t ? __expf(s.sc[i] - gmax) : 0.f;
       acc = acc + vf[u] * pr;
       ls += pr;
     }
   };
   accum(0, vf0);
-  for (int i0 = 256; i0 <= t; i0 += 256) {
-    f32x4 vf[4];
+  for (int i0 = KB; i0 <= t; i0 += KB) {
+    f32x4 vf[U];
     load_v(i0, vf);
     accum(i0, vf);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) { acc[e] += __shfl_xor(acc[e], 16, 64); acc[e] += __shfl_xor(acc[e], 32, 64); }
   ls += __shfl_xor(ls, 16, 64); ls += __shfl_xor(ls, 32, 64);  // every c4 lane holds the wave's sum over its kk keys
-  if (kk == 0 && cok) *reinterpret_cast<f32x4*>(&yacc[wave][4 * c4]) = acc;
-  if (lane == 0) red[ATT_WAVES + wave] = ls;
+  if (kk == 0 && cok) *reinterpret_cast<f32x4*>(&s.yacc[wave][4 * c4]) = acc;
+  if (lane == 0) s.red[NWV + wave] = ls;
   __syncthreads();
   if (tid < HD) {
     float o = 0.f, l = 0.f;
 #pragma unroll
-    for (int w = 0; w < ATT_WAVES; ++w) { o += yacc[w][tid]; l += red[ATT_WAVES + w]; }
-    y[pk_off(b, h * HD + tid, D)] = o / l;   // fragment-packed (M x D)
+    for (int w = 0; w < NWV; ++w) { o += s.yacc[w][tid]; l += s.red[NWV + w]; }
+    a.y[pk_off(b, h * HD + tid, D)] = o / l;   // fragment-packed (M x D)
+  }
+}
+
+template <int NWV, int U>
+__global__ __launch_bounds__(64 * NWV, U == 4 ? 8 : 4) void attn_decode_kernel(AttnArgs a) {   // U = 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128
+  __shared__ AttnLds<NWV> s;
+  const int nitems = a.B * a.H;
+  for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const int h = __builtin_amdgcn_readfirstlane(it / a.B);   // wave-uniform: keeps the cache bases in scalar registers
+    attn_decode_item<NWV, U>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
+    if (it + (int)gridDim.x < nitems) __syncthreads();   // the next item rewrites the hand-off tiles
   }
 }
 
@@ -1244,13 +1274,57 @@ int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* 
   return SFMI_OK;
 }
 
+// tuning hooks (performance only: none of them changes a result bit).  Set through sfmi_tune_set(name, value) by bench.py /
+// tools/ar_sweep.py; read at LAUNCH time, i.e. baked into a captured hipGraph (re-capture after changing one).
+//   attn_blocks : 0 = one workgroup per (row, head) item; n > 0 = persistent grid of n workgroups striding over the items
+//   attn_unroll : float4 loads in flight per lane (4 or 8)
+//   attn_waves  : 16 or 8 waves per workgroup (NOT bit-identical to each other: different summation order)
+//   attn_lds_pad: extra dynamic LDS bytes per workgroup (caps resident workgroups per CU)
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad; };
+static SfmiTune g_tune = {0, 4, 16, 0};
+int sfmi_tune_set(const char* name, int value) {
+  if (!name) return SFMI_EINVAL;
+  const std::string n(name);
+  if (n == "attn_blocks" && value >= 0) g_tune.attn_blocks = value;
+  else if (n == "attn_unroll" && (value == 4 || value == 8)) g_tune.attn_unroll = value;
+  else if (n == "attn_waves" && (value == 8 || value == 16)) g_tune.attn_waves = value;
+  else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) g_tune.attn_lds_pad = value;
+  else return SFMI_EINVAL;
+  return SFMI_OK;
+}
+int sfmi_tune_get(const char* name) {
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "attn_blocks") return g_tune.attn_blocks;
+  if (n == "attn_unroll") return g_tune.attn_unroll;
+  if (n == "attn_waves") return g_tune.attn_waves;
+  if (n == "attn_lds_pad") return g_tune.attn_lds_pad;
+  return -1;
+}
+
 // replaces CausalSelfAttention.forward for ONE new position per row with a KV cache (mingpt.py:73-91)
 int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc, float* Vc, const int* len, float* y,
                              int S, int B, int D, int H, int Lmax, const int* shared_len, void* stream) {
   if (!qkv_part || !bqkv || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
-  const int HD = D / H;
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(B, H), dim3(1024), 0, (hipStream_t)stream, qkv_part, bqkv, Kc, Vc, len, y, S, B, D,
-                     Lmax, HD, 1.0f / sqrtf((float)HD), shared_len);
+  AttnArgs a;
+  a.qkv = qkv_part; a.Kc = Kc; a.Vc = Vc; a.len = len; a.y = y; a.shared_len = shared_len;
+  a.B = B; a.H = H; a.D = D; a.Lmax = Lmax; a.HD = D / H; a.scale = 1.0f / sqrtf((float)a.HD);
+  const int nitems = B * H;
+  const int grid = g_tune.attn_blocks > 0 ? min(g_tune.attn_blocks, nitems) : nitems;
+  const size_t pad = (size_t)g_tune.attn_lds_pad;
+  hipStream_t st = (hipStream_t)stream;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {   // the occupancy-cap experiments ask for more dynamic LDS than the 64 KB default
+#define AT_ATTR(W_, U_) do { hipError_t e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; } while (0)
+    AT_ATTR(16, 4); AT_ATTR(16, 8); AT_ATTR(8, 4); AT_ATTR(8, 8);
+#undef AT_ATTR
+  });
+  if (pad && attr_err != hipSuccess) return (int)attr_err;
+#define AT(W_, U_) hipLaunchKernelGGL((attn_decode_kernel<W_, U_>), dim3(grid), dim3(64 * W_), pad, st, a)
+  if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else AT(16, 4); }
+  else { if (g_tune.attn_unroll == 8) AT(8, 8); else AT(8, 4); }
+#undef AT
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

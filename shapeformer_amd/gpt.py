@@ -43,13 +43,12 @@ class _Layer:
 class CondTupleGPT:
     S_PROJ, S_FC2 = 1, 4   # in-kernel split-K of the N = n_embd GEMMs (64 n-tiles -> 256 workgroups)
     S_PROJ_M = 1           # proj above 16 rows: with four chains in flight 1 beats 2 beats 4 (4.13 / 4.17 / 4.18 ms per step); fc2: 4 beats 2 and 8
-    import os as _os2
-    if _os2.environ.get("SFMI_SPLITK"):   # tuning hook: "proj,fc2" split-K of the 17..96-row decode step (tools/sweep_dgemm.sh)
-        S_PROJ_M, S_FC2 = (int(v) for v in _os2.environ["SFMI_SPLITK"].split(","))
-    import os as _os
-    # prefill GEMMs with at least this many rows go to the library sgemm; None (default): every GEMM is csrc/sgemm.hip
     PREFILL_ON_CHAIN_STREAMS = True   # tools/probe_chain_streams.py switches it off for the A/B
-    PREFILL_BLAS_ROWS = 2048 if _os.environ.get("SFMI_ROCBLAS") == "1" else None
+    # prefill GEMMs with at least this many rows go to the library sgemm; None (default): every GEMM is csrc/sgemm.hip
+    PREFILL_BLAS_ROWS = 2048 if os.environ.get("SFMI_ROCBLAS") == "1" else None
+    # True: the plain GEMMs of the prefill / teacher-forced forward run on the r1 tile kernel (csrc/conv3d.hip:sfmi_gemm_f32)
+    # instead of csrc/sgemm.hip - the alternative in-tree implementation, kept as a cross-check (tests/test_gpt_fullsize_gpu.py)
+    PREFILL_TILE_KERNEL = False
 
     def _blas(self):
         if not hasattr(self, "_has_blas"):
@@ -72,8 +71,12 @@ class CondTupleGPT:
         self.load_state_dict(sd)
         self._state = None
         self._states, self._graphs = {}, {}
-        import os
-        self._force_wide = os.environ.get("SFMI_DGEMM_WIDE") == "1"     # tuning hook: two-n-tiles-per-wave kernel for 17..96 rows too
+        # debug / measurement hooks, set explicitly by bench.py and tools/ (never read from the environment on the product path):
+        #   _force_wide : two-n-tiles-per-wave decode GEMM for 17..96 rows too (tools/sweep_dgemm.sh)
+        #   _ablate     : TIMING-ONLY ablation of decode_step, "gemm" / "attn" / "gemm@0,attn@1" (per chain): the named kernel
+        #                 family is not launched, sampled tokens are garbage; part of the hipGraph cache key
+        self._force_wide = False
+        self._ablate = ""
 
     def get_block_size(self):
         return self.Lmax
@@ -241,7 +244,7 @@ class CondTupleGPT:
                 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
             L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
             return
-        if not og and N % 4 == 0 and K % 4 == 0:
+        if not og and N % 4 == 0 and K % 4 == 0 and not self.PREFILL_TILE_KERNEL:
             L.check(L.lib().sfmi_sgemm_mfma_f32(0, 1, M, N, K, L.ptr(x), K, L.ptr(w), K, L.ptr(y), N, 0, L.ptr(bias), act, L.ptr(resid),
                                                 None, 0, 0.0, 0, L.stream_ptr()), "sfmi_sgemm_mfma_f32")
             return
@@ -392,8 +395,7 @@ class CondTupleGPT:
         D = self.D
         lib = L.lib()
         r = st["resid"]
-        import os
-        skip = os.environ.get("SFMI_DECODE_SKIP", "")   # timing ablation hook (tools/sweep_dgemm.sh): results are garbage
+        skip = self._ablate                               # timing-only ablation hook (see __init__): results are garbage
         if "@" in skip:      # per-chain form "gemm@0,attn@1,attn@2": chain index = micro-batch slot
             skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
         # in-kernel split-K per GEMM: 64-row kernel (B <= 64) / wide kernel (one launch for up to 256 rows)
@@ -481,7 +483,8 @@ class CondTupleGPT:
                 "sfmi_gpt_embed_packed_f32")
         graph = None
         if use_graph and steps > 1:
-            gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force", "seed"))), return_logits)
+            gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force", "seed"))), return_logits,
+                    self._ablate, self._force_wide, self.S_PROJ, self.S_PROJ_M, self.S_FC2)
             cached = self._graphs.get(slot)
             if cached is None or cached[0] != gkey or return_logits:
                 side = torch.cuda.Stream(device=self.dev)

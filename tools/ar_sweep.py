@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""AR-loop-only A/B of decode-step launch shapes on ONE process (model built once): for each configuration line the decode
+graphs are re-captured and the 512-step loop of `--rows` synthetic sequences (`--chains` interleaved hipGraph chains) is timed
+with HIP events, optionally with one kernel family disabled (timing-only ablation, gpt._ablate).
+
+    python tools/ar_sweep.py --out gpurun_out/r3/ar_sweep.txt [--rows 320 --chains 4] < configs
+
+A configuration line is `name key=value ...`; keys: the sfmi_tune_set knobs (attn_blocks, attn_unroll, attn_waves,
+attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `fused=0|1` (gpt.FUSED_SLOTS).  Lines starting with # are skipped.
+Condition lengths are uniform in [100, 216] (mean 158 = the bench's synthetic clouds); positions ascending, end-token closed.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def synth_cond(seed, B, lo=100, hi=216, Lpad=406):
+    rs = np.random.RandomState(seed)
+    tok = np.full((B, Lpad, 2), 4096, np.int32)
+    Lc = rs.randint(lo, hi + 1, B).astype(np.int32)
+    for b in range(B):
+        n = Lc[b] - 1
+        tok[b, :n, 0] = np.sort(rs.choice(4096, n, replace=False))
+        tok[b, :n, 1] = rs.randint(0, 4096, n)
+    return torch.from_numpy(tok), torch.from_numpy(Lc)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/r3/ar_sweep.txt")
+    ap.add_argument("--rows", type=int, default=320)
+    ap.add_argument("--chains", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=1)
+    a = ap.parse_args()
+    from shapeformer_amd import _lib as L
+    from shapeformer_amd.gpt import CondTupleGPT
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+    gpt = CondTupleGPT(device=dev)
+    lib = L.lib()
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    out = open(a.out, "a")
+
+    def say(s):
+        print(s, flush=True)
+        out.write(s + "\n"); out.flush()
+    say(f"# ar_sweep: model built in {time.time() - t0:.1f}s; default rows {a.rows} chains {a.chains} steps {a.steps}")
+    defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad")}
+    cache = {}
+    for line in sys.stdin:
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        name, *kvs = line.split()
+        kv = dict(x.split("=", 1) for x in kvs)
+        rows, chains = int(kv.pop("rows", a.rows)), int(kv.pop("chains", a.chains))
+        gpt._ablate = kv.pop("ablate", "")
+        if hasattr(gpt, "FUSED_SLOTS"):
+            gpt.FUSED_SLOTS = bool(int(kv.pop("fused", "0")))
+        for k, v in defaults.items():
+            L.check(lib.sfmi_tune_set(k.encode(), int(kv.pop(k, v))), f"tune {k}")
+        for k, v in kv.items():
+            L.check(lib.sfmi_tune_set(k.encode(), int(v)), f"tune {k}")
+        gpt._graphs = {}
+        if rows not in cache:
+            cache[rows] = synth_cond(7, rows)
+        tok, Lc = cache[rows]
+        ms = []
+        try:
+            for rep in range(a.reps + 1):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                kw = dict(max_steps=a.steps, stop_early=False, seed=rep, after_prefill=lambda: ev[0].record())
+                if chains > 1:
+                    r = gpt.sample_microbatched(tok, Lc, n_micro=chains, **kw)
+                else:
+                    r = gpt.sample(tok, Lc, to_host=False, **kw)
+                ev[1].record()
+                torch.cuda.synchronize()
+                assert int(r["steps"]) == a.steps
+                if rep:
+                    ms.append(ev[0].elapsed_time(ev[1]) / a.steps)
+            say(f"{name:28s} rows {rows} chains {chains} ablate '{gpt._ablate}' {' '.join(kvs):40s} ms/step " + " ".join(f"{m:.3f}" for m in ms)
+                + f"   rows/ms {rows / min(ms):.1f}")
+        except Exception as e:   # keep sweeping
+            say(f"{name:28s} FAILED: {type(e).__name__}: {e}")
+            torch.cuda.synchronize()
+    gpt._ablate = ""
+
+
+if __name__ == "__main__":
+    main()
