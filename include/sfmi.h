@@ -24,6 +24,7 @@ extern "C" {
 
 #define SFMI_OK 0
 #define SFMI_EINVAL (-1)
+#define SFMI_ELDS (-4)    /* hipFuncSetAttribute refused the dynamic-LDS size a kernel needs (csrc/sgemm.hip: 73.7 KB) */
 #define SFMI_ENOBLAS (-3) /* rocBLAS could not be bound (csrc/blas.hip); callers fall back to the tile kernels */
 
 int sfmi_version(void);
@@ -151,6 +152,10 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
                         float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
                         unsigned seed, const unsigned* seed_dev /* optional device-resident seed (overrides `seed`) */, int advance,
                         int row_offset, int rows_total, void* stream);
+/* ShapeRepresenter.sampling_masker alone (representers.py:120-155): logits (B,ldv) -> masked copy out (B,V); no draw, seq / len
+ * are read only.  Row b holds len[b] complete tokens; for tuple_i == 1 the position just drawn sits at seq[b][len[b]][0]. */
+int sfmi_gpt_mask_logits_f32(const float* logits, const int* seq, const int* len, const int* Lc, float* out, int B, int V, int ldv,
+                             int Lmax, int tuple_i, int end0, int end1, int mask_invalid, int mask_completion, void* stream);
 int sfmi_set_len_i32(int* len, const int* src, int B, int delta, void* stream);
 
 /* ---- Training step of the transformer (csrc/train.hip): shapeformer.py:26-46,132-207 (forward/loss/AdamW groups),

@@ -131,7 +131,7 @@ def uniforms(seed, n_steps, B):
 @torch.no_grad()
 def sample_indices(sd, cfg, c_indices, max_steps, u, top_k=100, top_p=0.4, temperature=1.0,
                    best_in_first=True, mask_invalid=True, mask_invalid_completion=True,
-                   use_cache=True, stop_early=True, force_tokens=None, return_logits=True):
+                   use_cache=True, stop_early=True, force_tokens=None, return_logits=True, z_indices=None):
     """ShapeFormer.sample_indices (shapeformer.py:54-123) with AR_N extra indices
     (representers.py:188-196), the representer's sampling_masker (:120-155) and
     filter_sampling_logits (common.py:260-285); multinomial -> inverse CDF on supplied u.
@@ -141,15 +141,21 @@ def sample_indices(sd, cfg, c_indices, max_steps, u, top_k=100, top_p=0.4, tempe
     force_tokens (B,steps,2): teacher-forced stepwise mode — logits are recorded, tokens forced.
     Steps are capped so the sequence never exceeds block_size (the reference's crop at
     shapeformer.py:73-76 is buggy/unreachable; the build stops instead).
+    z_indices (B,L_z,2): tokens already generated (shapeformer.py:60-70 copies cat(c, z) into `sampled` and continues after
+    them); the step counter j of the masker / history / uniforms starts at 0 at the first NEW token, as in the reference's loop,
+    and the returned tokens are sampled[:, L_c:] - the prefix included (shapeformer.py:121).
     """
     c = torch.as_tensor(c_indices).long()
     B, L_c, _ = c.shape
+    z = torch.zeros(B, 0, 2, dtype=torch.long) if z_indices is None else torch.as_tensor(z_indices).long()
+    L_z = z.shape[1]
     end = cfg.end_tokens
-    max_steps = min(max_steps, cfg.block_size - L_c)
-    sampled = torch.zeros(B, L_c + max_steps, 2, dtype=torch.long)
+    max_steps = min(max_steps, cfg.block_size - L_c - L_z)
+    sampled = torch.zeros(B, L_c + L_z + max_steps, 2, dtype=torch.long)
     sampled[:, :L_c] = c
+    sampled[:, L_c:L_c + L_z] = z
     hist = [[], []]
-    tail = L_c
+    tail = L_c + L_z
     caches = [None, None]
     done_steps = 0
     for j in range(max_steps):

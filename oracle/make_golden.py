@@ -229,6 +229,35 @@ def gpt_fixtures(vq, rq, tokens):
                         ref_sampled=rx.numpy(), ref_hist0_row0=rhist[0][0].numpy(), ref_hist1_row0=rhist[1][0].numpy(),
                         steps=np.int64(steps), orc_sampled=os_, orc_logprob=lp)
 
+    # continuing a NON-EMPTY z_indices (shapeformer.py:60-70): the reference copies cat(c, z) into `sampled` and generates after it;
+    # its step counter (masker's step_j) restarts at 0, so the first new position is not constrained by mask_invalid
+    Lz, steps2 = 5, 10
+    zp = z_idx[:1, :Lz].expand(S, -1, -1).contiguous()
+    torch.manual_seed(1)
+    rx2, rhist2 = sf.sample_indices(c_indices=c1, z_indices=zp, max_steps=steps2, best_in_first=True, top_k=100, top_p=0.4,
+                                    temperature=1.0, mask_invalid=True, mask_invalid_completion=True)
+    assert np.array_equal(rx2[:, :Lz].numpy(), zp.numpy()), "the returned tokens start with the z prefix"
+    n2 = rx2.shape[1] - Lz
+    u2 = GO.uniforms(1, steps2, S)
+    for use_cache in (False, True):
+        ox2, ohist2, _ = GO.sample_indices(gsd, cfg, c1, steps2, u2, use_cache=use_cache, force_tokens=rx2[:, Lz:].numpy(),
+                                           stop_early=False, z_indices=zp)
+        assert np.array_equal(ox2[:, :Lz + n2], rx2.numpy())
+        for i in range(2):
+            a, b = rhist2[i].numpy(), ohist2[i][:, :n2]
+            fin = np.isfinite(a)
+            assert np.array_equal(fin, np.isfinite(b)), "z-prefix continuation: masks differ"
+            dd = np.abs(a[fin] - b[fin]).max()
+            assert dd < 2e-4, dd
+        print(f"z-prefix continuation logits_history (cache={use_cache}) max|diff| {dd:.2e}; masks identical")
+    og2, _, _ = GO.sample_indices(gsd, cfg, c1[:1], steps2, u2[:, :, :1], use_cache=True, stop_early=False, z_indices=zp[:1])
+    assert np.array_equal(og2[0, :rx2.shape[1]], rx2[0].numpy()), "greedy row diverged after a z prefix"
+    print(f"greedy row after a {Lz}-token z prefix: {n2} steps token-exact vs reference")
+    os2, oshist2, _ = GO.sample_indices(gsd, cfg, c1, steps2, u2, use_cache=True, stop_early=False, z_indices=zp)
+    np.savez_compressed(os.path.join(OUT, "gpt_tiny_zprefix.npz"), c_idx=c1.numpy(), z_prefix=zp.numpy(), ref_sampled=rx2.numpy(),
+                        ref_hist0_row0=rhist2[0][0].numpy(), ref_hist1_row0=rhist2[1][0].numpy(), steps=np.int64(steps2),
+                        orc_sampled=os2)
+
     section("CondTupleGPT full config (20+4 layers, d=1024): reference forward vs oracle")
     g = R.build_gpt()
     fsd = VO.to_torch_sd(W.make_state_dict(W.gpt_spec()))

@@ -686,7 +686,7 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
 }
 
 template <int NWV, int U>
-__global__ __launch_bounds__(64 * NWV, U == 4 ? 8 : 4) void attn_decode_kernel(AttnArgs a) {   // U = 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128
+__global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : 4) void attn_decode_kernel(AttnArgs a) {   // U <= 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128
   __shared__ AttnLds<NWV> s;
   const int nitems = a.B * a.H;
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
@@ -844,6 +844,7 @@ struct SampleArgs {
   unsigned seed;
   const unsigned* seed_dev;     // optional: the seed lives in device memory (a captured hipGraph is reused across seeds)
   int row_offset, rows_total;   // micro-batching: global row = row_offset + blockIdx.x of rows_total (uniform stream, greedy row 0)
+  float* mask_out;              // mask-only mode (sfmi_gpt_mask_logits_f32): masked logits -> mask_out[b*V + v], nothing else happens
 };
 
 #define SMP_MAXC 512
@@ -891,9 +892,11 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       if (a.mask_completion && v > next_cond) x = -INFINITY;
     }
     lg[v] = x;
+    if (a.mask_out) a.mask_out[(long long)b * a.V + v] = x;
     if (a.hist) a.hist[((long long)b * a.max_steps + j) * a.V + v] = x;
     if (x > lmax) { lmax = x; amax = v; }
   }
+  if (a.mask_out) return;   // mask-only mode (uniform per launch)
   // block argmax (lowest index on ties) + logsumexp
   for (int o = 32; o > 0; o >>= 1) {
     const float om = __shfl_xor(lmax, o, 64);
@@ -1286,7 +1289,7 @@ int sfmi_tune_set(const char* name, int value) {
   if (!name) return SFMI_EINVAL;
   const std::string n(name);
   if (n == "attn_blocks" && value >= 0) g_tune.attn_blocks = value;
-  else if (n == "attn_unroll" && (value == 4 || value == 8)) g_tune.attn_unroll = value;
+  else if (n == "attn_unroll" && (value == 2 || value == 4 || value == 8)) g_tune.attn_unroll = value;
   else if (n == "attn_waves" && (value == 8 || value == 16)) g_tune.attn_waves = value;
   else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) g_tune.attn_lds_pad = value;
   else return SFMI_EINVAL;
@@ -1317,13 +1320,13 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {   // the occupancy-cap experiments ask for more dynamic LDS than the 64 KB default
 #define AT_ATTR(W_, U_) do { hipError_t e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; } while (0)
-    AT_ATTR(16, 4); AT_ATTR(16, 8); AT_ATTR(8, 4); AT_ATTR(8, 8);
+    AT_ATTR(16, 2); AT_ATTR(16, 4); AT_ATTR(16, 8); AT_ATTR(8, 2); AT_ATTR(8, 4); AT_ATTR(8, 8);
 #undef AT_ATTR
   });
   if (pad && attr_err != hipSuccess) return (int)attr_err;
 #define AT(W_, U_) hipLaunchKernelGGL((attn_decode_kernel<W_, U_>), dim3(grid), dim3(64 * W_), pad, st, a)
-  if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else AT(16, 4); }
-  else { if (g_tune.attn_unroll == 8) AT(8, 8); else AT(8, 4); }
+  if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else if (g_tune.attn_unroll == 2) AT(16, 2); else AT(16, 4); }
+  else { if (g_tune.attn_unroll == 8) AT(8, 8); else if (g_tune.attn_unroll == 2) AT(8, 2); else AT(8, 4); }
 #undef AT
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
@@ -1360,8 +1363,24 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
   a.Lmax = Lmax; a.tuple_i = tuple_i; a.end0 = end0; a.end1 = end1; a.top_k = top_k; a.greedy_row0 = greedy_row0;
   a.mask_invalid = mask_invalid; a.mask_completion = mask_completion; a.max_steps = max_steps; a.advance = advance;
   a.top_p = top_p; a.temperature = temperature; a.seed = seed; a.seed_dev = seed_dev; a.row_offset = row_offset; a.rows_total = rows_total;
+  a.mask_out = nullptr;
   const size_t dyn = (top_k <= 0 || top_k > SMP_MAXC) ? (size_t)SMP_BIG * 12 : 0;
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), dyn, (hipStream_t)stream, a);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// replaces ShapeRepresenter.sampling_masker alone (representers.py:120-155): logits (B,ldv) -> masked copy out (B,V); the masking
+// stage of sample_kernel and nothing else (no draw, seq / len untouched).  seq (B,Lmax,2): row b holds len[b] complete tokens and,
+// for tuple_i == 1, the position just drawn at seq[b][len[b]][0].
+int sfmi_gpt_mask_logits_f32(const float* logits, const int* seq, const int* len, const int* Lc, float* out, int B, int V, int ldv,
+                             int Lmax, int tuple_i, int end0, int end1, int mask_invalid, int mask_completion, void* stream) {
+  if (!logits || !seq || !len || !Lc || !out || B <= 0 || V <= 0 || V > 4352 || ldv < V || (tuple_i != 0 && tuple_i != 1)) return SFMI_EINVAL;
+  SampleArgs a = {};
+  a.part = logits; a.seq = const_cast<int*>(seq); a.len = const_cast<int*>(len); a.Lc = Lc; a.S = 1; a.M = B; a.V = V; a.ldv = ldv;
+  a.Lmax = Lmax; a.tuple_i = tuple_i; a.end0 = end0; a.end1 = end1; a.top_k = 1; a.mask_invalid = mask_invalid;
+  a.mask_completion = mask_completion; a.max_steps = 1; a.temperature = 1.0f; a.rows_total = B; a.mask_out = out;
+  hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

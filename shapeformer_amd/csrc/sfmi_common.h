@@ -10,6 +10,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SFMI_OK 0
 #define SFMI_EINVAL (-1)
 #define SFMI_ELAUNCH (-2)
+#define SFMI_ELDS (-4)   /* the device refused the dynamic-LDS size a kernel needs */
 
 #define SFMI_CHECK_LAUNCH()                       \
   do {                                            \

@@ -18,6 +18,7 @@
 // Block order is XCD-aware (block b runs on XCD b % 8): the N-tiles of one M-tile are consecutive on ONE XCD, so the A tile is
 // fetched from HBM once per XCD L2 instead of once per N-tile.
 #include "sfmi_common.h"
+#include <mutex>
 
 #define SG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -291,14 +292,19 @@ int sfmi_sgemm_mfma_f32(int transA, int transB, int M, int N, int K, const float
   if (blocks > 0x7fffffffLL) return SFMI_EINVAL;
   const size_t lds = 4 * SG_TILE * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;   // idempotent, race-free
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sgemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)sgemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)sgemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)sgemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  // the 73.7 KB tile pair needs the dynamic-LDS limit raised above the 64 KB default: once per process, and a refusal is an
+  // error the caller sees (SFMI_ELDS) instead of a generic launch failure on every prefill / training GEMM
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [lds] {
+    const void* ks[4] = {(const void*)sgemm_mfma_kernel<true, true>, (const void*)sgemm_mfma_kernel<true, false>,
+                         (const void*)sgemm_mfma_kernel<false, false>, (const void*)sgemm_mfma_kernel<false, true>};
+    for (const void* k : ks) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) attr_err = e;
+    }
+  });
+  if (attr_err != hipSuccess) return SFMI_ELDS;
   const dim3 grid((unsigned)blocks, S), block(256);
   if (!transA && transB) hipLaunchKernelGGL((sgemm_mfma_kernel<true, true>), grid, block, lds, st, a);
   else if (!transA && !transB) hipLaunchKernelGGL((sgemm_mfma_kernel<true, false>), grid, block, lds, st, a);

@@ -105,8 +105,11 @@ class VQDIFModel:
         """HIP training state for this model: Adam(lr) over all parameters + EMA codebook (train_vqdif.VQDIFTrainer)."""
         from .train_vqdif import VQDIFTrainer
         oo = optim_opt or self.hparams.get("optim_opt") or {}
+        # the StepLR base is optim_opt.lr (on_epoch_end computes lr0 * gamma ** k from it); `lr_now` lets resume() restore a
+        # decayed current rate without moving that base
+        self._optim_used = {k: v for k, v in oo.items() if k != "lr_now"}
         self._lr0 = oo.get("lr", 1e-4)
-        self.trainer = VQDIFTrainer(self.core.state_dict_np(), res=self.core.res, device=self.core.dev, lr=self._lr0,
+        self.trainer = VQDIFTrainer(self.core.state_dict_np(), res=self.core.res, device=self.core.dev, lr=oo.get("lr_now", self._lr0),
                                     beta=self.hparams.get("vq_beta", 1.0), dist=dist)
         return self.trainer
 
@@ -124,7 +127,7 @@ class VQDIFModel:
         self.sync_inference_weights()
         sd = self.trainer.state_dict() if hasattr(self, "trainer") else self.core.state_dict_np()
         ck = dict(state_dict={k: torch.as_tensor(v) for k, v in sd.items()}, hyper_parameters=dict(self.hparams), epoch=epoch,
-                  global_step=getattr(getattr(self, "trainer", None), "step_count", 0))
+                  global_step=getattr(getattr(self, "trainer", None), "step_count", 0), lr=getattr(getattr(self, "trainer", None), "lr", None))
         if hasattr(self, "trainer"):
             ck["sfmi_optimizer_state"] = self.trainer.optimizer_state()     # flat Adam moments (not a torch.optim state dict)
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -133,19 +136,24 @@ class VQDIFModel:
 
     def on_epoch_end(self, epoch):
         """StepLR of the shipped optim_opt (vqdif.py:127-133): lr = lr0 * gamma ** ((epoch + 1) // step_size)."""
-        oo = self.hparams.get("optim_opt") or {}
+        oo = getattr(self, "_optim_used", None) or self.hparams.get("optim_opt") or {}
         if hasattr(self, "trainer") and oo.get("scheduler") == "StepLR":
             self.trainer.lr = self._lr0 * float(oo.get("gamma", 0.9)) ** ((int(epoch) + 1) // int(oo.get("step_size", 10)))
         return getattr(getattr(self, "trainer", None), "lr", None)
 
     def resume(self, path):
-        """Continue training from save_checkpoint's file: weights, EMA codebook buffers, Adam moments, step count."""
+        """Continue training from save_checkpoint's file: weights, EMA codebook buffers, Adam moments, step count, and the
+        learning rate the run had reached (the StepLR base stays the configured optim_opt.lr)."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
         self.core.load_state_dict(ck["state_dict"])
-        lr = self.trainer.lr if hasattr(self, "trainer") else None
-        self.make_trainer(dict(lr=lr) if lr else None, dist=getattr(getattr(self, "trainer", None), "dist", None))
-        if ck.get("sfmi_optimizer_state") is not None:
-            self.trainer.load_optimizer_state(ck["sfmi_optimizer_state"])
+        lr = ck.get("lr") or (self.trainer.lr if hasattr(self, "trainer") else None)
+        oo = dict(getattr(self, "_optim_used", None) or self.hparams.get("optim_opt") or {})
+        if lr:
+            oo["lr_now"] = lr
+        self.make_trainer(oo or None, dist=getattr(getattr(self, "trainer", None), "dist", None))
+        st = _optimizer_state_of(ck)
+        if st is not None:
+            self.trainer.load_optimizer_state(st)
         return ck
 
     def sync_inference_weights(self):
@@ -158,6 +166,17 @@ class VQDIFModel:
     def load_from_checkpoint(cls, ckpt_path, **kw):
         ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
         return cls(**ck["hyper_parameters"], state_dict=ck["state_dict"], **kw)
+
+
+def _optimizer_state_of(ck):
+    """Our flat Adam(W) moments in a checkpoint: `sfmi_optimizer_state`, or - files written before the key was renamed -
+    `optimizer_states[0]` when that entry is ours (it carries `exp_avg`; a Lightning per-tensor state does not and is skipped)."""
+    st = ck.get("sfmi_optimizer_state")
+    if st is None:
+        legacy = ck.get("optimizer_states")
+        if isinstance(legacy, (list, tuple)) and legacy and isinstance(legacy[0], dict) and "exp_avg" in legacy[0]:
+            st = legacy[0]
+    return st
 
 
 class CondTupleGPTModel:
@@ -267,23 +286,21 @@ class ARNRepresenter:
         """logits (B,V) -> masked copy; idx (B,L+1,2): idx[:, -1] is the position being sampled.  Runs the masking stage of the
         fused sampler kernel (csrc/gpt.hip:sample_kernel - the code the decode step uses) on a scratch copy of `idx`."""
         from . import _lib as L
+        if L_cond is None or tuple_i is None:
+            raise ValueError("sampling_masker needs L_cond and tuple_i (representers.py:120: the masks depend on both)")
         dev = self.dev
         lg = torch.as_tensor(logits).to(dev, torch.float32).contiguous()
         seq = torch.as_tensor(idx).to(dev, torch.int32).contiguous()
         B, V = lg.shape
         Lt = seq.shape[1]
-        if step_j is not None and L_cond is not None and tuple_i == 0 and step_j != Lt - 1 - L_cond:
+        if step_j is not None and tuple_i == 0 and step_j != Lt - 1 - int(L_cond):
             raise ValueError("sampling_masker: step_j must equal idx.shape[1] - 1 - L_cond (shapeformer.py:86-93)")
-        seq = torch.cat([seq, torch.zeros(B, 1, 2, device=dev, dtype=torch.int32)], 1).contiguous()   # kernel writes the draw at [L]
         ln = torch.full((B,), Lt - 1, device=dev, dtype=torch.int32)
         lc = torch.full((B,), int(L_cond), device=dev, dtype=torch.int32)
-        j = Lt - 1 - int(L_cond)
         out = torch.empty(B, V, device=dev, dtype=torch.float32)
-        hist_base = out.data_ptr() - j * V * 4          # kernel writes hist[(b*max_steps + j)*V + v] with max_steps = 1
-        L.check(L.lib().sfmi_gpt_sample_f32(L.ptr(lg), L.ptr(seq), L.ptr(ln), L.ptr(lc), None, hist_base, None,
-                                            None, None, None, None, None, 0, 1, B, V, V, Lt + 1, int(tuple_i),
-                                            int(self.end_tokens[0]), int(self.end_tokens[1]), 1, 0.0, 1.0, 0, int(self.mask_invalid),
-                                            int(self.mask_invalid_completion), 1, 0, None, 0, 0, B, L.stream_ptr()), "sfmi_gpt_sample_f32")
+        L.check(L.lib().sfmi_gpt_mask_logits_f32(L.ptr(lg), L.ptr(seq), L.ptr(ln), L.ptr(lc), L.ptr(out), B, V, V, Lt, int(tuple_i),
+                                                 int(self.end_tokens[0]), int(self.end_tokens[1]), int(self.mask_invalid),
+                                                 int(self.mask_invalid_completion), L.stream_ptr()), "sfmi_gpt_mask_logits_f32")
         return out
 
 
@@ -419,7 +436,7 @@ class ShapeFormerModel:
         old = getattr(self, "trainer", None)
         if old is not None:
             self.make_trainer(dict(lr=old.lr), dist=old.dist)
-        st = ck.get("sfmi_optimizer_state")
+        st = _optimizer_state_of(ck)
         if resume_optimizer and st is not None:
             if old is None:
                 self.make_trainer(self.optim_opt)

@@ -184,3 +184,19 @@ def test_checkpoint_resume_is_bit_exact_for_both_models(dev, tmp_path):
     v2.resume(vpath)
     assert v2.trainer.step_count == 2
     assert [float(v2.training_step(vb)) for _ in range(2)] == want
+    # StepLR across an in-process resume (vqdif.py:127-133): the base stays optim_opt.lr, the decayed rate is restored once
+    v3 = P.instantiate_from_opt({"class": "shapeformer.models.vqdif.vqdif.VQDIF", "kwargs": kw})
+    v3.hparams["optim_opt"] = dict(lr=1e-3, scheduler="StepLR", step_size=2, gamma=0.5)
+    v3.make_trainer()
+    assert v3.on_epoch_end(0) == 1e-3 and v3.on_epoch_end(1) == 5e-4          # epoch 1 ends: (1 + 1) // 2 = 1 decay
+    p3 = v3.save_checkpoint(str(tmp_path / "ck" / "vq3.ckpt"), epoch=1)
+    v3.resume(p3)
+    assert v3.trainer.lr == 5e-4 and v3._lr0 == 1e-3
+    assert v3.on_epoch_end(2) == 5e-4 and v3.on_epoch_end(3) == 2.5e-4        # NOT 1.25e-4: the decay is applied to the base once
+    # a checkpoint written before the optimizer key was renamed still restores its moments
+    ck3 = torch.load(p3, map_location="cpu", weights_only=False)
+    ck3["optimizer_states"] = [ck3.pop("sfmi_optimizer_state")]
+    torch.save(ck3, p3)
+    v3.trainer.step_count = 0
+    v3.resume(p3)
+    assert v3.trainer.step_count == ck3["global_step"]
