@@ -198,7 +198,7 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
     st["seq"].zero_()
     ms = ev_time(lambda: L_.check(lib.sfmi_gpt_sample_f32(L_.ptr(lg), L_.ptr(st["seq"]), L_.ptr(st["len"]), L_.ptr(st["Lc"]), None, None, None,
                                                           None, None, None, None, None, 0, 1, B, gpt.V, gpt.Vpad, gpt.Lmax + 1, 0, 4096, 4096, 100, 0.4, 1.0,
-                                                          0, 1, 1, 512, 12345, None, 0, 0, B, L_.stream_ptr()), "sample"), 20)
+                                                          0, 1, 1, 512, 12345, None, 0, 0, B, 0, L_.stream_ptr()), "sample"), 20)
     st["len"].zero_(); st["Lc"].zero_()
     add("sample_kernel (masker + top-k + top-p + inverse CDF)", ms, "hbm", B * gpt.Vpad * 4, 1e9, HBM, "GB/s", f"{B} rows x 4097 logits; latency-bound by design ({ms * 1e3:.1f} us)")
     # prefill attention on the matrix cores: rows of mean condition length

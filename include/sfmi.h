@@ -151,7 +151,9 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
                         int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
                         float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
                         unsigned seed, const unsigned* seed_dev /* optional device-resident seed (overrides `seed`) */, int advance,
-                        int row_offset, int rows_total, void* stream);
+                        int row_offset, int rows_total,
+                        int step_offset /* tokens generated before this run (non-empty z_indices, shapeformer.py:60-70): step j = len - Lc - step_offset */,
+                        void* stream);
 /* ShapeRepresenter.sampling_masker alone (representers.py:120-155): logits (B,ldv) -> masked copy out (B,V); no draw, seq / len
  * are read only.  Row b holds len[b] complete tokens; for tuple_i == 1 the position just drawn sits at seq[b][len[b]][0]. */
 int sfmi_gpt_mask_logits_f32(const float* logits, const int* seq, const int* len, const int* Lc, float* out, int B, int V, int ldv,

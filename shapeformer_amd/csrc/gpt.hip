@@ -844,6 +844,8 @@ struct SampleArgs {
   unsigned seed;
   const unsigned* seed_dev;     // optional: the seed lives in device memory (a captured hipGraph is reused across seeds)
   int row_offset, rows_total;   // micro-batching: global row = row_offset + blockIdx.x of rows_total (uniform stream, greedy row 0)
+  int step_offset;              // tokens generated BEFORE this call (a non-empty z_indices, shapeformer.py:60-70): the step counter
+                                // of masker / history / log-prob / uniforms restarts at 0 at the first new token, as the reference's does
   float* mask_out;              // mask-only mode (sfmi_gpt_mask_logits_f32): masked logits -> mask_out[b*V + v], nothing else happens
 };
 
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   float* cexp = big ? dyn_lds + 2 * SMP_BIG : cexp_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = a.len[b], lc = a.Lc[b];
-  const int j = L - lc;  // step index of this row
+  const int j = L - lc - a.step_offset;  // step index of this row (the reference's loop counter, shapeformer.py:71)
   const int* row = a.seq + (long long)b * a.Lmax * 2;
   const int last_pos = row[2 * (L - 1)];
   const int cur_pos = row[2 * L];  // valid for tuple 1 (pos just sampled)
@@ -1354,8 +1356,9 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
                         float* resid, const float* E0, const float* E1, const float* Ex, const float* pos_emb, int D,
                         int S, int B, int V, int ldv, int Lmax, int tuple_i, int end0, int end1, int top_k, float top_p,
                         float temperature, int greedy_row0, int mask_invalid, int mask_completion, int max_steps,
-                        unsigned seed, const unsigned* seed_dev, int advance, int row_offset, int rows_total, void* stream) {
-  if (!part || !seq || !len || !Lc || V > 4352 || temperature <= 0.f || rows_total < B + row_offset) return SFMI_EINVAL;
+                        unsigned seed, const unsigned* seed_dev, int advance, int row_offset, int rows_total, int step_offset,
+                        void* stream) {
+  if (!part || !seq || !len || !Lc || V > 4352 || temperature <= 0.f || rows_total < B + row_offset || step_offset < 0) return SFMI_EINVAL;
   if (resid && (!E0 || (tuple_i == 1 && (!E1 || !Ex || !pos_emb)) || D % 4)) return SFMI_EINVAL;
   SampleArgs a;
   a.part = part; a.seq = seq; a.len = len; a.Lc = Lc; a.logp = logp; a.hist = hist; a.force = force; a.S = S; a.M = B; a.V = V;
@@ -1363,7 +1366,7 @@ int sfmi_gpt_sample_f32(const float* part, int* seq, int* len, const int* Lc, fl
   a.Lmax = Lmax; a.tuple_i = tuple_i; a.end0 = end0; a.end1 = end1; a.top_k = top_k; a.greedy_row0 = greedy_row0;
   a.mask_invalid = mask_invalid; a.mask_completion = mask_completion; a.max_steps = max_steps; a.advance = advance;
   a.top_p = top_p; a.temperature = temperature; a.seed = seed; a.seed_dev = seed_dev; a.row_offset = row_offset; a.rows_total = rows_total;
-  a.mask_out = nullptr;
+  a.mask_out = nullptr; a.step_offset = step_offset;
   const size_t dyn = (top_k <= 0 || top_k > SMP_MAXC) ? (size_t)SMP_BIG * 12 : 0;
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), dyn, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();

@@ -392,6 +392,13 @@ class CondTupleGPT:
     def decode_step(self, st, B, sp):
         """Position t = len[b]-1 of every row through both stages; st["resid"] must hold its embedding on entry
         (written by the previous step's sampler tail, or by `_embed` before the first step)."""
+        for _ in self._decode_step_iter(st, B, sp):
+            pass
+
+    def _decode_step_iter(self, st, B, sp):
+        """The launches of one decode step as a generator that yields just BEFORE ("pre_attn", layer) and just AFTER
+        ("post_attn", layer) every attention launch: the lock-step scheduler (`_rot_steps`) puts its cross-chain
+        dependencies there; `decode_step` simply exhausts it."""
         D = self.D
         lib = L.lib()
         r = st["resid"]
@@ -403,11 +410,13 @@ class CondTupleGPT:
         for li, ly in enumerate(self.layers):
             if "gemm" not in skip:
                 self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
+            yield "pre_attn", li
             if "attn" not in skip:
                 L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
                                                      L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
                                                      L.ptr(st["shared"]) if sp.get("shared_prefix") else None,
                                                      L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
+            yield "post_attn", li
             if "gemm" not in skip:
                 self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st)
                 self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st)
@@ -424,25 +433,104 @@ class CondTupleGPT:
                                                 s, self.end[0], self.end[1], sp["top_k"], sp["top_p"], sp["temperature"],
                                                 int(sp["best_in_first"]), int(sp["mask_invalid"]),
                                                 int(sp["mask_invalid_completion"]), sp["max_steps"], sp["seed"], L.ptr(st.get("seed")), int(s == 1),
-                                                sp.get("row_offset", 0), sp.get("rows_total", B), L.stream_ptr()), "sfmi_gpt_sample_f32")
+                                                sp.get("row_offset", 0), sp.get("rows_total", B), int(sp.get("step_offset", 0)),
+                                                L.stream_ptr()), "sfmi_gpt_sample_f32")
+
+    # ------------------------------------------------------------------ lock-step chains: ONE graph for all chains
+    ROT_LANES = 0          # > 0: sample_microbatched runs its chains in lock-step (see _rot_steps) with this many attention lanes
+    ROT_STEPS = 1          # decode steps captured per lock-step graph (amortises the join at the end of a replay)
+
+    def _rot_steps(self, ctxs, streams, lanes, nsteps):
+        """`nsteps` decode steps of ALL chains, issued on the chains' streams with cross-chain dependencies that serialise the
+        attention launches: lane k holds the chains k, k+lanes, ...; within a lane the attention of (chain c, layer l) starts
+        only when the lane's previous attention - (chain c-lanes, layer l), or the last chain's (l-1) - has finished.  So at
+        most `lanes` KV streams are in flight at any time (each sized to saturate HBM on its own, with a resident footprint
+        that leaves room for GEMM workgroups on every CU), and the other chains' GEMMs run beside them instead of queueing
+        behind two or three chip-filling attention kernels (profiles/r03_ar_overlap.md).  Under stream capture the event
+        waits become graph edges: one hipGraph replays the step of every chain."""
+        its = [None] * len(ctxs)
+        last = [None] * lanes          # last attention event of every lane
+        for _ in range(nsteps):
+            its = [self._decode_step_iter(c["st"], c["B"], c["sp"]) for c in ctxs]
+            for li in range(len(self.layers)):
+                for ci, (c, s) in enumerate(zip(ctxs, streams)):
+                    with torch.cuda.stream(s):
+                        tag = next(its[ci])                 # previous layer's tail + this layer's qkv
+                        assert tag == ("pre_attn", li)
+                        lane = ci % lanes
+                        if last[lane] is not None:
+                            s.wait_event(last[lane])
+                        assert next(its[ci]) == ("post_attn", li)
+                        ev = torch.cuda.Event()
+                        ev.record(s)
+                        last[lane] = ev
+            for ci, s in enumerate(streams):            # the last layer's tail (proj, MLP, head, sampler)
+                with torch.cuda.stream(s):
+                    for _t in its[ci]:
+                        raise AssertionError("decode step iterator out of step")
+
+    def _rot_graph(self, ctxs, streams, lanes, nsteps):
+        """Capture `_rot_steps` into one hipGraph (fork from / join to the capture stream)."""
+        key = ("rot", lanes, nsteps, tuple((c["B"], tuple(sorted((k, v) for k, v in c["sp"].items() if k not in ("hist", "force", "seed"))),
+                                            tuple(h.data_ptr() for h in (c["hist"] or ()))) for c in ctxs),
+               self._ablate, self._force_wide, self.S_PROJ, self.S_PROJ_M, self.S_FC2)
+        cached = self._graphs.get("rot")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        keep = ("seq", "len", "logp", "resid")
+        saved = [{k: c["st"][k].clone() for k in keep} for c in ctxs]
+        cur = torch.cuda.current_stream()
+        for s in streams:
+            s.wait_stream(cur)
+        self._rot_steps(ctxs, streams, lanes, 1)      # warm-up outside capture
+        for s in streams:
+            cur.wait_stream(s)
+        torch.cuda.synchronize()
+        for c, sv in zip(ctxs, saved):
+            for k in keep:
+                c["st"][k].copy_(sv[k])
+        cap = torch.cuda.Stream(device=self.dev)
+        cap.wait_stream(cur)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cap):
+            for s in streams:
+                s.wait_stream(cap)
+            self._rot_steps(ctxs, streams, lanes, nsteps)
+            for s in streams:
+                cap.wait_stream(s)
+        cur.wait_stream(cap)
+        for c, sv in zip(ctxs, saved):
+            for k in keep:
+                c["st"][k].copy_(sv[k])
+        torch.cuda.synchronize()
+        self._graphs["rot"] = (key, graph)
+        return graph
 
     # ------------------------------------------------------------------ sample_indices
     def _prepare(self, c_tokens, Lc, max_steps, sp_kw, slot=0, row_offset=0, rows_total=None, return_logits=False,
-                 force_tokens=None, use_graph=True, shared_prefix=False):
-        """State + prefill + step-0 embedding + (cached) hipGraph of one decode step for one (micro-)batch."""
+                 force_tokens=None, use_graph=True, shared_prefix=False, z_tokens=None):
+        """State + prefill + step-0 embedding + (cached) hipGraph of one decode step for one (micro-)batch.
+        z_tokens (B,L_z,2): tokens already generated after the condition (shapeformer.py:60-70 copies cat(c, z) into `sampled`):
+        they are prefilled together with the condition and sampling continues after them; the step counter restarts at 0."""
         B = c_tokens.shape[0]
+        Lz = 0 if z_tokens is None else int(z_tokens.shape[1])
         if B > 256:
             raise L.SfmiError("decode kernels support up to 256 rows per (micro-)batch")
         if getattr(self, "_decode_stale", False):
             self.refresh_decode_weights()
         Lc_host = Lc.cpu().tolist()
         Lc_max = max(Lc_host)
-        steps = min(max_steps, self.Lmax - Lc_max)   # never exceed block_size (DESIGN.md: stop, don't crop)
+        steps = min(max_steps, self.Lmax - Lc_max - Lz)   # never exceed block_size (DESIGN.md: stop, don't crop)
         st = self._alloc(B, max_steps, slot)
         st["seq"].zero_()
         st["seq"][:, :c_tokens.shape[1]] = c_tokens.to(self.dev, torch.int32)
         st["Lc"].copy_(Lc.to(self.dev, torch.int32))
         st["len"].copy_(st["Lc"])
+        if Lz:      # row b: positions Lc[b] .. Lc[b]+Lz-1 hold its z tokens (rows are ragged in Lc)
+            pos = st["Lc"].long()[:, None] + torch.arange(Lz, device=self.dev)[None, :]
+            st["seq"][torch.arange(B, device=self.dev)[:, None], pos] = torch.as_tensor(z_tokens).to(self.dev, torch.int32)
+            st["len"].add_(Lz)
+            shared_prefix = False
         st["logp"].zero_()
         st["seed"].copy_(torch.from_numpy(np.array([sp_kw["seed"]], np.uint32).view(np.int32)))
         hist = None
@@ -450,14 +538,16 @@ class CondTupleGPT:
             hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
         sp = dict(sp_kw, max_steps=int(max_steps), hist=hist, row_offset=int(row_offset),
                   rows_total=int(rows_total if rows_total is not None else B), chain=int(slot - 100 if slot >= 100 else 0),
-                  shared_prefix=bool(shared_prefix))
+                  shared_prefix=bool(shared_prefix), step_offset=Lz)
         if force_tokens is not None:   # (B,max_steps,2) teacher forcing for stepwise parity tests
             ft = torch.zeros(B, max_steps, 2, dtype=torch.int32)
             ft[:, :force_tokens.shape[1]] = torch.as_tensor(force_tokens).to(torch.int32)
             sp["force"] = ft.to(self.dev)
             use_graph = False
-        P = Lc_max - 1
+        P = Lc_max + Lz - 1
         st["nval"], st["extra"] = None, None
+        if Lz:
+            st["nval"] = (st["len"] - 1).contiguous()     # prefill rows t < Lc + Lz - 1; the last z token is step 0's input
         if shared_prefix:
             # all rows carry the SAME condition (the sample_n copies of one shape, shapeformer.py:222-260): prefill it ONCE,
             # as row 0; its keys / values (positions < Lc-1) are then read from row 0's cache by every row's decode attention
@@ -471,7 +561,7 @@ class CondTupleGPT:
         else:
             st["shared"].zero_()
             # ragged condition prefixes are packed back to back: the prefill GEMMs / attention do no work on padding rows
-            nrow = [max(l - 1, 0) for l in Lc_host]
+            nrow = [max(l + Lz - 1, 0) for l in Lc_host]
             st["M_packed"] = sum(nrow)
             st["rowoff"] = torch.tensor([0] + list(np.cumsum(nrow)), dtype=torch.int32).to(self.dev)
             if P > 0 and st["M_packed"] > 0:
@@ -503,7 +593,7 @@ class CondTupleGPT:
                     st[k].copy_(v)
                 self._graphs[slot] = (gkey, graph)
             graph = self._graphs[slot][1]
-        return dict(st=st, sp=sp, B=B, steps=steps, graph=graph, hist=hist, Lc_host=Lc_host)
+        return dict(st=st, sp=sp, B=B, steps=steps, graph=graph, hist=hist, Lc_host=Lc_host, Lz=Lz)
 
     @staticmethod
     def _sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed):
@@ -514,15 +604,18 @@ class CondTupleGPT:
     @torch.no_grad()
     def sample(self, c_tokens, Lc, max_steps=512, top_k=100, top_p=0.4, temperature=1.0, best_in_first=True,
                mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True, use_graph=True,
-               return_logits=False, check_every=32, force_tokens=None, to_host=True, after_prefill=None, shared_prefix=False):
-        """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32.
+               return_logits=False, check_every=32, force_tokens=None, to_host=True, after_prefill=None, shared_prefix=False,
+               z_tokens=None):
+        """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32; z_tokens (B,L_z,2):
+        optional tokens already generated (sampling continues after them; `samples` then starts with them, as the reference's
+        x = sampled[:, L_c:] does, shapeformer.py:121, while log_prob / logits_history cover the NEW steps only).
 
-        Returns dict(samples (B,steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
+        Returns dict(samples (B,L_z+steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
         Mirrors ShapeFormer.sample_indices (shapeformer.py:54-123); torch.multinomial is replaced by an
         inverse-CDF draw on counter-hash uniforms (oracle/gpt_oracle.py:uniforms)."""
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
         ctx = self._prepare(c_tokens, Lc, max_steps, sp_kw, return_logits=return_logits, force_tokens=force_tokens,
-                            use_graph=use_graph, shared_prefix=shared_prefix)
+                            use_graph=use_graph, shared_prefix=shared_prefix, z_tokens=z_tokens)
         st, sp, B, steps, g, hist, Lc_host = (ctx[k] for k in ("st", "sp", "B", "steps", "graph", "hist", "Lc_host"))
         if after_prefill is not None:
             after_prefill()
@@ -549,9 +642,10 @@ class CondTupleGPT:
         seq = st["seq"].cpu()
         for b in range(B):
             out[b] = seq[b, Lc_host[b]:Lc_host[b] + nsteps].long()
-        res = dict(samples=out, log_prob=st["logp"][:, :nsteps].cpu(), steps=nsteps)
+        n_new = nsteps - ctx["Lz"]
+        res = dict(samples=out, log_prob=st["logp"][:, :n_new].cpu(), steps=n_new)
         if return_logits:
-            res["logits_history"] = [h[:, :nsteps].cpu() for h in hist]
+            res["logits_history"] = [h[:, :n_new].cpu() for h in hist]
         return res
 
     @torch.no_grad()
@@ -603,7 +697,7 @@ class CondTupleGPT:
 
     def sample_microbatched(self, c_tokens, Lc, n_micro=2, max_steps=512, top_k=100, top_p=0.4, temperature=1.0,
                             best_in_first=True, mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True,
-                            check_every=32, after_prefill=None):
+                            check_every=32, after_prefill=None, return_logits=False):
         """Same result as `sample(..., to_host=False)` (identical tokens: the uniform stream and the greedy row are
         indexed by GLOBAL row), but the rows are split into `n_micro` independent micro-batches whose decode steps are
         separate hipGraphs replayed on separate HIP streams: one micro-batch's HBM-bound attention overlaps the other's
@@ -614,6 +708,7 @@ class CondTupleGPT:
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
         streams = self._chain_streams(len(groups))
         cur = torch.cuda.current_stream()
+        rot_mode = self.ROT_LANES > 0 and len(groups) > 1      # lock-step: one graph for all chains instead of one per chain
         ctxs = []
         # every chain's prefill is issued on that chain's own stream: the chains' GEMMs / attention launches then fill each
         # other's last partial round of workgroups (a 10k-row x 1024-column GEMM is 632 tiles for 512 resident slots), and the
@@ -621,8 +716,17 @@ class CondTupleGPT:
         for i, (lo, hi) in enumerate(groups):
             streams[i].wait_stream(cur)
             with torch.cuda.stream(streams[i] if self.PREFILL_ON_CHAIN_STREAMS else cur):
-                ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B))
+                ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B,
+                                          return_logits=return_logits, use_graph=not rot_mode))
         steps = min(c["steps"] for c in ctxs)
+        rot = None
+        if rot_mode and steps > 1:
+            for s in streams:
+                cur.wait_stream(s)
+            rot_n = self.ROT_STEPS if (steps % self.ROT_STEPS == 0 and (not stop_early or check_every % self.ROT_STEPS == 0)) else 1
+            rot = self._rot_graph(ctxs, streams, min(self.ROT_LANES, len(ctxs)), rot_n)
+            for s in streams:
+                s.wait_stream(cur)
         if after_prefill is not None:
             for s in streams:
                 cur.wait_stream(s)
@@ -630,7 +734,17 @@ class CondTupleGPT:
             for s in streams:
                 s.wait_stream(cur)
         done = 0
-        while done < steps:
+        if rot is not None:
+            for s in streams:
+                cur.wait_stream(s)
+            while done < steps:
+                n = min(check_every, steps - done) if stop_early else steps - done
+                for _ in range(n // rot_n):
+                    rot.replay()                       # one replay = rot_n steps of every chain
+                done += n
+                if stop_early and all(self._all_ended(c["st"], c["B"]) for c in ctxs):
+                    break
+        while rot is None and done < steps:
             n = min(check_every, steps - done) if stop_early else steps - done
             for _ in range(n):
                 for c, s in zip(ctxs, streams):
@@ -648,7 +762,10 @@ class CondTupleGPT:
         for s in streams:
             cur.wait_stream(s)
         merged = {k: torch.cat([c["st"][k] for c in ctxs], 0) for k in ("seq", "len", "Lc", "logp")}
-        return dict(state=merged, steps=done)
+        res = dict(state=merged, steps=done)
+        if return_logits:     # masked-logit history of every row, (B, max_steps, V) x 2 (parity tests of the chain interleave)
+            res["logits_history"] = [torch.cat([c["hist"][i] for c in ctxs], 0) for i in range(2)]
+        return res
 
     def _all_ended(self, st, B):
         seq, ln = st["seq"], st["len"].long()

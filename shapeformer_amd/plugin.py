@@ -342,8 +342,9 @@ class ShapeFormerModel:
     @torch.no_grad()
     def sample_indices(self, c_indices, z_indices, max_steps, sample=False, best_in_first=False, top_k=100, top_p=.8, temperature=1.0,
                        mask_invalid=True, mask_invalid_completion=False, callback=lambda k: None, seed=0):
-        """ShapeFormer.sample_indices: c (B,L_c,2), z (B,0,2) -> (x (B,steps,2) int64 on the device, logits_history =
-        [ (B,steps,V) ] * 2 on the CPU: the masked logits every draw was made from).  Prefill + KV-cached hipGraph decode
+        """ShapeFormer.sample_indices: c (B,L_c,2), z (B,L_z,2) (usually empty; a non-empty z is prefilled with the condition and
+        sampling continues after it, shapeformer.py:60-70) -> (x (B,L_z+steps,2) int64 on the device, logits_history =
+        [ (B,steps,V) ] * 2 on the CPU: the masked logits every NEW draw was made from).  Prefill + KV-cached hipGraph decode
         instead of the reference's full re-forward per step; torch.multinomial is replaced by the counter-hash inverse CDF
         (DESIGN.md §2), so only the greedy row (`best_in_first`) is token-comparable with the reference.  Stops at the step
         where every row's newest token is an end token (shapeformer.py:110-115) or at the block size (no crop: DESIGN §2 D4).
@@ -351,20 +352,19 @@ class ShapeFormerModel:
         there too); `sample`/`callback` are accepted and unused (as in the reference)."""
         c = torch.as_tensor(c_indices)
         z = torch.as_tensor(z_indices)
-        if z.shape[1] != 0:
-            raise NotImplementedError("sample_indices: continuing a non-empty z_indices is not supported (every caller of the "
-                                      "reference passes z_indices = c_indices[:, :0])")
         B, L_c, _ = c.shape
+        L_z = int(z.shape[1])
         rep = self.representer
         res = self.transformer.sample(c.to(torch.int32), torch.full((B,), L_c, dtype=torch.int32), max_steps=int(max_steps), top_k=top_k,
                                       top_p=top_p, temperature=temperature, best_in_first=best_in_first, mask_invalid=rep.mask_invalid,
                                       mask_invalid_completion=rep.mask_invalid_completion, seed=seed, stop_early=True, check_every=8,
-                                      return_logits=True, shared_prefix=bool(B > 1 and (c == c[:1]).all()))   # sample_n copies
-        x = res["samples"]
+                                      return_logits=True, z_tokens=z.to(torch.int32) if L_z else None,
+                                      shared_prefix=bool(B > 1 and L_z == 0 and (c == c[:1]).all()))   # sample_n copies
+        x = res["samples"]                                             # (B, L_z + steps, 2): the z prefix comes first (shapeformer.py:121)
         end = torch.tensor(self.end_tokens)
-        ended = (x == end[None, None, :]).any(-1).all(0)          # step j: no row without a stop token
-        n = int(torch.nonzero(ended)[0]) + 1 if bool(ended.any()) else x.shape[1]
-        return x[:, :n].to(rep.dev), [h[:, :n] for h in res["logits_history"]]
+        ended = (x[:, L_z:] == end[None, None, :]).any(-1).all(0)      # NEW step j: no row without a stop token (shapeformer.py:110-115)
+        n = int(torch.nonzero(ended)[0]) + 1 if bool(ended.any()) else x.shape[1] - L_z
+        return x[:, :L_z + n].to(rep.dev), [h[:, :n] for h in res["logits_history"]]
 
     @torch.no_grad()
     def sample(self, **sampling_kwargs):

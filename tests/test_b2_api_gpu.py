@@ -48,8 +48,51 @@ def test_sample_reproduces_the_reference_greedy_row_and_masked_logit_history(dev
     # x, logits_history alone
     x2, h2 = m.sample_indices(c1, c1[:, :0], int(t["steps"]), best_in_first=True, top_k=100, top_p=0.4)
     assert torch.equal(x2, x) and torch.equal(h2[0], hist[0])
-    with pytest.raises(NotImplementedError):
-        m.sample_indices(c1, c1[:, :2], 4)
+
+
+def test_sample_indices_continues_a_non_empty_z_prefix_like_the_reference(dev):
+    """shapeformer.py:54-70: `sampled` starts as cat(c_indices, z_indices) and generation continues after it; the loop counter
+    (the masker's step_j) restarts at 0, so the first NEW position is not constrained by mask_invalid; x = sampled[:, L_c:]
+    carries the prefix.  Fixture gpt_tiny_zprefix.npz = the REAL reference's run (oracle/make_golden.py): greedy row + masked
+    logits of row 0; the stochastic rows are checked against the oracle started from the same prefix (shared uniforms)."""
+    from oracle import gpt_oracle as GO, vqdif_oracle as VO
+    from shapeformer_amd import weights as W
+    t = np.load(os.path.join(G, "gpt_tiny_zprefix.npz"))
+    m = _model()
+    c1, zp, steps = torch.from_numpy(t["c_idx"]), torch.from_numpy(t["z_prefix"]), int(t["steps"])
+    Lz = zp.shape[1]
+    x, hist = m.sample_indices(c1, zp, steps, best_in_first=True, top_k=100, top_p=0.4, seed=1)
+    ref = t["ref_sampled"]
+    assert tuple(x.shape) == ref.shape and np.array_equal(x[:, :Lz].cpu().numpy(), t["z_prefix"]), "x = sampled[:, L_c:] starts with z"
+    assert np.array_equal(x[0].cpu().numpy(), ref[0]), "greedy row after a z prefix must equal the reference token for token"
+    n_new = ref.shape[1] - Lz
+    assert all(tuple(h.shape) == (3, n_new, 4097) for h in hist)
+    for i, key in enumerate(("ref_hist0_row0", "ref_hist1_row0")):
+        a, r = hist[i][0].numpy(), t[key]
+        fin = np.isfinite(r)
+        assert np.array_equal(np.isfinite(a), fin), "mask differs from the reference's (step counter must restart at the first new token)"
+        assert np.abs(a[fin] - r[fin]).max() < 1e-3
+    # every row (stochastic ones included) == the oracle continued from the same prefix under the shared uniforms
+    gsd = VO.to_torch_sd(W.make_state_dict(W.gpt_spec(n_embd=64, n_layers=(2, 1), block_size=96)))
+    cfg = GO.GPTCfg(n_embd=64, n_head=4, n_layers=(2, 1), block_size=96)
+    res = m.transformer.sample(c1.to(torch.int32), torch.full((3,), c1.shape[1], dtype=torch.int32), max_steps=steps, seed=1, stop_early=False,
+                               z_tokens=zp.to(torch.int32), return_logits=True)
+    og, oh, _ = GO.sample_indices(gsd, cfg, c1, steps, GO.uniforms(1, steps, 3), use_cache=True, stop_early=False, z_indices=zp)
+    assert np.array_equal(res["samples"].numpy(), og) and np.array_equal(og, t["orc_sampled"])
+    for i in range(2):
+        a, r = res["logits_history"][i].numpy(), oh[i]
+        fin = np.isfinite(r)
+        assert np.array_equal(np.isfinite(a), fin) and np.abs(a[fin] - r[fin]).max() < 1e-3
+    # ragged rows + a prefix: row b's z tokens sit right after ITS condition
+    Lc = torch.tensor([c1.shape[1], c1.shape[1] - 3, c1.shape[1] - 6], dtype=torch.int32)
+    cr = c1.clone().to(torch.int32)
+    for b in range(3):
+        cr[b, int(Lc[b]) - 1:] = 4096
+    res2 = m.transformer.sample(cr, Lc, max_steps=6, seed=2, stop_early=False, z_tokens=zp.to(torch.int32))
+    for b in range(3):
+        ob, _, _ = GO.sample_indices(gsd, cfg, cr[b:b + 1, :int(Lc[b])].long(), 6, GO.uniforms(2, 6, 3)[:, :, b:b + 1], use_cache=True,
+                                     stop_early=False, z_indices=zp[b:b + 1], best_in_first=(b == 0))
+        assert np.array_equal(res2["samples"][b].numpy(), ob[0]), b
 
 
 def test_representer_methods_match_reference_vectors_and_oracle(dev):

@@ -126,7 +126,7 @@ def test_sampler_kernel_vs_oracle_filter(dev):
         seed = W._fnv1a32("sample-uniforms-9")
         L.check(L.lib().sfmi_gpt_sample_f32(L.ptr(dpart), L.ptr(dseq), L.ptr(dlen), L.ptr(dLc), None, L.ptr(hist), None,
                                             None, None, None, None, None, 0, 1, B,
-                                            V, Vpad, Lmax, 0, 4096, 4096, k, p, T, 0, 1, 1, 4, seed, None, 0, 0, B, L.stream_ptr()), "sample")
+                                            V, Vpad, Lmax, 0, 4096, 4096, k, p, T, 0, 1, 1, 4, seed, None, 0, 0, B, 0, L.stream_ptr()), "sample")
         got = dseq.cpu().numpy()[:, 5, 0]
         u = W.hash_unit("sample-uniforms-9", 4 * 2 * B).reshape(4, 2, B)
         idx = np.concatenate([seq[:, :5], np.zeros((B, 1, 2), np.int32)], 1)

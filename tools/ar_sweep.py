@@ -6,7 +6,8 @@ with HIP events, optionally with one kernel family disabled (timing-only ablatio
     python tools/ar_sweep.py --out gpurun_out/r3/ar_sweep.txt [--rows 320 --chains 4] < configs
 
 A configuration line is `name key=value ...`; keys: the sfmi_tune_set knobs (attn_blocks, attn_unroll, attn_waves,
-attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `fused=0|1` (gpt.FUSED_SLOTS).  Lines starting with # are skipped.
+attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `lanes=` / `rsteps=` (gpt.ROT_LANES / ROT_STEPS: lock-step
+chains in one graph with that many attention lanes).  Lines starting with # are skipped.
 Condition lengths are uniform in [100, 216] (mean 158 = the bench's synthetic clouds); positions ascending, end-token closed.
 """
 from __future__ import annotations
@@ -65,8 +66,7 @@ def main():
         kv = dict(x.split("=", 1) for x in kvs)
         rows, chains = int(kv.pop("rows", a.rows)), int(kv.pop("chains", a.chains))
         gpt._ablate = kv.pop("ablate", "")
-        if hasattr(gpt, "FUSED_SLOTS"):
-            gpt.FUSED_SLOTS = bool(int(kv.pop("fused", "0")))
+        gpt.ROT_LANES, gpt.ROT_STEPS = int(kv.pop("lanes", "0")), int(kv.pop("rsteps", "1"))
         for k, v in defaults.items():
             L.check(lib.sfmi_tune_set(k.encode(), int(kv.pop(k, v))), f"tune {k}")
         for k, v in kv.items():
