@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="keep the stage / AR-loop breakdown, skip the per-kernel roofline timings")
+    ap.add_argument("--no-subrecords", action="store_true", help="skip the config3 (batch-16 sampling) and train (one-rank training step) sub-records")
     ap.add_argument("--mode", default="complete", choices=["complete", "train"],
                     help="complete: the shapes/s metric (default); train: DDP training step of the transformer (BASELINE config 5)")
     ap.add_argument("--share-device", action="store_true",
@@ -218,15 +219,28 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
 def pmc_traffic(kernel, B):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic_B64.json: FETCH_SIZE
     doubled per the gfx950 correction + WRITE_SIZE); only valid for the configuration it was collected on."""
-    f = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_B{B}.json")     # collected at 64 rows (tools/pmc_run.sh)
-    if not os.path.exists(f):
-        f = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_B{B}.json")
-    if not os.path.exists(f):
+    f = None
+    for r in ("r03", "r02", "r01"):                                      # newest collection for this launch shape (tools/pmc_run.sh)
+        c = os.path.join(ROOT, "profiles", f"{r}_pmc_traffic_B{B}.json")
+        if os.path.exists(c):
+            f = c
+            break
+    if f is None:
         return None
     key = "dgemm_kernel" if kernel.startswith("dgemm_kernel") else "attn_decode_kernel"
     for k, v in json.load(open(f))["kernels"].items():
         if key in k:
             return v["hbm_bytes_per_launch"]
+    return None
+
+
+def pmc_traffic_source(B):
+    """Where `roofline.traffic` comes from: it is NOT measured in this run (PMC passes need rocprofv3 around the process)."""
+    for r in ("r03", "r02", "r01"):
+        f = os.path.join("profiles", f"{r}_pmc_traffic_B{B}.json")
+        if os.path.exists(os.path.join(ROOT, f)):
+            return (f"{f}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled per the gfx950 correction) of "
+                    f"tools/pmc_decode.py at {B} rows per launch, one chain; not re-measured in this run")
     return None
 
 
@@ -301,6 +315,74 @@ def cpu_baseline(points, ar_steps, decode_res):
                         f"({t_ar:.0f}s)"))
 
 
+def config3_record(pipe, gpt, Xct, a):
+    """BASELINE config 3 (ShapeFormer AR sampling, 512 tokens, batch 16), measured in the same run as the headline:
+    (i) `sample_n` route of VisShapeFormer.compute_batch (shapeformer.py:222-260): 16 sequences of ONE shape, the condition
+    prefilled once and its keys / values shared by the 16 rows (gpt.sample(shared_prefix=True)); (ii) plain batch 16: 16
+    different shapes through the whole path.  HBM-bound at 16 rows: one weight pass + the KV stream per step."""
+    HBM = 8000.0
+    enc = pipe.encode_cloud(Xct[:1])
+    Lc1 = int(enc["Lc"][0])
+    S = 16
+    ct = enc["c_tokens"][:1].expand(S, -1, -1).contiguous()
+    lt = enc["Lc"][:1].expand(S).contiguous()
+    kw = dict(max_steps=a.ar_steps, stop_early=False, to_host=False, best_in_first=False)
+    w_one = 4.0 * (sum(l.wqkv.numel() + l.wproj.numel() + l.wfc1.numel() + l.wfc2.numel() for l in gpt.layers) + sum(w.numel() for w in gpt.head_w))
+    rec = {}
+    for name, shared in (("sample_n16_shared_prefix", True), ("sample_n16_expanded", False)):
+        ts = []
+        for it in range(2):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            r = gpt.sample(ct, lt, seed=it, shared_prefix=shared, after_prefill=lambda: ev[0].record(), **kw)
+            ev[1].record(); torch.cuda.synchronize()
+            assert int(r["steps"]) == a.ar_steps
+            ts.append(ev[0].elapsed_time(ev[1]))
+        ms_step = min(ts) / a.ar_steps
+        # per step: one pass over the weights + K and V of every row at its mean cached length (shared rows read the condition once)
+        Lgen = (a.ar_steps - 1) / 2.0
+        kv = 2 * gpt.D * 4 * len(gpt.layers) * ((Lc1 + S * Lgen) if shared else S * (Lc1 + Lgen))
+        rec[name] = {"ms_per_step": round(ms_step, 4), "sequences_per_s": round(S / (min(ts) * 1e-3), 2),
+                     "ar_loop_ms": round(min(ts), 1), "L_c": Lc1,
+                     "roofline": {"bound": "hbm", "achieved": round((w_one + kv) / ms_step / 1e6, 1), "peak": HBM, "unit": "GB/s",
+                                  "frac": round((w_one + kv) / ms_step / 1e6 / HBM, 4),
+                                  "note": "algorithmic bytes per step = one weight pass (1.24 GB) + f32 K/V of the rows at the mean cached length"}}
+    X16 = Xct[:16].contiguous()
+    ts = []
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = pipe.complete(X16, max_steps=a.ar_steps, decode_res=a.decode_res, seed=it, stop_early=False, sigmoid=True)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    assert int(r["steps"]) == a.ar_steps
+    rec["batch16_whole_path"] = {"shapes_per_s": round(16 / min(ts[1:]), 2), "ms_per_step": round(min(ts[1:]) * 1e3, 1),
+                                 "note": "16 different shapes, encode -> 512 AR steps (one 16-row chain) -> UNet + 128^3 SDF query"}
+    rec["workload"] = "BASELINE config 3: ShapeFormer 24-layer AR sampling, 512 tokens, batch 16, 1 GPU (d = 1024 as in the shipped YAML)"
+    return rec
+
+
+def train_record(gpt, a, batches=(1, 8), steps=5, warm=2):
+    """BASELINE config 5 on ONE process, measured in the same run as the headline: the CondTupleGPT training step (forward, backward,
+    fused AdamW; no gradient collective with one rank) at the YAML's per-GPU batch 1 and at batch 8."""
+    from shapeformer_amd.train import GPTTrainer
+    F32 = 157.3
+    tr = GPTTrainer(gpt, lr=1e-5, dist=None)
+    rec = {"workload": "BASELINE config 5 on one rank: CondTupleGPT 20+4 layers d1024, fwd+bwd+AdamW, synthetic tokens L_c 200 + L_z 300", "dtype": "f32"}
+    for bs in batches:
+        c, z = synth_tokens(1000, bs, a.train_lc, a.train_lz)
+        for _ in range(warm):
+            loss = tr.training_step(c, z)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.training_step(c, z)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        tok = bs * (a.train_lc + a.train_lz - 1)
+        tf = 6 * 324.95e6 * tok / dt / 1e12
+        rec[f"batch{bs}"] = {"ms_per_step": round(dt * 1e3, 3), "tokens_per_s": round(tok / dt, 1), "loss": round(float(loss.item()), 4),
+                             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": F32, "unit": "TFLOP/s", "frac": round(tf / F32, 4),
+                                          "note": "model FLOPs 6 x 324.95 M parameters x tokens (attention FLOPs not counted)"}}
+    del tr
+    return rec
+
+
 def synth_tokens(seed, B, Lc, Lz):
     """(pos,val) rows like the representer emits: ascending positions, end-token padded (representers.py:79-103)."""
     rs = np.random.RandomState(seed)
@@ -322,12 +404,13 @@ def main_train(a, rank, world, dev, dist):
     from shapeformer_amd.gpt import CondTupleGPT
     from shapeformer_amd.train import GPTTrainer
     g = CondTupleGPT(device=dev)
-    tr = GPTTrainer(g, lr=1e-5, dist=dist)
+    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist)
     c, z = synth_tokens(1000 + rank, a.train_batch, a.train_lc, a.train_lz)
     losses = []
     for _ in range(a.warmup):
         losses.append(float(tr.training_step(c, z).item()))
     torch.cuda.synchronize()
+    tr.buckets.wait_ms()                  # drop the warm-up steps' records
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -344,6 +427,7 @@ def main_train(a, rank, world, dev, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     losses.append(float(loss.item()))
+    wait_ms = tr.buckets.wait_ms()        # mean stall of the compute stream in GradBuckets.finish() over the timed steps
     if rank == 0:
         tok = world * a.train_batch * (a.train_lc + a.train_lz - 1) * a.steps
         print(json.dumps({
@@ -353,6 +437,11 @@ def main_train(a, rank, world, dev, dist):
             "config": {"workload": "ShapeFormer DDP training step, synthetic IMNet-style token batches (BASELINE config 5)",
                        "batch_per_gpu": a.train_batch, "L_c": a.train_lc, "L_z": a.train_lz, "parallelism": f"dp{world}",
                        "grad_sync": "26 gradient buckets (one per block) all-reduced under the backward pass"},
+            "allreduce_wait_ms": None if wait_ms is None else round(wait_ms, 3),
+            "allreduce_wait_note": ("time per step the compute stream waits in GradBuckets.finish() for gradient collectives that are still "
+                                    "running after the last backward kernel = the EXPOSED communication (ms_per_step - this = compute); "
+                                    "null without a process group"),
+            "grad_bytes_per_step": int(tr.flat_grad.numel() * 4),
             "model_TFLOPs": round(6 * 324.95e6 * tok / dt / 1e12, 2),
             "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}), flush=True)
     if dist is not None:
@@ -491,15 +580,14 @@ def main():
                                                  "(sum ~ real), profiles/r02_decode_step_experiments.md")
             nm = a.micro or default_chains(B)
             Bk = -(-B // nm)     # rows per decode launch (micro-batch)
-            if a.no_kernels:
-                print(json.dumps(line), flush=True)
-                return
+        if not a.no_roofline and not a.no_kernels:
             ks = kernel_rooflines(vq, gpt, Bk, dev, lc_mean=sanity["Lc_mean"])
             # dominant kernel symbol of the decode step (>90 % of the run): the one with the larger per-layer time
             cands = [k for k in ks if k["kernel"].startswith(("dgemm_kernel", "attn_decode_kernel"))]
             dom = max(cands, key=lambda k: k["ms"])
             line["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                                 "frac": dom["frac"], "traffic": pmc_traffic(dom["kernel"], Bk), "kernel": dom["kernel"],
+                                "traffic_source": pmc_traffic_source(Bk),
                                 "rows_per_launch": Bk,
                                 "timing": ("isolated: one chain, hipGraph of 24 consecutive layers, HIP events (the per-launch average of the "
                                            "interleaved run is in profiles/: rocprofv3 --kernel-trace --stats)")}
@@ -509,6 +597,10 @@ def main():
                 line["roofline"]["all_chains_in_flight"] = {"achieved": line["ar_loop"]["gemm_only_TFLOPs"], "unit": "TFLOP/s",
                                                             "frac": round(line["ar_loop"]["gemm_only_TFLOPs"] / 157.3, 4)}
             line["kernels"] = ks
+        if world == 1 and not a.no_subrecords:
+            # BASELINE configs 3 and 5 in the same driver run (short: ~3 s + ~2 s), so that their numbers are not builder-only
+            line["config3"] = config3_record(pipe, gpt, Xct, a)
+            line["train"] = train_record(gpt, a)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline_kv"], line["cpu_baseline"] = cpu_baseline(a.points, a.ar_steps, a.decode_res)
         print(json.dumps(line), flush=True)

@@ -72,16 +72,21 @@ class GradBuckets:
     each large enough to run the ring at xGMI link rate.  gloo (CPU tests) takes the same path with SUM + scale.
     """
 
-    def __init__(self, flat: torch.Tensor, ranges: dict, dist):
+    def __init__(self, flat: torch.Tensor, ranges: dict, dist, single_rank_collectives=False):
+        """single_rank_collectives: run the collectives even in a 1-rank process group (a no-op numerically; bench.py --force-dist
+        uses it to exercise the RCCL ReduceOp.AVG bucket path on a 1-GPU box)."""
         self.flat, self.ranges, self.dist = flat, dict(ranges), dist
-        self.world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+        inited = dist is not None and dist.is_initialized()
+        self.world = dist.get_world_size() if inited else 1
+        self.active = inited and (self.world > 1 or single_rank_collectives)
         self.pending, self.done = [], set()
         self.avg = False
-        if self.world > 1:
+        if self.active:
             self.avg = dist.get_backend() == "nccl"     # RCCL averages in the collective; gloo has no AVG
+        self._wait_events = []                           # (before, after) HIP-event pairs around the waits of finish()
 
     def ready(self, name):
-        if self.world == 1 or name in self.done:
+        if not self.active or name in self.done:
             return
         lo, hi = self.ranges[name]
         op = self.dist.ReduceOp.AVG if self.avg else self.dist.ReduceOp.SUM
@@ -89,11 +94,17 @@ class GradBuckets:
         self.done.add(name)
 
     def finish(self):
-        """Launch whatever was never marked ready, wait for everything, return the bucket names in launch order."""
-        if self.world == 1:
+        """Launch whatever was never marked ready, wait for everything, return the bucket names in launch order.  On a HIP
+        device the compute stream's stall in these waits (collectives still running when the backward's last kernel is done
+        = the EXPOSED communication of the step) is bracketed by two events; `wait_ms()` reads them."""
+        if not self.active:
             return []
         for name in self.ranges:
             self.ready(name)
+        ev = None
+        if self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         order = []
         for name, work in self.pending:
             work.wait()
@@ -101,5 +112,19 @@ class GradBuckets:
             if not self.avg:
                 lo, hi = self.ranges[name]
                 self.flat[lo:hi].div_(self.world)
+        if ev is not None:
+            ev[1].record()
+            self._wait_events.append(ev)
         self.pending, self.done = [], set()
         return order
+
+    def wait_ms(self, reset=True):
+        """Mean time per finish() the compute stream spent waiting for gradient collectives since the last reset (ms); None
+        when nothing was recorded (CPU tensors / inactive).  Synchronises."""
+        if not self._wait_events:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events) / len(self._wait_events)
+        if reset:
+            self._wait_events = []
+        return ms

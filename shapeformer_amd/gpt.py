@@ -240,14 +240,18 @@ class CondTupleGPT:
         launch, so sampled tokens are bit-identical however the rows are split into chains.  PREFILL_BLAS_ROWS (None by
         default; SFMI_ROCBLAS=1 sets 2048) sends long prefills to the library sgemm instead - its kernel choice depends on M,
         so that identity then holds only to fp32 rounding."""
+        calls = self.__dict__.setdefault("_gemm_calls", {"blas": 0, "sgemm": 0, "tile": 0})   # which kernel ran (tests / diagnostics)
         if self.PREFILL_BLAS_ROWS is not None and M >= self.PREFILL_BLAS_ROWS and not og and N % 4 == 0 and self._blas() \
                 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
+            calls["blas"] += 1
             L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
             return
         if not og and N % 4 == 0 and K % 4 == 0 and not self.PREFILL_TILE_KERNEL:
+            calls["sgemm"] += 1
             L.check(L.lib().sfmi_sgemm_mfma_f32(0, 1, M, N, K, L.ptr(x), K, L.ptr(w), K, L.ptr(y), N, 0, L.ptr(bias), act, L.ptr(resid),
                                                 None, 0, 0.0, 0, L.stream_ptr()), "sfmi_sgemm_mfma_f32")
             return
+        calls["tile"] += 1
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, og, ogs,
                                       L.stream_ptr()), "sfmi_gemm_f32")
 

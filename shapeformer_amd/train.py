@@ -25,7 +25,8 @@ def _ru(x, m):
 
 
 class GPTTrainer:
-    def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0):
+    def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0,
+                 single_rank_collectives=False):
         self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
         # (embd_pdrop, resid_pdrop, attn_pdrop): the model's (CondTupleGPT ctor kwargs / YAML) unless given
         self.pdrop = tuple(float(v) for v in (pdrop if pdrop is not None else getattr(gpt, "pdrop", (0.0, 0.0, 0.0))))
@@ -68,7 +69,7 @@ class GPTTrainer:
         rng["heads"] = (off["head0.ln.w"][0], off["head1.w"][1])
         rng["emb"] = (off["E0"][0], off["cond_pos_emb"][1])
         from .dist import GradBuckets
-        self.buckets = GradBuckets(self.flat_grad, rng, dist)
+        self.buckets = GradBuckets(self.flat_grad, rng, dist, single_rank_collectives=single_rank_collectives)
         self._sync = False
 
     # ------------------------------------------------------------------ small wrappers

@@ -103,6 +103,13 @@ def test_bench_launches_its_own_ranks(dev):
     import json
     line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1 and line[0]["n_gpus"] == 2 and line[0]["config"]["parallelism"] == "shard2"
+    # the training line (BASELINE config 5) the same way: 2 ranks, gradient buckets all-reduced under the backward (gloo here)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--mode", "train", "--steps", "2",
+                        "--warmup", "1", "--train-lc", "24", "--train-lz", "40"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and line[0]["n_gpus"] == 2 and line[0]["config"]["parallelism"] == "dp2" and line[0]["unit"] == "tokens/s"
+    assert line[0]["allreduce_wait_ms"] is not None and line[0]["allreduce_wait_ms"] >= 0 and line[0]["grad_bytes_per_step"] > 1.2e9
     # and the guard: asking for more ranks than GPUs is an error, never a silent 1-rank run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "only" in (r.stdout + r.stderr)
@@ -125,3 +132,16 @@ def test_bench_rccl_path_with_one_rank(dev):
     assert r.returncode == 0, r.stdout + r.stderr
     line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1 and line[0]["n_gpus"] == 1 and line[0]["value"] > 0
+    # --mode train under the same launcher: the 26 gradient buckets go through RCCL all_reduce(ReduceOp.AVG, async_op=True) fired
+    # from inside the backward (a one-rank group: numerically a no-op, the calls / stream ordering / waits are the real ones)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--mode", "train",
+                        "--steps", "2", "--warmup", "1", "--train-lc", "24", "--train-lz", "40"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and line[0]["n_gpus"] == 1 and line[0]["unit"] == "tokens/s" and np.isfinite(line[0]["loss_last"])
+    assert line[0]["allreduce_wait_ms"] is not None, "the RCCL bucket path did not run"
