@@ -142,6 +142,12 @@ int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex,
  * of one condition (shapeformer.py:222-260) keep the condition's keys / values once */
 int sfmi_gpt_attn_decode_f32(const float* qkv_packed, const float* unused, float* Kc, float* Vc, const int* len, float* y_packed,
                              int S, int B, int D, int H, int Lmax, const int* shared_len, void* stream);
+/* the same behind the attention turnstile of the interleaved decode chains (no reference counterpart: the reference runs one
+ * chain): sem = 3 device ints {next ticket, finished launches, gate time-outs} shared by all chains, zeroed by the caller while
+ * nothing is in flight; blk = 1 zeroed device int per chain; at most `lanes` gated launches stream their KV cache at a time, in
+ * ticket order.  Scheduling only - results are those of sfmi_gpt_attn_decode_f32.  sem == NULL: no turnstile. */
+int sfmi_gpt_attn_decode_gated_f32(const float* qkv_packed, float* Kc, float* Vc, const int* len, float* y_packed, int B, int D, int H,
+                                   int Lmax, const int* shared_len, int* sem, int* blk, int lanes, void* stream);
 /* one tuple element of one sampling step per row: sampling_masker (representers.py:120-155) + filter_sampling_logits /
  * sample_logits (models/common.py:260-299: temperature, top-k with ties, top-p) + inverse-CDF draw from counter-hash uniforms
  * indexed (step, tuple, row_offset + b) + best_in_first greedy row + log-prob + optional masked-logit history; writes the

@@ -564,6 +564,8 @@ struct AttnArgs {
   const int* len; float* y /*fragment-packed (M x D)*/;
   const int* shared_len;
   int B, H, D, Lmax, HD; float scale;
+  int* sem;      // optional turnstile words {next ticket, finished launches, gate time-outs}: the LAST workgroup of a launch bumps sem[1]
+  int* blk;      // this chain's finished-workgroup counter (re-armed by the last workgroup)
 };
 template <int NWV>
 struct AttnLds {
@@ -693,6 +695,32 @@ __global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : 4) void attn_decode_kernel(A
     const int h = __builtin_amdgcn_readfirstlane(it / a.B);   // wave-uniform: keeps the cache bases in scalar registers
     attn_decode_item<NWV, U>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
     if (it + (int)gridDim.x < nitems) __syncthreads();   // the next item rewrites the hand-off tiles
+  }
+  if (a.sem && threadIdx.x == 0) {     // turnstile release: the launch's last workgroup to finish admits the next KV stream
+    if (__hip_atomic_fetch_add(a.blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(a.blk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(a.sem + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Turnstile in front of a decode-attention launch (one wavefront): takes a ticket and waits until fewer than `lanes` of the
+// earlier tickets are still streaming.  The decode chains are independent hipGraphs on separate hardware queues; without the
+// turnstile two or three of them are in their attention phase at any time, those launches together take every wave slot and
+// vector register of every CU, and the other chains' GEMM workgroups cannot be placed until one of them drains: HBM-bound and
+// MFMA-bound phases then time-share the chip instead of overlapping (profiles/r03_ar_overlap.md).  With at most `lanes` KV
+// streams resident - each sized to saturate HBM with half of a CU's registers - a GEMM workgroup always fits beside them.
+// Carries no data (pure scheduling): a wrong order can only cost time.  A wait longer than 20 ms gives up and counts in sem[2].
+__global__ __launch_bounds__(64) void attn_gate_kernel(int* sem, int lanes) {
+  if (threadIdx.x != 0) return;
+  const int my = __hip_atomic_fetch_add(sem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+  while (__hip_atomic_load(sem + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + lanes <= my) {
+    __builtin_amdgcn_s_sleep(8);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) {
+      __hip_atomic_fetch_add(sem + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
   }
 }
 
@@ -1307,13 +1335,17 @@ int sfmi_tune_get(const char* name) {
   return -1;
 }
 
-// replaces CausalSelfAttention.forward for ONE new position per row with a KV cache (mingpt.py:73-91)
-int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc, float* Vc, const int* len, float* y,
-                             int S, int B, int D, int H, int Lmax, const int* shared_len, void* stream) {
-  if (!qkv_part || !bqkv || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
+// replaces CausalSelfAttention.forward for ONE new position per row with a KV cache (mingpt.py:73-91).
+// sem (optional, 3 device ints zeroed by the caller while no launch is in flight) + blk (1 device int, zero; one per chain):
+// the launch passes the attention turnstile first (at most `lanes` gated launches stream at a time, FIFO).
+int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, const int* len, float* y, int B, int D, int H,
+                                   int Lmax, const int* shared_len, int* sem, int* blk, int lanes, void* stream) {
+  if (!qkv_part || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
+  if (sem && (!blk || lanes <= 0)) return SFMI_EINVAL;
   AttnArgs a;
   a.qkv = qkv_part; a.Kc = Kc; a.Vc = Vc; a.len = len; a.y = y; a.shared_len = shared_len;
   a.B = B; a.H = H; a.D = D; a.Lmax = Lmax; a.HD = D / H; a.scale = 1.0f / sqrtf((float)a.HD);
+  a.sem = sem; a.blk = blk;
   const int nitems = B * H;
   const int grid = g_tune.attn_blocks > 0 ? min(g_tune.attn_blocks, nitems) : nitems;
   const size_t pad = (size_t)g_tune.attn_lds_pad;
@@ -1326,12 +1358,18 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
 #undef AT_ATTR
   });
   if (pad && attr_err != hipSuccess) return (int)attr_err;
+  if (sem) hipLaunchKernelGGL(attn_gate_kernel, dim3(1), dim3(64), 0, st, sem, lanes);
 #define AT(W_, U_) hipLaunchKernelGGL((attn_decode_kernel<W_, U_>), dim3(grid), dim3(64 * W_), pad, st, a)
   if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else if (g_tune.attn_unroll == 2) AT(16, 2); else AT(16, 4); }
   else { if (g_tune.attn_unroll == 8) AT(8, 8); else if (g_tune.attn_unroll == 2) AT(8, 2); else AT(8, 4); }
 #undef AT
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
+}
+int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc, float* Vc, const int* len, float* y,
+                             int S, int B, int D, int H, int Lmax, const int* shared_len, void* stream) {
+  if (!bqkv) return SFMI_EINVAL;
+  return sfmi_gpt_attn_decode_gated_f32(qkv_part, Kc, Vc, len, y, B, D, H, Lmax, shared_len, nullptr, nullptr, 0, stream);
 }
 
 // causal self-attention over the conditioning prefix (positions 0..Lc[b]-2), also fills the KV caches

@@ -77,6 +77,7 @@ class CondTupleGPT:
         #                 family is not launched, sampled tokens are garbage; part of the hipGraph cache key
         self._force_wide = False
         self._ablate = ""
+        self._sem = torch.zeros(4, device=self.dev, dtype=torch.int32)   # attention turnstile {next ticket, finished, time-outs}
 
     def get_block_size(self):
         return self.Lmax
@@ -196,6 +197,7 @@ class CondTupleGPT:
                   slab=f(L.lib().sfmi_decode_gemm_slab_floats(Bp, 4 * D, 4)), cnt=torch.zeros(Bp // 16 * (max(4 * D, self.Vpad) // 16 + 1), device=dev, dtype=torch.int32),
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32),
+                  blk=torch.zeros(1, device=dev, dtype=torch.int32),      # attention turnstile: this chain's finished-workgroup counter
                   shared=torch.zeros(1, device=dev, dtype=torch.int32),  # shared-prefix length of the sample_n mode (device-resident)
                   seed=torch.zeros(1, device=dev, dtype=torch.int32))   # sampler seed (device-resident: graphs are seed-independent)
         self._state = st
@@ -393,34 +395,32 @@ class CondTupleGPT:
         return loss / 2
 
     # ------------------------------------------------------------------ one decode step (graph-capturable)
+    # Attention turnstile of the interleaved decode chains (csrc/gpt.hip:attn_gate_kernel): > 0 = at most this many chains stream
+    # their KV cache at the same time (FIFO tickets in device memory); the other chains' GEMM workgroups then always find room
+    # on every CU.  0 = off (independent chains, round 2 behaviour).  Scheduling only: tokens / logits are bit-identical.
+    ATTN_LANES = 0
+
     def decode_step(self, st, B, sp):
         """Position t = len[b]-1 of every row through both stages; st["resid"] must hold its embedding on entry
         (written by the previous step's sampler tail, or by `_embed` before the first step)."""
-        for _ in self._decode_step_iter(st, B, sp):
-            pass
-
-    def _decode_step_iter(self, st, B, sp):
-        """The launches of one decode step as a generator that yields just BEFORE ("pre_attn", layer) and just AFTER
-        ("post_attn", layer) every attention launch: the lock-step scheduler (`_rot_steps`) puts its cross-chain
-        dependencies there; `decode_step` simply exhausts it."""
         D = self.D
         lib = L.lib()
         r = st["resid"]
         skip = self._ablate                               # timing-only ablation hook (see __init__): results are garbage
         if "@" in skip:      # per-chain form "gemm@0,attn@1,attn@2": chain index = micro-batch slot
             skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
+        lanes = int(sp.get("gate_lanes", 0))
         # in-kernel split-K per GEMM: 64-row kernel (B <= 64) / wide kernel (one launch for up to 256 rows)
         Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if (B > 96 or self._force_wide) else (1, self.S_PROJ if B <= 16 else self.S_PROJ_M, 1, self.S_FC2, 1)
         for li, ly in enumerate(self.layers):
             if "gemm" not in skip:
                 self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
-            yield "pre_attn", li
             if "attn" not in skip:
-                L.check(lib.sfmi_gpt_attn_decode_f32(L.ptr(st["qkv"]), L.ptr(self.zero_bqkv), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
-                                                     L.ptr(st["len"]), L.ptr(st["y"]), 1, B, D, self.H, self.Lmax + 1,
-                                                     L.ptr(st["shared"]) if sp.get("shared_prefix") else None,
-                                                     L.stream_ptr()), "sfmi_gpt_attn_decode_f32")
-            yield "post_attn", li
+                L.check(lib.sfmi_gpt_attn_decode_gated_f32(L.ptr(st["qkv"]), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
+                                                           L.ptr(st["len"]), L.ptr(st["y"]), B, D, self.H, self.Lmax + 1,
+                                                           L.ptr(st["shared"]) if sp.get("shared_prefix") else None,
+                                                           L.ptr(self._sem) if lanes else None, L.ptr(st["blk"]) if lanes else None, lanes,
+                                                           L.stream_ptr()), "sfmi_gpt_attn_decode_gated_f32")
             if "gemm" not in skip:
                 self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st)
                 self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st)
@@ -440,79 +440,9 @@ class CondTupleGPT:
                                                 sp.get("row_offset", 0), sp.get("rows_total", B), int(sp.get("step_offset", 0)),
                                                 L.stream_ptr()), "sfmi_gpt_sample_f32")
 
-    # ------------------------------------------------------------------ lock-step chains: ONE graph for all chains
-    ROT_LANES = 0          # > 0: sample_microbatched runs its chains in lock-step (see _rot_steps) with this many attention lanes
-    ROT_STEPS = 1          # decode steps captured per lock-step graph (amortises the join at the end of a replay)
-
-    def _rot_steps(self, ctxs, streams, lanes, nsteps):
-        """`nsteps` decode steps of ALL chains, issued on the chains' streams with cross-chain dependencies that serialise the
-        attention launches: lane k holds the chains k, k+lanes, ...; within a lane the attention of (chain c, layer l) starts
-        only when the lane's previous attention - (chain c-lanes, layer l), or the last chain's (l-1) - has finished.  So at
-        most `lanes` KV streams are in flight at any time (each sized to saturate HBM on its own, with a resident footprint
-        that leaves room for GEMM workgroups on every CU), and the other chains' GEMMs run beside them instead of queueing
-        behind two or three chip-filling attention kernels (profiles/r03_ar_overlap.md).  Under stream capture the event
-        waits become graph edges: one hipGraph replays the step of every chain."""
-        its = [None] * len(ctxs)
-        last = [None] * lanes          # last attention event of every lane
-        for _ in range(nsteps):
-            its = [self._decode_step_iter(c["st"], c["B"], c["sp"]) for c in ctxs]
-            for li in range(len(self.layers)):
-                for ci, (c, s) in enumerate(zip(ctxs, streams)):
-                    with torch.cuda.stream(s):
-                        tag = next(its[ci])                 # previous layer's tail + this layer's qkv
-                        assert tag == ("pre_attn", li)
-                        lane = ci % lanes
-                        if last[lane] is not None:
-                            s.wait_event(last[lane])
-                        assert next(its[ci]) == ("post_attn", li)
-                        ev = torch.cuda.Event()
-                        ev.record(s)
-                        last[lane] = ev
-            for ci, s in enumerate(streams):            # the last layer's tail (proj, MLP, head, sampler)
-                with torch.cuda.stream(s):
-                    for _t in its[ci]:
-                        raise AssertionError("decode step iterator out of step")
-
-    def _rot_graph(self, ctxs, streams, lanes, nsteps):
-        """Capture `_rot_steps` into one hipGraph (fork from / join to the capture stream)."""
-        key = ("rot", lanes, nsteps, tuple((c["B"], tuple(sorted((k, v) for k, v in c["sp"].items() if k not in ("hist", "force", "seed"))),
-                                            tuple(h.data_ptr() for h in (c["hist"] or ()))) for c in ctxs),
-               self._ablate, self._force_wide, self.S_PROJ, self.S_PROJ_M, self.S_FC2)
-        cached = self._graphs.get("rot")
-        if cached is not None and cached[0] == key:
-            return cached[1]
-        keep = ("seq", "len", "logp", "resid")
-        saved = [{k: c["st"][k].clone() for k in keep} for c in ctxs]
-        cur = torch.cuda.current_stream()
-        for s in streams:
-            s.wait_stream(cur)
-        self._rot_steps(ctxs, streams, lanes, 1)      # warm-up outside capture
-        for s in streams:
-            cur.wait_stream(s)
-        torch.cuda.synchronize()
-        for c, sv in zip(ctxs, saved):
-            for k in keep:
-                c["st"][k].copy_(sv[k])
-        cap = torch.cuda.Stream(device=self.dev)
-        cap.wait_stream(cur)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=cap):
-            for s in streams:
-                s.wait_stream(cap)
-            self._rot_steps(ctxs, streams, lanes, nsteps)
-            for s in streams:
-                cap.wait_stream(s)
-        cur.wait_stream(cap)
-        for c, sv in zip(ctxs, saved):
-            for k in keep:
-                c["st"][k].copy_(sv[k])
-        torch.cuda.synchronize()
-        self._graphs["rot"] = (key, graph)
-        return graph
-
     # ------------------------------------------------------------------ sample_indices
     def _prepare(self, c_tokens, Lc, max_steps, sp_kw, slot=0, row_offset=0, rows_total=None, return_logits=False,
-                 force_tokens=None, use_graph=True, shared_prefix=False, z_tokens=None):
+                 force_tokens=None, use_graph=True, shared_prefix=False, z_tokens=None, gate_lanes=0):
         """State + prefill + step-0 embedding + (cached) hipGraph of one decode step for one (micro-)batch.
         z_tokens (B,L_z,2): tokens already generated after the condition (shapeformer.py:60-70 copies cat(c, z) into `sampled`):
         they are prefilled together with the condition and sampling continues after them; the step counter restarts at 0."""
@@ -542,7 +472,7 @@ class CondTupleGPT:
             hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
         sp = dict(sp_kw, max_steps=int(max_steps), hist=hist, row_offset=int(row_offset),
                   rows_total=int(rows_total if rows_total is not None else B), chain=int(slot - 100 if slot >= 100 else 0),
-                  shared_prefix=bool(shared_prefix), step_offset=Lz)
+                  shared_prefix=bool(shared_prefix), step_offset=Lz, gate_lanes=int(gate_lanes))
         if force_tokens is not None:   # (B,max_steps,2) teacher forcing for stepwise parity tests
             ft = torch.zeros(B, max_steps, 2, dtype=torch.int32)
             ft[:, :force_tokens.shape[1]] = torch.as_tensor(force_tokens).to(torch.int32)
@@ -696,6 +626,7 @@ class CondTupleGPT:
             import warnings
             warnings.warn(f"only {len(chosen)} of {n} decode chains get a hardware queue of their own; the others share one")
             chosen += spare[:n - len(chosen)]
+            self._mb_shared_queue = True
         self._mb_streams = chosen
         return chosen[:n]
 
@@ -712,7 +643,9 @@ class CondTupleGPT:
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
         streams = self._chain_streams(len(groups))
         cur = torch.cuda.current_stream()
-        rot_mode = self.ROT_LANES > 0 and len(groups) > 1      # lock-step: one graph for all chains instead of one per chain
+        # attention turnstile (ATTN_LANES): only when every chain owns a hardware queue - a gate kernel spinning at the head of a
+        # shared queue would hold up the very launch it waits for (it gives up after 20 ms, but that is no way to run)
+        lanes = self.ATTN_LANES if (self.ATTN_LANES > 0 and len(groups) > self.ATTN_LANES and not getattr(self, "_mb_shared_queue", False)) else 0
         ctxs = []
         # every chain's prefill is issued on that chain's own stream: the chains' GEMMs / attention launches then fill each
         # other's last partial round of workgroups (a 10k-row x 1024-column GEMM is 632 tiles for 512 resident slots), and the
@@ -721,14 +654,14 @@ class CondTupleGPT:
             streams[i].wait_stream(cur)
             with torch.cuda.stream(streams[i] if self.PREFILL_ON_CHAIN_STREAMS else cur):
                 ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B,
-                                          return_logits=return_logits, use_graph=not rot_mode))
+                                          return_logits=return_logits, gate_lanes=lanes))
         steps = min(c["steps"] for c in ctxs)
-        rot = None
-        if rot_mode and steps > 1:
+        if lanes:                      # re-arm the turnstile while nothing of the decode loop is in flight
             for s in streams:
                 cur.wait_stream(s)
-            rot_n = self.ROT_STEPS if (steps % self.ROT_STEPS == 0 and (not stop_early or check_every % self.ROT_STEPS == 0)) else 1
-            rot = self._rot_graph(ctxs, streams, min(self.ROT_LANES, len(ctxs)), rot_n)
+            self._sem.zero_()
+            for c in ctxs:
+                c["st"]["blk"].zero_()
             for s in streams:
                 s.wait_stream(cur)
         if after_prefill is not None:
@@ -738,17 +671,7 @@ class CondTupleGPT:
             for s in streams:
                 s.wait_stream(cur)
         done = 0
-        if rot is not None:
-            for s in streams:
-                cur.wait_stream(s)
-            while done < steps:
-                n = min(check_every, steps - done) if stop_early else steps - done
-                for _ in range(n // rot_n):
-                    rot.replay()                       # one replay = rot_n steps of every chain
-                done += n
-                if stop_early and all(self._all_ended(c["st"], c["B"]) for c in ctxs):
-                    break
-        while rot is None and done < steps:
+        while done < steps:
             n = min(check_every, steps - done) if stop_early else steps - done
             for _ in range(n):
                 for c, s in zip(ctxs, streams):

@@ -6,8 +6,8 @@ with HIP events, optionally with one kernel family disabled (timing-only ablatio
     python tools/ar_sweep.py --out gpurun_out/r3/ar_sweep.txt [--rows 320 --chains 4] < configs
 
 A configuration line is `name key=value ...`; keys: the sfmi_tune_set knobs (attn_blocks, attn_unroll, attn_waves,
-attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `lanes=` / `rsteps=` (gpt.ROT_LANES / ROT_STEPS: lock-step
-chains in one graph with that many attention lanes).  Lines starting with # are skipped.
+attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `lanes=` (gpt.ATTN_LANES: attention turnstile, at most that many
+chains stream their KV cache at a time).  Lines starting with # are skipped.
 Condition lengths are uniform in [100, 216] (mean 158 = the bench's synthetic clouds); positions ascending, end-token closed.
 """
 from __future__ import annotations
@@ -66,7 +66,7 @@ def main():
         kv = dict(x.split("=", 1) for x in kvs)
         rows, chains = int(kv.pop("rows", a.rows)), int(kv.pop("chains", a.chains))
         gpt._ablate = kv.pop("ablate", "")
-        gpt.ROT_LANES, gpt.ROT_STEPS = int(kv.pop("lanes", "0")), int(kv.pop("rsteps", "1"))
+        gpt.ATTN_LANES = int(kv.pop("lanes", "0"))
         for k, v in defaults.items():
             L.check(lib.sfmi_tune_set(k.encode(), int(kv.pop(k, v))), f"tune {k}")
         for k, v in kv.items():
@@ -89,8 +89,9 @@ def main():
                 assert int(r["steps"]) == a.steps
                 if rep:
                     ms.append(ev[0].elapsed_time(ev[1]) / a.steps)
-            say(f"{name:28s} rows {rows} chains {chains} ablate '{gpt._ablate}' {' '.join(kvs):40s} ms/step " + " ".join(f"{m:.3f}" for m in ms)
-                + f"   rows/ms {rows / min(ms):.1f}")
+            sem = gpt._sem.cpu().tolist()
+            say(f"{name:28s} rows {rows} chains {chains} {' '.join(kvs):50s} ms/step " + " ".join(f"{m:.3f}" for m in ms)
+                + f"   rows/ms {rows / min(ms):.1f}" + (f"   turnstile tickets {sem[0]} time-outs {sem[2]}" if gpt.ATTN_LANES else ""))
         except Exception as e:   # keep sweeping
             say(f"{name:28s} FAILED: {type(e).__name__}: {e}")
             torch.cuda.synchronize()
