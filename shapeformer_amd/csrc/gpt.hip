@@ -21,6 +21,39 @@
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// tuning hooks (performance only: none of them changes a result bit unless stated).  Set through sfmi_tune_set(name, value) by
+// bench.py / tools/ar_sweep.py; read at LAUNCH time, i.e. baked into a captured hipGraph (re-capture after changing one).
+//   attn_blocks : 0 = one workgroup per (row, head) item; n > 0 = persistent grid of n workgroups striding over the items
+//   attn_unroll : float4 loads in flight per lane (2, 4 or 8)
+//   attn_waves  : 16 or 8 waves per workgroup (NOT bit-identical to each other: different summation order)
+//   attn_lds_pad: extra dynamic LDS bytes per workgroup (caps resident workgroups per CU)
+//   dgemm_pipe  : 1 = decode GEMM main loop with the wave's whole weight slice requested up front + double-buffered activations
+//                 (latency-tolerant form for launches that run beside a KV stream); same arithmetic order, bit-identical
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, dgemm_pipe; };
+static SfmiTune g_tune = {0, 4, 16, 0, 0};
+extern "C" int sfmi_tune_set(const char* name, int value) {
+  if (!name) return SFMI_EINVAL;
+  const std::string n(name);
+  if (n == "attn_blocks" && value >= 0) g_tune.attn_blocks = value;
+  else if (n == "attn_unroll" && (value == 2 || value == 4 || value == 8)) g_tune.attn_unroll = value;
+  else if (n == "attn_waves" && (value == 8 || value == 16)) g_tune.attn_waves = value;
+  else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) g_tune.attn_lds_pad = value;
+  else if (n == "dgemm_pipe" && (value == 0 || value == 1)) g_tune.dgemm_pipe = value;
+  else return SFMI_EINVAL;
+  return SFMI_OK;
+}
+extern "C" int sfmi_tune_get(const char* name) {
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "attn_blocks") return g_tune.attn_blocks;
+  if (n == "attn_unroll") return g_tune.attn_unroll;
+  if (n == "attn_waves") return g_tune.attn_waves;
+  if (n == "attn_lds_pad") return g_tune.attn_lds_pad;
+  if (n == "dgemm_pipe") return g_tune.dgemm_pipe;
+  return -1;
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // rowprep
 // ------------------------------------------------------------------------------------------------
@@ -185,10 +218,23 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
 #ifndef DG_MFMA
 #define DG_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 #endif
-template <int MT, int NW, int UN>
-__global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[NW][MT][4][64];
-  __shared__ float st1[NW][MT][16], st2[NW][MT][16];
+template <int MT, int NW, int UN, int PIPE = 0>
+__global__ __launch_bounds__(64 * NW, PIPE ? 4 : 1) void dgemm_kernel(DGemmArgs a) {   // PIPE: <= 128 VGPRs (a workgroup must fit beside a KV stream)
+  // LDS: the cross-wave reduction tiles + LayerNorm statistics.  PIPE: dynamic LDS - the waves' weight slices (NW x 8 KiB, LDS-DMA)
+  // come first and the reduction tiles reuse that space after the main loop; the statistics sit behind it.
+  extern __shared__ __attribute__((aligned(16))) float dg_dyn[];
+  float (*red)[MT][4][64];
+  float (*st1)[MT][16], (*st2)[MT][16];
+  if constexpr (PIPE) {
+    static_assert(MT * 256 <= 2048, "the reduction tiles must fit in the weight slices they replace");
+    red = reinterpret_cast<float (*)[MT][4][64]>(dg_dyn);
+    st1 = reinterpret_cast<float (*)[MT][16]>(dg_dyn + NW * 2048);
+    st2 = st1 + NW;
+  } else {
+    __shared__ __attribute__((aligned(16))) float red_s[NW][MT][4][64];
+    __shared__ float st1_s[NW][MT][16], st2_s[NW][MT][16];
+    red = red_s; st1 = st1_s; st2 = st2_s;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, ml = lane & 15;
   const int nt = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
   const int kslice = a.K / S;
@@ -211,11 +257,14 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   const int n_ep = nt * 16 + 4 * q;
   const long long off_ep = a.out_packed ? (((long long)wave * (a.N >> 4) + nt) * 64 + lane) * 4
                                         : (long long)min(wave * 16 + ml, a.M - 1) * a.ldo + n_ep;
-  if (wave < MT && n_ep < a.N) {
-    if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
-    if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
-    if (a.resid) pres = *reinterpret_cast<const f32x4*>(a.resid + off_ep);
-  }
+  auto load_epilogue_operands = [&]() {
+    if (wave < MT && n_ep < a.N) {
+      if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
+      if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
+      if (a.resid) pres = *reinterpret_cast<const f32x4*>(a.resid + off_ep);
+    }
+  };
+  if constexpr (!PIPE) load_epilogue_operands();   // (PIPE: after the main loop - 12 registers it cannot spare - under the LDS reduction)
   const int steps = kw / 16;
   // software pipeline over batches of UN k16-steps: the loads of batch b+1 are issued BEFORE the MFMAs of batch b
   // (two register sets, statically indexed), and every load of a batch is pinned ahead of the first MFMA that
@@ -240,8 +289,46 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
         acc[j][e & 1] = DG_MFMA(wv[e], xv[e], acc[j][e & 1]);
     }
   };
+  if constexpr (PIPE == 1) {
+    // latency-tolerant form (host guarantees steps == 8): the wave's WHOLE weight slice (8 x 1 KiB, the only HBM traffic of the
+    // launch) goes to LDS by DMA at t = 0 - no registers, ONE HBM round trip per launch instead of one per batch (beside a
+    // saturating KV stream that round trip is 3-4x the unloaded one) - and the activation fragments (L2 hits) are double-buffered
+    // one step ahead in registers.  The fragment order of Wp16 is lane-linear, which is exactly what an LDS-DMA writes
+    // (base + lane x 16 B), and each wave reads back only its own slice: no barrier, conflict-free ds_read_b128.
+    // Same k order, same accumulator chains: bit-identical to the batched form.
+    float* wl = dg_dyn + wave * 2048;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + u * 64 + lo),
+                                       (__attribute__((address_space(3))) void*)(wl + u * 256), 16, 0, 0);
+    f32x4 xa[MT], xc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) xa[j] = xr[j][lo];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slices landed (the issuing wave is the only reader) + first activations
+    const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
+    // rolled on purpose: with the 8 steps unrolled hipcc lets the accumulator chains wander through fresh registers (the MFMA's
+    // destination need not be its C operand) and the kernel spills; a loop-carried accumulator stays where it is
+#pragma unroll 1
+    for (int s2 = 0; s2 < 8; s2 += 2) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) xc[j] = xr[j][XIDX((s2 + 1) * 64) + lo];
+      const f32x4 w0 = wf[s2 * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(w0, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      const int sn = min(s2 + 2, 7);       // (the last iteration re-reads step 7: one wasted, cached fragment set instead of a branch)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) xa[j] = xr[j][XIDX(sn * 64) + lo];
+      const f32x4 w1 = wf[(s2 + 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(w1, xc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_epilogue_operands();
+    __syncthreads();        // every wave is done with its weight slice: the reduction tiles may overwrite them
+  } else
   // batches of UN k16-steps: UN weight + UN*MT activation loads in flight, all pinned ahead of the MFMAs
-  // (measured alternatives for MT > 1 — two-deep register pipeline, up-front weight preload — were 4-6 % slower)
+  // (measured alternatives for MT > 1 — two-deep register pipeline, up-front weight preload — were 4-6 % slower in isolation)
   for (int s0 = 0; s0 < steps; s0 += UN) {
     f32x4 w[UN], xb[UN][MT];
 #pragma unroll
@@ -1264,6 +1351,23 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
     else return SFMI_EINVAL;
   }
   else if (NWv == 1) { if (MT == 1) DG(1, 1, 1); else return SFMI_EINVAL; }
+  else if (g_tune.dgemm_pipe == 1 && steps == 8 && MT >= 3) {
+    constexpr int kPipeLds = (8 * 2048 + 2 * 8 * 6 * 16) * 4;    // weight slices + statistics (MT <= 6): 71 680 B
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+      const void* ks[4] = {(const void*)dgemm_kernel<3, 8, 1, 1>, (const void*)dgemm_kernel<4, 8, 1, 1>, (const void*)dgemm_kernel<5, 8, 1, 1>,
+                           (const void*)dgemm_kernel<6, 8, 1, 1>};
+      for (const void* k : ks) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds);
+        if (e != hipSuccess) attr_err = e;
+      }
+    });
+    if (attr_err != hipSuccess) return SFMI_ELDS;
+#define DGP(MT_) hipLaunchKernelGGL((dgemm_kernel<MT_, 8, 1, 1>), grid, dim3(512), kPipeLds, st, a)
+    if (MT == 3) DGP(3); else if (MT == 4) DGP(4); else if (MT == 5) DGP(5); else DGP(6);
+#undef DGP
+  }
   else if (MT <= 4) { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
   else if (MT == 5) { if (un >= 2) DG(5, 8, 2); else DG(5, 8, 1); }   // 65..96 rows: still the 8-wave kernel
   else { if (un >= 2) DG(6, 8, 2); else DG(6, 8, 1); }
@@ -1305,34 +1409,6 @@ int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* 
   hipLaunchKernelGGL(rowprep_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
-}
-
-// tuning hooks (performance only: none of them changes a result bit).  Set through sfmi_tune_set(name, value) by bench.py /
-// tools/ar_sweep.py; read at LAUNCH time, i.e. baked into a captured hipGraph (re-capture after changing one).
-//   attn_blocks : 0 = one workgroup per (row, head) item; n > 0 = persistent grid of n workgroups striding over the items
-//   attn_unroll : float4 loads in flight per lane (4 or 8)
-//   attn_waves  : 16 or 8 waves per workgroup (NOT bit-identical to each other: different summation order)
-//   attn_lds_pad: extra dynamic LDS bytes per workgroup (caps resident workgroups per CU)
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad; };
-static SfmiTune g_tune = {0, 4, 16, 0};
-int sfmi_tune_set(const char* name, int value) {
-  if (!name) return SFMI_EINVAL;
-  const std::string n(name);
-  if (n == "attn_blocks" && value >= 0) g_tune.attn_blocks = value;
-  else if (n == "attn_unroll" && (value == 2 || value == 4 || value == 8)) g_tune.attn_unroll = value;
-  else if (n == "attn_waves" && (value == 8 || value == 16)) g_tune.attn_waves = value;
-  else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) g_tune.attn_lds_pad = value;
-  else return SFMI_EINVAL;
-  return SFMI_OK;
-}
-int sfmi_tune_get(const char* name) {
-  if (!name) return -1;
-  const std::string n(name);
-  if (n == "attn_blocks") return g_tune.attn_blocks;
-  if (n == "attn_unroll") return g_tune.attn_unroll;
-  if (n == "attn_waves") return g_tune.attn_waves;
-  if (n == "attn_lds_pad") return g_tune.attn_lds_pad;
-  return -1;
 }
 
 // replaces CausalSelfAttention.forward for ONE new position per row with a KV cache (mingpt.py:73-91).

@@ -281,3 +281,68 @@ def test_shared_prefix_sampling_is_bit_identical_to_expanded_rows(dev):
         assert len(set(map(tuple, a["samples"][1:, :, 0].tolist()))) > 1          # the stochastic rows do differ from each other
     with pytest.raises(AssertionError):
         g.sample(torch.from_numpy(c3), torch.from_numpy(Lc3), max_steps=4, shared_prefix=True)   # different rows: refused
+
+
+@pytest.mark.parametrize("M", [48, 64, 80, 96])
+def test_decode_gemm_lds_pipelined_form_is_bit_identical(dev, M):
+    """csrc/gpt.hip dgemm_kernel<MT,8,1,PIPE=1> (weight slices by LDS-DMA up front, activations double-buffered; tuning knob
+    dgemm_pipe) against the batched form on the decode step's GEMM shapes (LN fold, GELU, residual, split-K 4): same k order and
+    accumulator chains, so every output bit must agree."""
+    from shapeformer_amd import _lib as L
+    from shapeformer_amd.gpt import pack_skinny16
+    lib = L.lib()
+    g = torch.Generator(device="cpu").manual_seed(M)
+    Mp = (M + 15) // 16 * 16
+    try:
+        for (N, K, ln, act, use_res, S) in [(3072, 1024, 1, 0, False, 1), (1024, 1024, 0, 0, True, 1), (4096, 1024, 1, 1, False, 1),
+                                            (1024, 4096, 0, 0, True, 4), (4097, 1024, 1, 0, False, 1)]:
+            Np = (N + 15) // 16 * 16
+            w = (torch.randn(N, K, generator=g) * 0.05)
+            wp = pack_skinny16(w).to(dev)
+            x = torch.randn(Mp * K, generator=g).to(dev)                  # fragment-packed activations: any values do
+            c1, c2 = torch.randn(Np, generator=g).to(dev), torch.randn(Np, generator=g).to(dev)
+            packed = 0 if N == 4097 else 1
+            ldo = 4128 if N == 4097 else N
+            res = torch.randn(Mp * N, generator=g).to(dev) if use_res else None
+            slab = torch.empty(lib.sfmi_decode_gemm_slab_floats(Mp, 4096, 4), device=dev)
+            cnt = torch.zeros(Mp // 16 * 260, device=dev, dtype=torch.int32)
+            outs = []
+            for pipe in (0, 1):
+                L.check(lib.sfmi_tune_set(b"dgemm_pipe", pipe), "tune")
+                out = torch.zeros(Mp * max(N, ldo), device=dev)
+                L.check(lib.sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1) if ln else None, L.ptr(c2), L.ptr(res), L.ptr(out), M, N, K, ldo,
+                                                 ln, act, packed, S, L.ptr(slab) if S > 1 else None, L.ptr(cnt) if S > 1 else None,
+                                                 L.stream_ptr()), "sfmi_decode_gemm_f32")
+                torch.cuda.synchronize()
+                outs.append(out.cpu())
+            assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+            assert torch.equal(outs[0], outs[1]), (M, N, K, float((outs[0] - outs[1]).abs().max()))
+    finally:
+        L.check(lib.sfmi_tune_set(b"dgemm_pipe", 0), "tune")
+
+
+def test_attention_turnstile_is_scheduling_only(dev):
+    """ATTN_LANES (csrc/gpt.hip:attn_gate_kernel): three interleaved chains behind a one-lane turnstile give exactly the
+    tokens / log-probs of the ungated run, every gate was passed in order (tickets == launches) and none timed out."""
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    kw = dict(n_embd=128, n_layers=(2, 1), block_size=400)
+    g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=400, device=dev)
+    rs = np.random.RandomState(5)
+    B, steps = 36, 12
+    Lc = rs.randint(8, 30, B).astype(np.int32)
+    tok = np.full((B, 64, 2), 4096, np.int32)
+    for b in range(B):
+        tok[b, :Lc[b] - 1, 0] = np.sort(rs.choice(4096, Lc[b] - 1, replace=False)); tok[b, :Lc[b] - 1, 1] = rs.randint(0, 4096, Lc[b] - 1)
+    ct, lt = torch.from_numpy(tok), torch.from_numpy(Lc)
+    ref = g.sample_microbatched(ct, lt, n_micro=3, max_steps=steps, stop_early=False, seed=3)
+    want = {k: v.clone() for k, v in ref["state"].items()}
+    g.ATTN_LANES = 1
+    try:
+        got = g.sample_microbatched(ct, lt, n_micro=3, max_steps=steps, stop_early=False, seed=3)
+    finally:
+        g.ATTN_LANES = 0
+    for k in ("seq", "len", "logp"):
+        assert torch.equal(got["state"][k], want[k]), k
+    sem = g._sem.cpu().tolist()
+    assert sem[0] == sem[1] == 3 * 3 * steps and sem[2] == 0, sem      # 3 chains x 3 layers x steps launches, no time-outs
