@@ -130,9 +130,6 @@ int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out); /* [hos
 size_t sfmi_decode_gemm_slab_floats(int M, int N, int S);
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
                          int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, void* stream);
-/* same contract, always the two-n-tiles-per-wave kernel (sfmi_decode_gemm_f32 routes M > 96 here) */
-int sfmi_decode_gemm_wide_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
-                              int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, void* stream);
 /* embedding of the token at t = len[b]-1 into the fragment-packed residual buffer (input of the first decode step) */
 int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                               const int* seq, const int* len, const int* Lc, float* resid, int B, int D, int Lmax, int end0,

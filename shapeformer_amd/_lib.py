@@ -95,7 +95,6 @@ PROTOTYPES = {
     "sfmi_gpt_sample_f32": (i32, [c_ptr] * 12 + [i32] * 10 + [C.c_float, C.c_float] + [i32] * 4 + [C.c_uint, c_ptr, i32, i32, i32, i32, c_ptr]),
     "sfmi_gpt_mask_logits_f32": (i32, [c_ptr] * 5 + [i32] * 9 + [c_ptr]),
     "sfmi_decode_gemm_f32": (i32, [c_ptr] * 6 + [i32] * 8 + [c_ptr, c_ptr, c_ptr]),
-    "sfmi_decode_gemm_wide_f32": (i32, [c_ptr] * 6 + [i32] * 8 + [c_ptr, c_ptr, c_ptr]),
     "sfmi_decode_gemm_slab_floats": (sz, [i32, i32, i32]),
     "sfmi_gpt_embed_packed_f32": (i32, [c_ptr] * 9 + [i32] * 4 + [c_ptr]),
     "sfmi_set_len_i32": (i32, [c_ptr, c_ptr, i32, i32, c_ptr]),

@@ -5,7 +5,7 @@
 // (valid by SURVEY Appendix A11) made of a handful of weight-streaming kernels that read all
 // per-row state (lengths, tokens) from device memory, so one captured hipGraph replays every step:
 //
-//   dgemm     LayerNorm-fused weight-streaming GEMM for M <= 96 rows on f32 MFMA 16x16x4 (mingpt.py:103-111):
+//   dgemm     LayerNorm-fused weight-streaming GEMM for M <= 96 rows per launch on f32 MFMA 16x16x4 (mingpt.py:103-111):
 //             weights AND activations in MFMA-fragment order (every wave access = 1 KiB contiguous), final
 //             outputs (bias / GELU / residual in the epilogue), optional in-kernel deterministic split-K
 //   attn      one workgroup per (row, head): KV append, softmax(QK^T/8)V over the row's own cached length
@@ -27,10 +27,8 @@
 //   attn_unroll : float4 loads in flight per lane (2, 4 or 8)
 //   attn_waves  : 16 or 8 waves per workgroup (NOT bit-identical to each other: different summation order)
 //   attn_lds_pad: extra dynamic LDS bytes per workgroup (caps resident workgroups per CU)
-//   dgemm_pipe  : 1 = decode GEMM main loop with the wave's whole weight slice requested up front + double-buffered activations
-//                 (latency-tolerant form for launches that run beside a KV stream); same arithmetic order, bit-identical
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, dgemm_pipe; };
-static SfmiTune g_tune = {0, 4, 16, 0, 0};
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad; };
+static SfmiTune g_tune = {0, 4, 16, 0};
 extern "C" int sfmi_tune_set(const char* name, int value) {
   if (!name) return SFMI_EINVAL;
   const std::string n(name);
@@ -38,7 +36,6 @@ extern "C" int sfmi_tune_set(const char* name, int value) {
   else if (n == "attn_unroll" && (value == 2 || value == 4 || value == 8)) g_tune.attn_unroll = value;
   else if (n == "attn_waves" && (value == 8 || value == 16)) g_tune.attn_waves = value;
   else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) g_tune.attn_lds_pad = value;
-  else if (n == "dgemm_pipe" && (value == 0 || value == 1)) g_tune.dgemm_pipe = value;
   else return SFMI_EINVAL;
   return SFMI_OK;
 }
@@ -49,7 +46,6 @@ extern "C" int sfmi_tune_get(const char* name) {
   if (n == "attn_unroll") return g_tune.attn_unroll;
   if (n == "attn_waves") return g_tune.attn_waves;
   if (n == "attn_lds_pad") return g_tune.attn_lds_pad;
-  if (n == "dgemm_pipe") return g_tune.dgemm_pipe;
   return -1;
 }
 
@@ -218,23 +214,10 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
 #ifndef DG_MFMA
 #define DG_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 #endif
-template <int MT, int NW, int UN, int PIPE = 0>
-__global__ __launch_bounds__(64 * NW, PIPE ? 4 : 1) void dgemm_kernel(DGemmArgs a) {   // PIPE: <= 128 VGPRs (a workgroup must fit beside a KV stream)
-  // LDS: the cross-wave reduction tiles + LayerNorm statistics.  PIPE: dynamic LDS - the waves' weight slices (NW x 8 KiB, LDS-DMA)
-  // come first and the reduction tiles reuse that space after the main loop; the statistics sit behind it.
-  extern __shared__ __attribute__((aligned(16))) float dg_dyn[];
-  float (*red)[MT][4][64];
-  float (*st1)[MT][16], (*st2)[MT][16];
-  if constexpr (PIPE) {
-    static_assert(MT * 256 <= 2048, "the reduction tiles must fit in the weight slices they replace");
-    red = reinterpret_cast<float (*)[MT][4][64]>(dg_dyn);
-    st1 = reinterpret_cast<float (*)[MT][16]>(dg_dyn + NW * 2048);
-    st2 = st1 + NW;
-  } else {
-    __shared__ __attribute__((aligned(16))) float red_s[NW][MT][4][64];
-    __shared__ float st1_s[NW][MT][16], st2_s[NW][MT][16];
-    red = red_s; st1 = st1_s; st2 = st2_s;
-  }
+template <int MT, int NW, int UN>
+__global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[NW][MT][4][64];
+  __shared__ float st1[NW][MT][16], st2[NW][MT][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, ml = lane & 15;
   const int nt = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
   const int kslice = a.K / S;
@@ -257,14 +240,11 @@ __global__ __launch_bounds__(64 * NW, PIPE ? 4 : 1) void dgemm_kernel(DGemmArgs 
   const int n_ep = nt * 16 + 4 * q;
   const long long off_ep = a.out_packed ? (((long long)wave * (a.N >> 4) + nt) * 64 + lane) * 4
                                         : (long long)min(wave * 16 + ml, a.M - 1) * a.ldo + n_ep;
-  auto load_epilogue_operands = [&]() {
-    if (wave < MT && n_ep < a.N) {
-      if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
-      if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
-      if (a.resid) pres = *reinterpret_cast<const f32x4*>(a.resid + off_ep);
-    }
-  };
-  if constexpr (!PIPE) load_epilogue_operands();   // (PIPE: after the main loop - 12 registers it cannot spare - under the LDS reduction)
+  if (wave < MT && n_ep < a.N) {
+    if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
+    if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
+    if (a.resid) pres = *reinterpret_cast<const f32x4*>(a.resid + off_ep);
+  }
   const int steps = kw / 16;
   // software pipeline over batches of UN k16-steps: the loads of batch b+1 are issued BEFORE the MFMAs of batch b
   // (two register sets, statically indexed), and every load of a batch is pinned ahead of the first MFMA that
@@ -289,46 +269,11 @@ __global__ __launch_bounds__(64 * NW, PIPE ? 4 : 1) void dgemm_kernel(DGemmArgs 
         acc[j][e & 1] = DG_MFMA(wv[e], xv[e], acc[j][e & 1]);
     }
   };
-  if constexpr (PIPE == 1) {
-    // latency-tolerant form (host guarantees steps == 8): the wave's WHOLE weight slice (8 x 1 KiB, the only HBM traffic of the
-    // launch) goes to LDS by DMA at t = 0 - no registers, ONE HBM round trip per launch instead of one per batch (beside a
-    // saturating KV stream that round trip is 3-4x the unloaded one) - and the activation fragments (L2 hits) are double-buffered
-    // one step ahead in registers.  The fragment order of Wp16 is lane-linear, which is exactly what an LDS-DMA writes
-    // (base + lane x 16 B), and each wave reads back only its own slice: no barrier, conflict-free ds_read_b128.
-    // Same k order, same accumulator chains: bit-identical to the batched form.
-    float* wl = dg_dyn + wave * 2048;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + u * 64 + lo),
-                                       (__attribute__((address_space(3))) void*)(wl + u * 256), 16, 0, 0);
-    f32x4 xa[MT], xc[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) xa[j] = xr[j][lo];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slices landed (the issuing wave is the only reader) + first activations
-    const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
-    // rolled on purpose: with the 8 steps unrolled hipcc lets the accumulator chains wander through fresh registers (the MFMA's
-    // destination need not be its C operand) and the kernel spills; a loop-carried accumulator stays where it is
-#pragma unroll 1
-    for (int s2 = 0; s2 < 8; s2 += 2) {
-#pragma unroll
-      for (int j = 0; j < MT; ++j) xc[j] = xr[j][XIDX((s2 + 1) * 64) + lo];
-      const f32x4 w0 = wf[s2 * 64];
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(w0, xa);
-      __builtin_amdgcn_sched_barrier(0);
-      const int sn = min(s2 + 2, 7);       // (the last iteration re-reads step 7: one wasted, cached fragment set instead of a branch)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) xa[j] = xr[j][XIDX(sn * 64) + lo];
-      const f32x4 w1 = wf[(s2 + 1) * 64];
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(w1, xc);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    load_epilogue_operands();
-    __syncthreads();        // every wave is done with its weight slice: the reduction tiles may overwrite them
-  } else
   // batches of UN k16-steps: UN weight + UN*MT activation loads in flight, all pinned ahead of the MFMAs
-  // (measured alternatives for MT > 1 — two-deep register pipeline, up-front weight preload — were 4-6 % slower in isolation)
+  // (measured alternatives for MT > 1 — two-deep register pipeline, up-front weight preload — were 4-6 % slower in isolation; round 3:
+  //  the wave's whole weight slice by LDS-DMA at t = 0 + double-buffered activations, built to make the launch tolerant of the
+  //  3-4x memory latency beside a KV stream, was slower alone (1.65 vs 1.50 ms per 80-row chain step) AND beside the stream:
+  //  profiles/r03_ar_overlap.md)
   for (int s0 = 0; s0 < steps; s0 += UN) {
     f32x4 w[UN], xb[UN][MT];
 #pragma unroll
@@ -426,210 +371,6 @@ __global__ __launch_bounds__(64 * NW, PIPE ? 4 : 1) void dgemm_kernel(DGemmArgs 
       const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
       if (a.resid) r = r + pres;
       *reinterpret_cast<f32x4*>(a.out + off) = r;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// wide decode GEMM: 96 < M <= 256 rows in ONE launch (MT = 8, 12 or 16 row tiles), same math / layouts as dgemm_kernel.
-//   - each wave owns TWO adjacent 16-column n-tiles over all MT row tiles, so an activation fragment feeds 8 MFMAs
-//     instead of 4 (per-CU L1 traffic (MT+2)/(2 MT) KB per 128 MFMA-clk per wave, 18.7 B/clk at MT = 12 against
-//     40 B/clk for the 64-row kernel and ~25 B/clk the L1 sustains), and the weights are streamed ONCE for all rows;
-//   - 4 waves (one per SIMD, up to 512 VGPRs each) split K; explicit two-buffer pipeline: activations one k16-step
-//     ahead, weights two steps ahead, issued in that order so the in-order vmcnt wait on the activations never
-//     waits for the younger weight loads;
-//   - one accumulator chain per tile (2 MT independent tiles already cover the MFMA dependent-issue latency);
-//   - ONE reduction pass through LDS (MT*8 KB), then wave w finishes row tiles [w MT/4, (w+1) MT/4) x both columns;
-//     split-K (S > 1): one ticket per (column pair, wave) covers those MT/2 tiles - a single atomic round trip.
-// grid (ceil(ceil(N/16)/2), S).  Packed x/out/resid must hold MT*16 rows; K/S must be a multiple of 128.
-// ------------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(256) void dgemm_wide_kernel(DGemmArgs a) {
-  constexpr int NW = 4, JW = MT / NW;   // JW row tiles finished per wave
-  static_assert(MT % NW == 0, "row tiles are dealt to the four waves");
-  extern __shared__ __attribute__((aligned(16))) float wide_lds[];
-  f32x4 (*red)[MT * 2][64] = reinterpret_cast<f32x4 (*)[MT * 2][64]>(wide_lds);           // [NW][MT*2][64]
-  float (*st1)[MT][16] = reinterpret_cast<float (*)[MT][16]>(wide_lds + NW * MT * 2 * 256);   // [NW][MT][16]
-  float (*st2)[MT][16] = st1 + NW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, ml = lane & 15;
-  const int np = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
-  const int ntiles = (a.N + 15) >> 4;
-  const int ntA = 2 * np, ntB = min(2 * np + 1, ntiles - 1);   // odd tile count: column B clamps, its store is masked
-  const bool okB = 2 * np + 1 < ntiles;
-  const int kslice = a.K / S, kw = kslice / NW, k0 = sp * kslice + wave * kw;
-  const long long kt = a.K / 16;
-  const f32x4* wpA = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)ntA * kt + k0 / 16) * 64 + lane;
-  const f32x4* wpB = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)ntB * kt + k0 / 16) * 64 + lane;
-  const f32x4* xr = reinterpret_cast<const f32x4*>(a.x) + (long long)(k0 / 16) * 64 + lane;
-  const long long xs = kt * 64;   // f32x4 stride between row tiles
-  const int steps = kw / 16;      // even (host check)
-  f32x4 acc[MT][2];
-  float s1[MT], s2[MT];
-#pragma unroll
-  for (int j = 0; j < MT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = acc[j][0]; s1[j] = 0.f; s2[j] = 0.f; }
-  f32x4 xa[MT], xb[MT];
-  f32x4 wA0 = __builtin_nontemporal_load(wpA), wB0 = __builtin_nontemporal_load(wpB);
-#pragma unroll
-  for (int j = 0; j < MT; ++j) xa[j] = xr[j * xs];
-  f32x4 wA1 = __builtin_nontemporal_load(wpA + 64), wB1 = __builtin_nontemporal_load(wpB + 64);
-  // epilogue operands of this wave's tiles, fetched ahead of the weight stream
-  const int nA = ntA * 16 + 4 * q, nB = (2 * np + 1) * 16 + 4 * q;
-  f32x4 pc1A = {0.f, 0.f, 0.f, 0.f}, pc1B = pc1A, pc2A = pc1A, pc2B = pc1A, pres[JW][2];
-#pragma unroll
-  for (int jj = 0; jj < JW; ++jj) { pres[jj][0] = pc1A; pres[jj][1] = pc1A; }
-  if (a.ln) { if (nA < a.N) pc1A = *reinterpret_cast<const f32x4*>(a.c1 + nA); if (okB && nB < a.N) pc1B = *reinterpret_cast<const f32x4*>(a.c1 + nB); }
-  if (a.c2) { if (nA < a.N) pc2A = *reinterpret_cast<const f32x4*>(a.c2 + nA); if (okB && nB < a.N) pc2B = *reinterpret_cast<const f32x4*>(a.c2 + nB); }
-  if (a.resid) {
-#pragma unroll
-    for (int jj = 0; jj < JW; ++jj) {
-      const int j = wave * JW + jj;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int nt = 2 * np + c, n = nt * 16 + 4 * q;
-        if (nt < ntiles && n < a.N) {
-          const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nt) * 64 + lane) * 4
-                                             : (long long)min(j * 16 + ml, a.M - 1) * a.ldo + n;
-          pres[jj][c] = *reinterpret_cast<const f32x4*>(a.resid + off);
-        }
-      }
-    }
-  }
-  auto mfma_block = [&](const f32x4 (&xv_)[MT], const f32x4& wa, const f32x4& wb) {
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const f32x4 xv = xv_[j];
-      s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
-      s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[j][0] = DG_MFMA(wa[e], xv[e], acc[j][0]);
-        acc[j][1] = DG_MFMA(wb[e], xv[e], acc[j][1]);
-      }
-    }
-  };
-  for (int s = 0; s < steps; s += 2) {
-    const int s2n = min(s + 2, steps - 1), s3n = min(s + 3, steps - 1);
-#pragma unroll
-    for (int j = 0; j < MT; ++j) xb[j] = xr[j * xs + XIDX((long long)(s + 1) * 64)];
-    const f32x4 wA2 = __builtin_nontemporal_load(wpA + s2n * 64), wB2 = __builtin_nontemporal_load(wpB + s2n * 64);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(xa, wA0, wB0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < MT; ++j) xa[j] = xr[j * xs + XIDX((long long)s2n * 64)];
-    const f32x4 wA3 = __builtin_nontemporal_load(wpA + s3n * 64), wB3 = __builtin_nontemporal_load(wpB + s3n * 64);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(xb, wA1, wB1);
-    __builtin_amdgcn_sched_barrier(0);
-    wA0 = wA2; wB0 = wB2; wA1 = wA3; wB1 = wB3;
-  }
-#ifdef WIDE_SKIP_EPI   // ablation (tools/ubench/run_wide.sh): main loop only
-  { f32x4 t = acc[0][0]; float u = s1[0] + s2[0];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) { t = t + acc[j][0] + acc[j][1]; u += s1[j] + s2[j]; }
-    if (t[0] + t[1] + t[2] + t[3] + u == 1.2345f) a.out[0] = 1.f;
-    return; }
-#endif
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    red[wave][j * 2][lane] = acc[j][0];
-    red[wave][j * 2 + 1][lane] = acc[j][1];
-    if (a.ln) {
-      float t1 = s1[j], t2 = s2[j];
-      t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
-      t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
-      if (q == 0) { st1[wave][j][ml] = t1; st2[wave][j][ml] = t2; }
-    }
-  }
-  __syncthreads();
-  f32x4 r[JW][2];
-  float t1[JW], t2[JW];
-#pragma unroll
-  for (int jj = 0; jj < JW; ++jj) {
-    const int j = wave * JW + jj;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      r[jj][c] = red[0][j * 2 + c][lane];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) r[jj][c] = r[jj][c] + red[w][j * 2 + c][lane];
-    }
-    t1[jj] = 0.f; t2[jj] = 0.f;
-    if (a.ln) {
-#pragma unroll
-      for (int w = 0; w < NW; ++w) { t1[jj] += st1[w][j][ml]; t2[jj] += st2[w][j][ml]; }
-    }
-  }
-  if (S > 1) {
-    // publish this slice's tiles write-through, ONE ticket for the wave's JW x 2 tiles; the last arriver sums the
-    // S slabs in slice order (deterministic) and runs the epilogue
-#pragma unroll
-    for (int jj = 0; jj < JW; ++jj) {
-      const int j = wave * JW + jj;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (c && !okB) continue;
-        float* slab = a.slab + (((long long)j * ntiles + 2 * np + c) * S + sp) * 320;
-        st_sc1(slab + lane * 4, r[jj][c]);
-        if (a.ln && c == 0 && q == 0) {
-          __hip_atomic_store(slab + 256 + ml, t1[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(slab + 272 + ml, t2[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int* cnt = a.cnt + np * NW + wave;
-    int ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __shfl(ticket, 0, 64);
-    if (ticket != S - 1) return;
-    if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-#pragma unroll
-    for (int jj = 0; jj < JW; ++jj) { r[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f}; r[jj][1] = r[jj][0]; t1[jj] = 0.f; t2[jj] = 0.f; }
-    const int cB = okB ? 1 : 0;
-    for (int s = 0; s < S; ++s) {   // all of a slice's tile loads are in flight together (no per-tile round trip)
-      f32x4 tv[JW][2];
-      float u1[JW], u2[JW];
-#pragma unroll
-      for (int jj = 0; jj < JW; ++jj) {
-        const long long tileA = (long long)(wave * JW + jj) * ntiles + 2 * np;
-        const float* bA = a.slab + (tileA * S + s) * 320;
-        const float* bB = a.slab + ((tileA + cB) * S + s) * 320;
-        tv[jj][0] = ld_sc1(bA + lane * 4);
-        tv[jj][1] = ld_sc1(bB + lane * 4);
-        u1[jj] = __hip_atomic_load(bA + 256 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u2[jj] = __hip_atomic_load(bA + 272 + ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int jj = 0; jj < JW; ++jj) {
-        r[jj][0] = r[jj][0] + tv[jj][0]; r[jj][1] = r[jj][1] + tv[jj][1];
-        t1[jj] += u1[jj]; t2[jj] += u2[jj];
-      }
-    }
-  }
-#pragma unroll
-  for (int jj = 0; jj < JW; ++jj) {
-    const int j = wave * JW + jj, m = j * 16 + ml;
-    float mean = 0.f, rstd = 1.f;
-    if (a.ln) {
-      mean = t1[jj] / (float)a.K;
-      const float var = fmaxf(t2[jj] / (float)a.K - mean * mean, 0.f);
-      rstd = rsqrtf(var + 1e-5f);
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int nt = 2 * np + c, n = nt * 16 + 4 * q;
-      if (nt >= ntiles || n >= a.N || !(a.out_packed || m < a.M)) continue;
-      f32x4 v = r[jj][c];
-      if (a.ln) v = (v - (c ? pc1B : pc1A) * mean) * rstd;
-      if (a.c2) v = v + (c ? pc2B : pc2A);
-      if (a.act == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
-      }
-      const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
-      if (a.resid) v = v + pres[jj][c];
-      *reinterpret_cast<f32x4*>(a.out + off) = v;
     }
   }
 }
@@ -1279,42 +1020,13 @@ int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out) {
 // writes row-major (M,ldo) (used for the logits handed to the sampler).  S > 1 splits K across S workgroups per
 // n-tile with an in-kernel deterministic last-arriver reduction (slab/cnt scratch, cnt zero-initialised ONCE).
 size_t sfmi_decode_gemm_slab_floats(int M, int N, int S) { return (size_t)((M + 63) / 64 * 4) * ((N + 15) / 16) * S * 320; }
-// the same GEMM through dgemm_wide_kernel (one launch for up to 192 rows; sfmi_decode_gemm_f32 routes M > 64 here)
-int sfmi_decode_gemm_wide_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
-                              float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
-                              int* cnt, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 256 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
-  if (out_packed && N % 16) return SFMI_EINVAL;
-  if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
-  if ((K / S) % 128) return SFMI_EINVAL;
-  DGemmArgs a;
-  a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
-  a.out_packed = out_packed; a.slab = slab; a.cnt = cnt;
-  const int ntiles = (N + 15) / 16;
-  dim3 grid((ntiles + 1) / 2, S);
-  hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;   // idempotent, race-free: raises the dynamic LDS limit of the three instantiations
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dgemm_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (8192 + 512));
-    (void)hipFuncSetAttribute((const void*)dgemm_wide_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (8192 + 512));
-    (void)hipFuncSetAttribute((const void*)dgemm_wide_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * (8192 + 512));
-    (void)hipFuncSetAttribute((const void*)dgemm_wide_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (8192 + 512));
-    attr_set = true;
-  }
-#define DW(MT_) hipLaunchKernelGGL((dgemm_wide_kernel<MT_>), grid, dim3(256), MT_ * (8192 + 512), st, a)
-  if (M <= 64) DW(4); else if (M <= 128) DW(8); else if (M <= 192) DW(12); else DW(16);
-#undef DW
-  SFMI_CHECK_LAUNCH();
-  return SFMI_OK;
-}
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
                          float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
                          int* cnt, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 256 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;
+  if (!x || !Wp16 || !out || M <= 0 || M > 96 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;   // larger batches: several chains (gpt.py)
   if (out_packed && N % 16) return SFMI_EINVAL;
   if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
   const int kslice = K / S;
-  if (M > 96) return sfmi_decode_gemm_wide_f32(x, Wp16, c1, c2, resid, out, M, N, K, ldo, ln, act, out_packed, S, slab, cnt, stream);
 #ifdef DG_FORCE_NW    // tuning hook of tools/ubench/dgemm_chain.hip
   const int NWv = DG_FORCE_NW;
 #else
@@ -1351,23 +1063,6 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
     else return SFMI_EINVAL;
   }
   else if (NWv == 1) { if (MT == 1) DG(1, 1, 1); else return SFMI_EINVAL; }
-  else if (g_tune.dgemm_pipe == 1 && steps == 8 && MT >= 3) {
-    constexpr int kPipeLds = (8 * 2048 + 2 * 8 * 6 * 16) * 4;    // weight slices + statistics (MT <= 6): 71 680 B
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-      const void* ks[4] = {(const void*)dgemm_kernel<3, 8, 1, 1>, (const void*)dgemm_kernel<4, 8, 1, 1>, (const void*)dgemm_kernel<5, 8, 1, 1>,
-                           (const void*)dgemm_kernel<6, 8, 1, 1>};
-      for (const void* k : ks) {
-        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds);
-        if (e != hipSuccess) attr_err = e;
-      }
-    });
-    if (attr_err != hipSuccess) return SFMI_ELDS;
-#define DGP(MT_) hipLaunchKernelGGL((dgemm_kernel<MT_, 8, 1, 1>), grid, dim3(512), kPipeLds, st, a)
-    if (MT == 3) DGP(3); else if (MT == 4) DGP(4); else if (MT == 5) DGP(5); else DGP(6);
-#undef DGP
-  }
   else if (MT <= 4) { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
   else if (MT == 5) { if (un >= 2) DG(5, 8, 2); else DG(5, 8, 1); }   // 65..96 rows: still the 8-wave kernel
   else { if (un >= 2) DG(6, 8, 2); else DG(6, 8, 1); }

@@ -72,10 +72,8 @@ class CondTupleGPT:
         self._state = None
         self._states, self._graphs = {}, {}
         # debug / measurement hooks, set explicitly by bench.py and tools/ (never read from the environment on the product path):
-        #   _force_wide : two-n-tiles-per-wave decode GEMM for 17..96 rows too (tools/sweep_dgemm.sh)
         #   _ablate     : TIMING-ONLY ablation of decode_step, "gemm" / "attn" / "gemm@0,attn@1" (per chain): the named kernel
         #                 family is not launched, sampled tokens are garbage; part of the hipGraph cache key
-        self._force_wide = False
         self._ablate = ""
         self._sem = torch.zeros(4, device=self.dev, dtype=torch.int32)   # attention turnstile {next ticket, finished, time-outs}
 
@@ -186,9 +184,8 @@ class CondTupleGPT:
             return cur
         dev, D = self.dev, self.D
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
-        # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off); the wide GEMM (B > 64) works on
-        # groups of four row tiles
-        Bp = (B + 15) // 16 * 16 if B <= 96 else (B + 63) // 64 * 64
+        # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off)
+        Bp = (B + 15) // 16 * 16
         st = dict(key=key,
                   seq=torch.zeros(B, self.Lmax + 1, 2, device=dev, dtype=torch.int32),
                   len=torch.zeros(B, device=dev, dtype=torch.int32), Lc=torch.zeros(B, device=dev, dtype=torch.int32),
@@ -210,11 +207,6 @@ class CondTupleGPT:
         st = st or self._state
         while S > 1 and (K // S) % 128:
             S //= 2
-        if self._force_wide and M > 16:
-            L.check(L.lib().sfmi_decode_gemm_wide_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
-                                                      ln, act, packed, S, L.ptr(st["slab"]) if S > 1 else None,
-                                                      L.ptr(st["cnt"]) if S > 1 else None, L.stream_ptr()), "sfmi_decode_gemm_wide_f32")
-            return
         L.check(L.lib().sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
                                              ln, act, packed, S, L.ptr(st["slab"]) if S > 1 else None,
                                              L.ptr(st["cnt"]) if S > 1 else None, L.stream_ptr()), "sfmi_decode_gemm_f32")
@@ -398,7 +390,10 @@ class CondTupleGPT:
     # Attention turnstile of the interleaved decode chains (csrc/gpt.hip:attn_gate_kernel): > 0 = at most this many chains stream
     # their KV cache at the same time (FIFO tickets in device memory); the other chains' GEMM workgroups then always find room
     # on every CU.  0 = off (independent chains, round 2 behaviour).  Scheduling only: tokens / logits are bit-identical.
-    ATTN_LANES = 0
+    # Two lanes measured best with four chains (6.48 against 6.68 ms per 320-row step ungated, 6.98 with one lane;
+    # profiles/r03_ar_overlap.md).
+    ATTN_LANES = 2
+    MAX_CHAIN_ROWS = 96    # rows per decode launch (6 row tiles of csrc/gpt.hip:dgemm_kernel); larger batches = several chains
 
     def decode_step(self, st, B, sp):
         """Position t = len[b]-1 of every row through both stages; st["resid"] must hold its embedding on entry
@@ -410,8 +405,8 @@ class CondTupleGPT:
         if "@" in skip:      # per-chain form "gemm@0,attn@1,attn@2": chain index = micro-batch slot
             skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
         lanes = int(sp.get("gate_lanes", 0))
-        # in-kernel split-K per GEMM: 64-row kernel (B <= 64) / wide kernel (one launch for up to 256 rows)
-        Sqkv, Sproj, Sfc1, Sfc2, Shead = (2, 4, 2, 8, 2) if (B > 96 or self._force_wide) else (1, self.S_PROJ if B <= 16 else self.S_PROJ_M, 1, self.S_FC2, 1)
+        # in-kernel split-K per GEMM (only the K = 4 n_embd product, and proj at <= 16 rows, use it)
+        Sqkv, Sproj, Sfc1, Sfc2, Shead = 1, self.S_PROJ if B <= 16 else self.S_PROJ_M, 1, self.S_FC2, 1
         for li, ly in enumerate(self.layers):
             if "gemm" not in skip:
                 self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
@@ -448,8 +443,8 @@ class CondTupleGPT:
         they are prefilled together with the condition and sampling continues after them; the step counter restarts at 0."""
         B = c_tokens.shape[0]
         Lz = 0 if z_tokens is None else int(z_tokens.shape[1])
-        if B > 256:
-            raise L.SfmiError("decode kernels support up to 256 rows per (micro-)batch")
+        if B > self.MAX_CHAIN_ROWS:
+            raise L.SfmiError(f"a decode chain holds up to {self.MAX_CHAIN_ROWS} rows (larger batches run as several chains: sample / sample_microbatched)")
         if getattr(self, "_decode_stale", False):
             self.refresh_decode_weights()
         Lc_host = Lc.cpu().tolist()
@@ -508,7 +503,7 @@ class CondTupleGPT:
         graph = None
         if use_graph and steps > 1:
             gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force", "seed"))), return_logits,
-                    self._ablate, self._force_wide, self.S_PROJ, self.S_PROJ_M, self.S_FC2)
+                    self._ablate, self.S_PROJ, self.S_PROJ_M, self.S_FC2)
             cached = self._graphs.get(slot)
             if cached is None or cached[0] != gkey or return_logits:
                 side = torch.cuda.Stream(device=self.dev)
@@ -547,6 +542,19 @@ class CondTupleGPT:
         Returns dict(samples (B,L_z+steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
         Mirrors ShapeFormer.sample_indices (shapeformer.py:54-123); torch.multinomial is replaced by an
         inverse-CDF draw on counter-hash uniforms (oracle/gpt_oracle.py:uniforms)."""
+        if c_tokens.shape[0] > self.MAX_CHAIN_ROWS:
+            # more rows than one decode launch holds: the same rows as interleaved chains (identical tokens - uniforms and the
+            # greedy row are indexed by global row), results gathered as for one chain
+            n_micro = min(4, -(-c_tokens.shape[0] // 80))      # up to 4 chains of <= 96 rows; beyond 384 rows: successive rounds
+            r = self.sample_microbatched(c_tokens, Lc, n_micro=n_micro, max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature,
+                                         best_in_first=best_in_first, mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion,
+                                         seed=seed, stop_early=stop_early, check_every=check_every, after_prefill=after_prefill,
+                                         return_logits=return_logits, force_tokens=force_tokens, shared_prefix=shared_prefix,
+                                         z_tokens=z_tokens, use_graph=use_graph)
+            if not to_host:
+                return r
+            Lz = 0 if z_tokens is None else int(z_tokens.shape[1])
+            return self._host_result(r["state"], Lc.cpu().tolist(), Lz, r.get("logits_history"))
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
         ctx = self._prepare(c_tokens, Lc, max_steps, sp_kw, return_logits=return_logits, force_tokens=force_tokens,
                             use_graph=use_graph, shared_prefix=shared_prefix, z_tokens=z_tokens)
@@ -570,15 +578,20 @@ class CondTupleGPT:
                     break
         if not to_host:   # device-resident result for the completion pipeline (no D2H of tokens)
             return dict(state=st, steps=done)
+        return self._host_result(st, Lc_host, ctx["Lz"], hist)
+
+    def _host_result(self, st, Lc_host, Lz, hist):
+        """Device state -> the host-side result dict of `sample` (tokens after each row's condition, the z prefix included)."""
+        B = len(Lc_host)
         ln = st["len"].cpu().tolist()
         nsteps = max(l - c for l, c in zip(ln, Lc_host))
         out = torch.full((B, nsteps, 2), 0, dtype=torch.int64)
         seq = st["seq"].cpu()
         for b in range(B):
             out[b] = seq[b, Lc_host[b]:Lc_host[b] + nsteps].long()
-        n_new = nsteps - ctx["Lz"]
+        n_new = nsteps - Lz
         res = dict(samples=out, log_prob=st["logp"][:, :n_new].cpu(), steps=n_new)
-        if return_logits:
+        if hist is not None:
             res["logits_history"] = [h[:, :n_new].cpu() for h in hist]
         return res
 
@@ -632,12 +645,30 @@ class CondTupleGPT:
 
     def sample_microbatched(self, c_tokens, Lc, n_micro=2, max_steps=512, top_k=100, top_p=0.4, temperature=1.0,
                             best_in_first=True, mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True,
-                            check_every=32, after_prefill=None, return_logits=False):
+                            check_every=32, after_prefill=None, return_logits=False, force_tokens=None, shared_prefix=False,
+                            z_tokens=None, use_graph=True, _row0=0, _rows_total=None):
         """Same result as `sample(..., to_host=False)` (identical tokens: the uniform stream and the greedy row are
         indexed by GLOBAL row), but the rows are split into `n_micro` independent micro-batches whose decode steps are
         separate hipGraphs replayed on separate HIP streams: one micro-batch's HBM-bound attention overlaps the other's
         MFMA-bound GEMMs (each chain is serial, the hardware interleaves the two)."""
         B = c_tokens.shape[0]
+        rows_total = B if _rows_total is None else _rows_total
+        cap = n_micro * self.MAX_CHAIN_ROWS
+        if B > cap:      # more rows than n_micro chains hold: successive rounds of the same shape (rows keep their global index)
+            nr = -(-B // cap)
+            rb = [round(i * B / nr) for i in range(nr + 1)]
+            sl = lambda t, lo, hi: None if t is None else torch.as_tensor(t)[lo:hi]
+            parts = [self.sample_microbatched(c_tokens[lo:hi], Lc[lo:hi], n_micro=n_micro, max_steps=max_steps, top_k=top_k, top_p=top_p,
+                                              temperature=temperature, best_in_first=best_in_first, mask_invalid=mask_invalid,
+                                              mask_invalid_completion=mask_invalid_completion, seed=seed, stop_early=stop_early,
+                                              check_every=check_every, after_prefill=after_prefill if lo == 0 else None,
+                                              return_logits=return_logits, force_tokens=sl(force_tokens, lo, hi), shared_prefix=shared_prefix,
+                                              z_tokens=sl(z_tokens, lo, hi), use_graph=use_graph, _row0=_row0 + lo, _rows_total=rows_total)
+                     for lo, hi in zip(rb[:-1], rb[1:])]
+            res = dict(state={k: torch.cat([p["state"][k] for p in parts], 0) for k in parts[0]["state"]}, steps=max(p["steps"] for p in parts))
+            if return_logits:
+                res["logits_history"] = [torch.cat([p["logits_history"][i] for p in parts], 0) for i in range(2)]
+            return res
         bounds = [round(i * B / n_micro) for i in range(n_micro + 1)]
         groups = [(bounds[i], bounds[i + 1]) for i in range(n_micro) if bounds[i + 1] > bounds[i]]
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
@@ -653,8 +684,10 @@ class CondTupleGPT:
         for i, (lo, hi) in enumerate(groups):
             streams[i].wait_stream(cur)
             with torch.cuda.stream(streams[i] if self.PREFILL_ON_CHAIN_STREAMS else cur):
-                ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=lo, rows_total=B,
-                                          return_logits=return_logits, gate_lanes=lanes))
+                ctxs.append(self._prepare(c_tokens[lo:hi], Lc[lo:hi], max_steps, sp_kw, slot=100 + i, row_offset=_row0 + lo, rows_total=rows_total,
+                                          return_logits=return_logits, gate_lanes=lanes, use_graph=use_graph, shared_prefix=shared_prefix,
+                                          force_tokens=None if force_tokens is None else torch.as_tensor(force_tokens)[lo:hi],
+                                          z_tokens=None if z_tokens is None else torch.as_tensor(z_tokens)[lo:hi]))
         steps = min(c["steps"] for c in ctxs)
         if lanes:                      # re-arm the turnstile while nothing of the decode loop is in flight
             for s in streams:

@@ -2,7 +2,7 @@
 
 The tiny-model tests (test_gpt_gpu.py) never reach the configurations the benchmark runs: d = 1024 / 16 heads / 20+4 layers,
 16- and 70-row launches (1 and 5 row tiles of the decode GEMM, in-kernel split-K on proj / fc2), cached lengths beyond 500
-(several 256-key passes of the decode attention), the wide GEMM at long prefixes, both in-tree prefill GEMMs (csrc/sgemm.hip and
+(several 256-key passes of the decode attention), many rows at long prefixes, both in-tree prefill GEMMs (csrc/sgemm.hip and
 the r1 tile kernel), and the bench's own launch shape: 320 rows as 4 interleaved 80-row chains on the probed streams.  Here the
 HIP path free-runs and the CPU oracle (pinned to the reference, oracle/make_golden.py) is driven teacher-forced on the HIP
 tokens: (a) every step's masked logits must agree (< 1e-3) and (b) at every step the oracle's own draw from ITS logits under
@@ -196,9 +196,9 @@ def test_block_size_812_run_to_the_last_position(small812):
 
 
 @pytest.mark.parametrize("B", [130, 200])
-def test_wide_decode_gemm_at_long_cached_lengths(small812, B):
-    """One chain of 130 / 200 rows (12 / 16 row tiles of dgemm_wide_kernel, in-kernel split-K) decoding at cached lengths
-    700..760 after a 699-token prefill (library GEMM: 130 x 699 rows)."""
+def test_many_rows_at_long_cached_lengths(small812, B):
+    """130 / 200 rows in one `sample` call (2 / 3 interleaved chains of up to 80 rows, turnstile on) decoding at cached lengths
+    700..760 after a 699-token prefill."""
     from oracle import gpt_oracle as GO
     g, sd_t, cfg = small812
     rs = np.random.RandomState(14 + B)
@@ -209,5 +209,5 @@ def test_wide_decode_gemm_at_long_cached_lengths(small812, B):
     got, hist = out["samples"].numpy(), [h.numpy() for h in out["logits_history"]]
     u = GO.uniforms(seed, steps, B)
     worst, bad = _oracle_check(sd_t, cfg, c, [Lc] * B, got, hist, u, list(range(B)), pick_rows={0, 1, 64, B - 1})
-    print(f"wide GEMM, {B} rows at L 700..760: max |logit diff| {worst:.2e}, draw mismatches {bad}")
+    print(f"{B} rows at L 700..760: max |logit diff| {worst:.2e}, draw mismatches {bad}")
     assert worst < LOGIT_TOL and bad == 0

@@ -230,11 +230,14 @@ def test_sample_next_tuple_generator_protocol(dev):
     assert torch.equal(l1, w1)
 
 
-# 72 / 90 rows: 5 / 6 row tiles of the 8-wave kernel; 105 / 138 / 210 rows: 8 / 12 / 16 row tiles of the wide decode GEMM
+# 72 / 90 rows: one chain of 5 / 6 row tiles of the decode GEMM; 105 / 138 / 210 rows: more than a decode launch holds, `sample`
+# runs them as 2 / 2 / 3 interleaved chains (the two-n-tile "wide" kernel that used to take them in one launch was retired in
+# round 3: it never beat the narrow chains)
 @pytest.mark.parametrize("reps", [24, 30, 35, 46, 70])
-def test_wide_single_chain_decode_matches_64_row_kernels(dev, reps):
-    """One hipGraph chain of more than 64 rows (csrc/gpt.hip dgemm_wide_kernel: one GEMM launch for all rows, in-kernel
-    split-K) against the 64-row kernels on the same rows: teacher-forced step logits within 2e-4, greedy picks equal."""
+def test_many_rows_in_one_sample_call_match_the_small_batch(dev, reps):
+    """`sample` on 72..210 rows (one 5/6-tile chain, or several interleaved chains behind the same call, teacher forcing and
+    logit history included) against the same rows in a 3-row batch: step logits within 2e-4 (bit-identical in practice: a
+    row's arithmetic does not depend on the launch shape), forced tokens returned, greedy row equal."""
     from shapeformer_amd.gpt import CondTupleGPT
     sd, sd_t, cfg = _tiny()
     g = CondTupleGPT(sd, n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
@@ -256,7 +259,7 @@ def test_wide_single_chain_decode_matches_64_row_kernels(dev, reps):
         ok = torch.isfinite(ref)
         assert torch.equal(ok, torch.isfinite(lb))
         assert float((lb[ok] - ref[ok]).abs().max()) < 2e-4
-    # and a free-running (hipGraph) wide chain completes with the stop rule intact
+    # and the free-running (hipGraph) form completes with the stop rule intact
     d = g.sample(ct, Lt, max_steps=steps, seed=5, stop_early=False)
     assert d["samples"].shape == (3 * reps, steps, 2)
     assert (d["samples"][0] == a["samples"][0]).all()   # greedy row 0 (best_in_first) is batch-size independent here
@@ -281,44 +284,6 @@ def test_shared_prefix_sampling_is_bit_identical_to_expanded_rows(dev):
         assert len(set(map(tuple, a["samples"][1:, :, 0].tolist()))) > 1          # the stochastic rows do differ from each other
     with pytest.raises(AssertionError):
         g.sample(torch.from_numpy(c3), torch.from_numpy(Lc3), max_steps=4, shared_prefix=True)   # different rows: refused
-
-
-@pytest.mark.parametrize("M", [48, 64, 80, 96])
-def test_decode_gemm_lds_pipelined_form_is_bit_identical(dev, M):
-    """csrc/gpt.hip dgemm_kernel<MT,8,1,PIPE=1> (weight slices by LDS-DMA up front, activations double-buffered; tuning knob
-    dgemm_pipe) against the batched form on the decode step's GEMM shapes (LN fold, GELU, residual, split-K 4): same k order and
-    accumulator chains, so every output bit must agree."""
-    from shapeformer_amd import _lib as L
-    from shapeformer_amd.gpt import pack_skinny16
-    lib = L.lib()
-    g = torch.Generator(device="cpu").manual_seed(M)
-    Mp = (M + 15) // 16 * 16
-    try:
-        for (N, K, ln, act, use_res, S) in [(3072, 1024, 1, 0, False, 1), (1024, 1024, 0, 0, True, 1), (4096, 1024, 1, 1, False, 1),
-                                            (1024, 4096, 0, 0, True, 4), (4097, 1024, 1, 0, False, 1)]:
-            Np = (N + 15) // 16 * 16
-            w = (torch.randn(N, K, generator=g) * 0.05)
-            wp = pack_skinny16(w).to(dev)
-            x = torch.randn(Mp * K, generator=g).to(dev)                  # fragment-packed activations: any values do
-            c1, c2 = torch.randn(Np, generator=g).to(dev), torch.randn(Np, generator=g).to(dev)
-            packed = 0 if N == 4097 else 1
-            ldo = 4128 if N == 4097 else N
-            res = torch.randn(Mp * N, generator=g).to(dev) if use_res else None
-            slab = torch.empty(lib.sfmi_decode_gemm_slab_floats(Mp, 4096, 4), device=dev)
-            cnt = torch.zeros(Mp // 16 * 260, device=dev, dtype=torch.int32)
-            outs = []
-            for pipe in (0, 1):
-                L.check(lib.sfmi_tune_set(b"dgemm_pipe", pipe), "tune")
-                out = torch.zeros(Mp * max(N, ldo), device=dev)
-                L.check(lib.sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1) if ln else None, L.ptr(c2), L.ptr(res), L.ptr(out), M, N, K, ldo,
-                                                 ln, act, packed, S, L.ptr(slab) if S > 1 else None, L.ptr(cnt) if S > 1 else None,
-                                                 L.stream_ptr()), "sfmi_decode_gemm_f32")
-                torch.cuda.synchronize()
-                outs.append(out.cpu())
-            assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
-            assert torch.equal(outs[0], outs[1]), (M, N, K, float((outs[0] - outs[1]).abs().max()))
-    finally:
-        L.check(lib.sfmi_tune_set(b"dgemm_pipe", 0), "tune")
 
 
 def test_attention_turnstile_is_scheduling_only(dev):
@@ -346,3 +311,30 @@ def test_attention_turnstile_is_scheduling_only(dev):
         assert torch.equal(got["state"][k], want[k]), k
     sem = g._sem.cpu().tolist()
     assert sem[0] == sem[1] == 3 * 3 * steps and sem[2] == 0, sem      # 3 chains x 3 layers x steps launches, no time-outs
+
+
+def test_more_rows_than_the_chains_hold_run_as_rounds(dev):
+    """200 rows on 2 chains (2 x 96 rows at most) = two successive rounds of 2 x 50-row chains; the same rows as 3 chains in one
+    round must give the same tokens / log-probs (uniforms and the greedy row are indexed by GLOBAL row in every round)."""
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    kw = dict(n_embd=128, n_layers=(2, 1), block_size=400)
+    g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=400, device=dev)
+    rs = np.random.RandomState(8)
+    B, steps = 200, 6
+    Lc = rs.randint(6, 20, B).astype(np.int32)
+    tok = np.full((B, 32, 2), 4096, np.int32)
+    for b in range(B):
+        tok[b, :Lc[b] - 1, 0] = np.sort(rs.choice(4096, Lc[b] - 1, replace=False)); tok[b, :Lc[b] - 1, 1] = rs.randint(0, 4096, Lc[b] - 1)
+    ct, lt = torch.from_numpy(tok), torch.from_numpy(Lc)
+    a = g.sample_microbatched(ct, lt, n_micro=3, max_steps=steps, stop_early=False, seed=4)
+    want = {k: v.clone() for k, v in a["state"].items()}
+    b2 = g.sample_microbatched(ct, lt, n_micro=2, max_steps=steps, stop_early=False, seed=4)
+    assert b2["steps"] == steps and b2["state"]["seq"].shape[0] == B
+    for k in ("seq", "len", "Lc", "logp"):
+        assert torch.equal(b2["state"][k], want[k]), k
+    # and through `sample` (host result), which splits 200 rows into 3 chains of <= 80
+    h = g.sample(ct, lt, max_steps=steps, stop_early=False, seed=4)
+    seq = want["seq"].cpu()
+    for r in (0, 57, 133, 199):
+        assert torch.equal(h["samples"][r], seq[r, int(Lc[r]):int(Lc[r]) + steps].long())
