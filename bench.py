@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="keep the stage / AR-loop breakdown, skip the per-kernel roofline timings")
+    ap.add_argument("--lanes", type=int, default=None, help="attention turnstile lanes of the interleaved decode chains (default: CondTupleGPT.ATTN_LANES; 0 = off)")
     ap.add_argument("--no-subrecords", action="store_true", help="skip the config3 (batch-16 sampling) and train (one-rank training step) sub-records")
     ap.add_argument("--mode", default="complete", choices=["complete", "train"],
                     help="complete: the shapes/s metric (default); train: DDP training step of the transformer (BASELINE config 5)")
@@ -482,6 +483,8 @@ def main():
 
     vq = VQDIF(res=16, device=dev)
     gpt = CondTupleGPT(device=dev)
+    if a.lanes is not None:
+        gpt.ATTN_LANES = a.lanes
     pipe = ShapeCompletion(vq, gpt)
     B = a.batch
     # synthetic partial clouds; keep only shapes whose condition length leaves room for ALL ar_steps inside the
@@ -553,6 +556,9 @@ def main():
             line["stages_ms"] = {k: round(v, 1) for k, v in tm.items()}
             if getattr(gpt, "_chain_probe", None):   # stream-pair probe times of gpt._chain_streams (0.2 ms = concurrent)
                 line["chain_stream_probe_ms"] = gpt._chain_probe
+            sem = gpt._sem.cpu().tolist()            # attention turnstile of the last pass: tickets taken / launches finished / gate time-outs
+            line["turnstile"] = {"lanes": gpt.ATTN_LANES, "shared_queue": bool(getattr(gpt, "_mb_shared_queue", False)),
+                                 "tickets": sem[0], "finished": sem[1], "timeouts": sem[2]}
             alg, streamed = kv_bytes + w_one, kv_bytes + n_chain * w_one
             line["ar_loop"] = {"ms_per_step": round(ms_step, 3),
                                "algorithmic_bytes_per_step": int(alg), "algorithmic_TBps": round(alg / ms_step / 1e9, 3),
