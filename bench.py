@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=320, help="shapes per GPU per step (default 320 = 4 interleaved decode chains of 80 rows, one per hardware queue; 192 = the round-1 workload)")
+    ap.add_argument("--batch", type=int, default=384, help="shapes per GPU per step (default 384 = 4 interleaved decode chains of 96 rows, one per hardware queue, the most a decode launch holds; 320 = the round-2 workload, 192 = round 1)")
     ap.add_argument("--ar-steps", type=int, default=512)
     ap.add_argument("--decode-res", type=int, default=128)
     ap.add_argument("--points", type=int, default=16384)
@@ -540,7 +540,7 @@ def main():
                        "weights": "hash-generated (no checkpoints ship)",
                        "input_selection": (f"synthetic partial clouds whose condition length L_c <= {gpt.Lmax - a.ar_steps} (so that all {a.ar_steps} steps fit "
                                            "the 812-token block; biases the cached length down)"),
-                       "other_batches": "--batch 192 = the round-1 workload (4 x 48-row chains); --batch 16 = BASELINE config 3's batch (one 16-row chain); --batch 64 = 2 x 32-row chains"},
+                       "other_batches": "--batch 320 = the round-2 workload (4 x 80-row chains); --batch 192 = round 1 (4 x 48); --batch 16 = BASELINE config 3's batch (one 16-row chain, also measured in this run: config3)"},
             "sanity": sanity,
         }
         if not a.no_roofline:

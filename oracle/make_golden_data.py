@@ -55,6 +55,19 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "data_side.npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print("wrote", path, {k: np.asarray(v).shape for k, v in out.items()})
+    # weighted target sampling (imnet_datasets.py:288-304, `weighted_sampling=True`): the reference's own function under a fixed numpy
+    # seed; a separate fixture so that data_side.npz stays byte-identical
+    imd = importlib.import_module("shapeformer.data.imnet_datasets.imnet_datasets")
+    from shapeformer_amd.data import make_grid
+    Xtg = make_grid([-1, -1, -1.], [1., 1, 1], [16] * 3)
+    Ytg = (np.linalg.norm(Xtg - 0.1, axis=-1, keepdims=True) < 0.6).astype(np.uint8)
+    Xb = X[:2048]
+    np.random.seed(300)
+    sx, sy = imd.balanced_sampling2(Xb, Xtg, Ytg, target_N=96, x_dim=3, grid_dim=16)
+    after = np.random.rand()          # the numpy stream position after the call must match as well
+    path2 = os.path.join(ROOT, "tests", "golden", "data_side_ws.npz")
+    np.savez_compressed(path2, Xbd=Xb, Ytg=Ytg, sub_Xtg=np.asarray(sx), sub_Ytg=np.asarray(sy), next_rand=np.float64(after))
+    print("wrote", path2, np.asarray(sx).shape, np.asarray(sy).shape)
 
 
 if __name__ == "__main__":

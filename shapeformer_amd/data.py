@@ -234,12 +234,23 @@ class _ArrayStore:
         return self.get(name, None).shape[0] if name not in self._mm else self._mm[name].shape[0]
 
 
+def balanced_sampling2(Xbd, Xtg, Ytg, target_N=4096, x_dim=3, random_scale=.1):
+    """imnet_datasets.py:288-304 (`weighted_sampling=True`), numpy draw for draw: target_N//2 boundary-point INDICES, a jitter
+    draw of the same count (the reference jitters those boundary points and looks their cells up, but returns neither), then
+    target_N//2 lattice indices; the sample is Xtg / Ytg at the concatenated index list - i.e. the boundary indices address the
+    TARGET lattice (as the reference's `Xtg[choice]` does; its torch.randint draw uses torch's generator and is unused)."""
+    rdc_xbd = np.random.choice(Xbd.shape[0], target_N // 2, replace=True)
+    np.random.randn(len(rdc_xbd), x_dim)
+    rdc1 = np.random.choice(Xtg.shape[0], target_N // 2, replace=True)
+    choice = np.concatenate([rdc_xbd, rdc1])
+    return Xtg[choice], Ytg[choice]
+
+
 class Imnet2LowResDataset:
     def __init__(self, dataset="IMNet2_64", cate="all", zoomfac=1, duplicate_size=1, split="train", boundary_N=2048,
                  target_N=-1, grid_dim=64, weighted_sampling=False, Xbd_as_Xct=False, Xct_as_Xbd=False, partial_opt=None,
                  root="datasets"):
-        if weighted_sampling:
-            raise NotImplementedError("balanced_sampling2 (weighted_sampling=True) is not used by the shipped configs")
+        self.weighted_sampling = bool(weighted_sampling)
         self.store = _ArrayStore(os.path.join(root, dataset, f"{split}.hdf5"))
         n = self.store.length("Xbd")
         if isinstance(cate, str):
@@ -265,7 +276,9 @@ class Imnet2LowResDataset:
         Xbd = Xbd[np.random.choice(Xbd.shape[0], self.boundary_N, replace=True)]
         Ytg = np.unpackbits(self.store.get("Ytg", src), axis=-1)[..., None]      # bit-packed occupancy of the grid_dim^3 lattice
         Xtg = self.all_Xtg
-        if self.target_N != -1 and not all_target:
+        if self.weighted_sampling:       # imnet_datasets.py:196-203
+            Xtg, Ytg = balanced_sampling2(Xbd, Xtg, Ytg, target_N=self.target_N if self.target_N != -1 else Xtg.shape[0], x_dim=Xbd.shape[-1])
+        elif self.target_N != -1 and not all_target:
             pick = np.random.choice(Xtg.shape[0], self.target_N, replace=True)
             Xtg, Ytg = Xtg[pick], Ytg[pick]
         if self.Xct_as_Xbd:

@@ -66,6 +66,11 @@ def test_datasets_datamodule_and_device_batching(tmp_path):
     assert np.array_equal(full["Ytg"][:, 0], occ[0].astype(np.float32))
     assert np.allclose(full["Xtg"], D.make_grid([-1, -1, -1], [1, 1, 1], [8, 8, 8]))
     assert np.allclose(full["Xtg"][1], [-1, -1, -1 + 2 / 7])   # 'ij': last axis fastest
+    # weighted_sampling=True (imnet_datasets.py:196-203): half of the targets at boundary-point INDICES of the lattice, half uniform
+    dw = D.Imnet2LowResDataset(cate="5", weighted_sampling=True, **kw)
+    np.random.seed(3)
+    iw = dw[0]
+    assert iw["Xtg"].shape == (64, 3) and iw["Ytg"].shape == (64, 1) and np.array_equal(iw["Xct"], it["Xct"]) and np.array_equal(iw["Xbd"], it["Xbd"])
     # TransformDataset on top, resolved from the reference dotted names (datamodule YAML layout)
     opt = {"class": "shapeformer.data.paper_datasets.transform_dataset.TransformDataset",
            "kwargs": dict(max_voxels=512, voxel_dim=16, mode=["scale"],
@@ -87,3 +92,16 @@ def test_datasets_datamodule_and_device_batching(tmp_path):
     ld = D.instantiate({"class": "shapeformer.data.paper_datasets.list_dataset.ListDataset",
                         "kwargs": dict(ditem_list=str(tmp_path / "demo" / "list.txt"), boundary_N=100, context_N=50)})
     assert len(ld) == 2 and ld[1]["Xbd"].shape == (100, 3) and ld[1]["Xct"].shape == (50, 3)
+
+
+def test_weighted_target_sampling_replays_the_reference_draw_for_draw():
+    """imnet_datasets.py:288-304 (`weighted_sampling=True` -> balanced_sampling2): the same numpy seed must select the same
+    target points / labels as the REAL reference did (tests/golden/data_side_ws.npz, oracle/make_golden_data.py) and leave the
+    numpy stream at the same position; the dataset takes the route when the flag is set."""
+    from shapeformer_amd import data as D
+    W = np.load(os.path.join(ROOT, "tests", "golden", "data_side_ws.npz"))
+    Xtg = D.make_grid([-1, -1, -1.], [1., 1, 1], [16] * 3)
+    np.random.seed(300)
+    sx, sy = D.balanced_sampling2(W["Xbd"], Xtg, W["Ytg"], target_N=96, x_dim=3)
+    assert np.array_equal(sx, W["sub_Xtg"]) and np.array_equal(sy, W["sub_Ytg"])
+    assert np.random.rand() == float(W["next_rand"])
