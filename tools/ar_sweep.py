@@ -65,6 +65,7 @@ def main():
         name, *kvs = line.split()
         kv = dict(x.split("=", 1) for x in kvs)
         rows, chains = int(kv.pop("rows", a.rows)), int(kv.pop("chains", a.chains))
+        lclo, lchi = int(kv.pop("lclo", 100)), int(kv.pop("lchi", 216))     # condition lengths (short traces: start near the mid-run length)
         gpt._ablate = kv.pop("ablate", "")
         gpt.ATTN_LANES = int(kv.pop("lanes", "0"))
         for k, v in defaults.items():
@@ -72,9 +73,9 @@ def main():
         for k, v in kv.items():
             L.check(lib.sfmi_tune_set(k.encode(), int(v)), f"tune {k}")
         gpt._graphs = {}
-        if rows not in cache:
-            cache[rows] = synth_cond(7, rows)
-        tok, Lc = cache[rows]
+        if (rows, lclo, lchi) not in cache:
+            cache[(rows, lclo, lchi)] = synth_cond(7, rows, lo=lclo, hi=lchi, Lpad=max(406, lchi + 1))
+        tok, Lc = cache[(rows, lclo, lchi)]
         ms = []
         try:
             for rep in range(a.reps + 1):

@@ -7,6 +7,6 @@ name=$1; shift
 rm -rf /tmp/prof_$name
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -- "$@" > /tmp/prof_$name.log 2>&1)
 DB=$(find /tmp/prof_$name -name "*.db" | head -1)
-mkdir -p $R/gpurun_out/r2
-{ echo "# rocprofv3 --kernel-trace --stats -- $*"; grep -a '^{"metric"' /tmp/prof_$name.log | cut -c1-400; python $R/tools/prof_summary.py $DB 40; } > $R/gpurun_out/r2/prof_$name.txt
-tail -n 45 $R/gpurun_out/r2/prof_$name.txt
+mkdir -p $R/gpurun_out/r3
+{ echo "# rocprofv3 --kernel-trace --stats -- $*"; grep -a '^{"metric"' /tmp/prof_$name.log | cut -c1-400; python $R/tools/prof_summary.py $DB 40; } > $R/gpurun_out/r3/prof_$name.txt
+tail -n 45 $R/gpurun_out/r3/prof_$name.txt
