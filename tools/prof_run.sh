@@ -9,4 +9,5 @@ rm -rf /tmp/prof_$name
 DB=$(find /tmp/prof_$name -name "*.db" | head -1)
 mkdir -p $R/gpurun_out/r3
 { echo "# rocprofv3 --kernel-trace --stats -- $*"; grep -a '^{"metric"' /tmp/prof_$name.log | cut -c1-400; python $R/tools/prof_summary.py $DB 40; } > $R/gpurun_out/r3/prof_$name.txt
+if [ -z "$DB" ]; then echo "no rocpd database produced; log tail:"; tail -n 20 /tmp/prof_$name.log; fi
 tail -n 45 $R/gpurun_out/r3/prof_$name.txt
