@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="keep the stage / AR-loop breakdown, skip the per-kernel roofline timings")
     ap.add_argument("--lanes", type=int, default=None, help="attention turnstile lanes of the interleaved decode chains (default: CondTupleGPT.ATTN_LANES; 0 = off)")
-    ap.add_argument("--no-subrecords", action="store_true", help="skip the config3 (batch-16 sampling) and train (one-rank training step) sub-records")
+    ap.add_argument("--no-subrecords", action="store_true", help="skip the config2 / config3 / config4 / train sub-records (BASELINE configs 2-5 on this GPU)")
     ap.add_argument("--mode", default="complete", choices=["complete", "train"],
                     help="complete: the shapes/s metric (default); train: DDP training step of the transformer (BASELINE config 5)")
     ap.add_argument("--share-device", action="store_true",
@@ -360,6 +360,57 @@ def config3_record(pipe, gpt, Xct, a):
     return rec
 
 
+def vqdif_records(vq16, dev):
+    """BASELINE configs 2 and 4, measured in the same run: (2) VQDIF-16 reconstruction of 32 full clouds (32768 points) on the 64^3
+    target lattice (vqdif.py:243-269: quantize -> sparse -> dense -> decode_index); (4) VQDIF-32 with a 256^3 query lattice,
+    batch 8 = 134 M query points (the decoder stress case).  Whole-call times; the SDF-query share is timed separately and
+    priced against its governing roofline (f32 MFMA, 31 488 FLOP per point) with the HBM fraction the north star asks for beside it."""
+    from shapeformer_amd import ops, synthetic, weights as W
+    from shapeformer_amd.pipeline import ShapeCompletion
+    from shapeformer_amd.vqdif import VQDIF
+    F32, HBM = 157.3, 8000.0
+    rec = {}
+
+    def timed(fn, n=3):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    def sdf_line(vq, B, Q):
+        grid = torch.randn(B, 64, 64, 64, 32, device=dev)
+        axis = torch.linspace(-1, 1, Q, device=dev)
+        o = torch.empty(B, Q ** 3, 1, device=dev)
+        ms = ev_time(lambda: ops.sdf_query_grid(axis, grid, vq.sdf_w, sigmoid=False, out=o), 2, warm=1)
+        pts = B * Q ** 3
+        tf = pts * 31488 / (ms * 1e-3) / 1e12
+        hb = (pts * 4 + B * 33.55e6) / (ms * 1e-3) / 1e9
+        return {"ms": round(ms, 3), "Gpts_per_s": round(pts / (ms * 1e-3) / 1e9, 2),
+                "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": F32, "unit": "TFLOP/s", "frac": round(tf / F32, 4)},
+                "hbm_algorithmic": {"achieved": round(hb, 1), "peak": HBM, "unit": "GB/s", "frac": round(hb / HBM, 4),
+                                    "note": "4 B out per lattice point + one read of the 33.5 MB feature grid per shape: the fused kernel is compute-bound (1 968 FLOP/B)"}}
+    # config 2
+    X2 = torch.from_numpy(synthetic.make_batch(2000, 32)["Xbd"]).to(dev)
+    pipe16 = ShapeCompletion(vq16, None)
+    t = timed(lambda: pipe16.reconstruct(X2, decode_res=64, max_length=512))
+    rec["config2"] = {"workload": "BASELINE config 2: VQDIF res16 reconstruction, batch 32, 32768-point clouds, 64^3 targets",
+                      "ms_per_batch": round(t * 1e3, 2), "shapes_per_s": round(32 / t, 1), "sdf_query_64cubed": sdf_line(vq16, 32, 64)}
+    del X2
+    # config 4
+    vq32 = VQDIF(res=32, device=dev)
+    X4 = torch.from_numpy(synthetic.make_batch(2100, 8)["Xbd"]).to(dev)
+    q, _, _ = vq32.quantize_cloud(X4)
+    t_enc = timed(lambda: vq32.quantize_cloud(X4))
+    t_dec = timed(lambda: vq32.decode_index(q, grid_Q=256), n=2)
+    rec["config4"] = {"workload": "BASELINE config 4: VQDIF res32 + 256^3 SDF query lattice, batch 8 (134 M query points)",
+                      "encode_quantize_ms": round(t_enc * 1e3, 2), "decode_index_ms": round(t_dec * 1e3, 1),
+                      "shapes_per_s": round(8 / (t_enc + t_dec), 2), "sdf_query_256cubed": sdf_line(vq32, 8, 256)}
+    del vq32, X4, q
+    torch.cuda.empty_cache()
+    return rec
+
+
 def train_record(gpt, a, batches=(1, 8), steps=5, warm=2):
     """BASELINE config 5 on ONE process, measured in the same run as the headline: the CondTupleGPT training step (forward, backward,
     fused AdamW; no gradient collective with one rank) at the YAML's per-GPU batch 1 and at batch 8."""
@@ -604,7 +655,8 @@ def main():
                                                             "frac": round(line["ar_loop"]["gemm_only_TFLOPs"] / 157.3, 4)}
             line["kernels"] = ks
         if world == 1 and not a.no_subrecords:
-            # BASELINE configs 3 and 5 in the same driver run (short: ~3 s + ~2 s), so that their numbers are not builder-only
+            # BASELINE configs 2-5 in the same driver run (a few seconds each), so that their numbers are not builder-only
+            line.update(vqdif_records(vq, dev))          # config2, config4
             line["config3"] = config3_record(pipe, gpt, Xct, a)
             line["train"] = train_record(gpt, a)
         if world == 1 and not a.no_cpu_baseline:
