@@ -1,5 +1,8 @@
 // libsfmi: version + small host utilities of the C ABI (include/sfmi.h).
 #include "sfmi_common.h"
+#include <string>
+
+SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512};
 
 // One wavefront that waits `ticks` of the constant 100 MHz wall clock: the probe `shapeformer_amd/gpt.py:_chain_streams` uses to
 // find HIP streams that really run concurrently (streams mapped to one hardware queue serialise; the runtime hands out only a few
@@ -11,6 +14,29 @@ __global__ void stream_spin_kernel(long long ticks) {
 
 extern "C" {
 int sfmi_version(void) { return 100; }
+int sfmi_tune_set(const char* name, int value) {
+  if (!name) return SFMI_EINVAL;
+  const std::string n(name);
+  SfmiTune& t = g_sfmi_tune;
+  if (n == "attn_blocks" && value >= 0) t.attn_blocks = value;
+  else if (n == "attn_unroll" && (value == 2 || value == 4 || value == 8)) t.attn_unroll = value;
+  else if (n == "attn_waves" && (value == 8 || value == 16)) t.attn_waves = value;
+  else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) t.attn_lds_pad = value;
+  else if (n == "sdf_blocks" && value >= 1 && value <= 512) t.sdf_blocks = value;
+  else return SFMI_EINVAL;
+  return SFMI_OK;
+}
+int sfmi_tune_get(const char* name) {
+  if (!name) return -1;
+  const std::string n(name);
+  const SfmiTune& t = g_sfmi_tune;
+  if (n == "attn_blocks") return t.attn_blocks;
+  if (n == "attn_unroll") return t.attn_unroll;
+  if (n == "attn_waves") return t.attn_waves;
+  if (n == "attn_lds_pad") return t.attn_lds_pad;
+  if (n == "sdf_blocks") return t.sdf_blocks;
+  return -1;
+}
 int sfmi_stream_spin(long long ticks, void* stream) {
   if (ticks < 0 || ticks > 100000000LL) return SFMI_EINVAL;   // <= 1 s
   hipLaunchKernelGGL(stream_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);

@@ -21,33 +21,7 @@
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// tuning hooks (performance only: none of them changes a result bit unless stated).  Set through sfmi_tune_set(name, value) by
-// bench.py / tools/ar_sweep.py; read at LAUNCH time, i.e. baked into a captured hipGraph (re-capture after changing one).
-//   attn_blocks : 0 = one workgroup per (row, head) item; n > 0 = persistent grid of n workgroups striding over the items
-//   attn_unroll : float4 loads in flight per lane (2, 4 or 8)
-//   attn_waves  : 16 or 8 waves per workgroup (NOT bit-identical to each other: different summation order)
-//   attn_lds_pad: extra dynamic LDS bytes per workgroup (caps resident workgroups per CU)
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad; };
-static SfmiTune g_tune = {0, 4, 16, 0};
-extern "C" int sfmi_tune_set(const char* name, int value) {
-  if (!name) return SFMI_EINVAL;
-  const std::string n(name);
-  if (n == "attn_blocks" && value >= 0) g_tune.attn_blocks = value;
-  else if (n == "attn_unroll" && (value == 2 || value == 4 || value == 8)) g_tune.attn_unroll = value;
-  else if (n == "attn_waves" && (value == 8 || value == 16)) g_tune.attn_waves = value;
-  else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) g_tune.attn_lds_pad = value;
-  else return SFMI_EINVAL;
-  return SFMI_OK;
-}
-extern "C" int sfmi_tune_get(const char* name) {
-  if (!name) return -1;
-  const std::string n(name);
-  if (n == "attn_blocks") return g_tune.attn_blocks;
-  if (n == "attn_unroll") return g_tune.attn_unroll;
-  if (n == "attn_waves") return g_tune.attn_waves;
-  if (n == "attn_lds_pad") return g_tune.attn_lds_pad;
-  return -1;
-}
+#define g_tune g_sfmi_tune   // launch-shape knobs (csrc/capi.hip: sfmi_tune_set)
 
 
 // ------------------------------------------------------------------------------------------------

@@ -232,7 +232,7 @@ int sfmi_sdf_pack_weights(const float* fc_p_w /*32x3*/, const float* fc_p_b, con
 
 static int sdf_grid_dim(long long total_tiles) {
   long long wgs = (total_tiles + 7) / 8;
-  if (wgs > 512) wgs = 512;   // 256 CUs x 2 resident workgroups (LDS-limited), persistent tile loop
+  if (wgs > g_sfmi_tune.sdf_blocks) wgs = g_sfmi_tune.sdf_blocks;   // default 512 = 256 CUs x 2 resident workgroups (LDS-limited), persistent tile loop
   if (wgs < 1) wgs = 1;
   return (int)wgs;
 }

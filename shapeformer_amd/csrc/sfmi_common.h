@@ -52,3 +52,15 @@ __device__ __forceinline__ float sfmi_hash_unit(unsigned seed, unsigned idx) {
 __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, float p, float inv_keep) {
   return sfmi_hash_unit(seed, idx) < p ? 0.0f : inv_keep;
 }
+
+// Launch-shape tuning knobs (performance only: none changes a result bit unless its comment says so).  Set through
+// sfmi_tune_set(name, value) (csrc/capi.hip) by bench.py / tools/ar_sweep.py; read at LAUNCH time, i.e. baked into a captured
+// hipGraph (re-capture after changing one).  Defaults = the product configuration.
+//   attn_blocks : 0 = one workgroup per (row, head) item of the decode attention; n > 0 = persistent grid of n workgroups
+//   attn_unroll : float4 loads in flight per lane (2, 4 or 8)
+//   attn_waves  : 16 or 8 waves per workgroup (NOT bit-identical to each other: different summation order)
+//   attn_lds_pad: extra dynamic LDS bytes per attention workgroup (caps resident workgroups per CU)
+//   sdf_blocks  : cap of the SDF-query kernel's persistent grid (default 512 = two workgroups per CU; 256 leaves half of every
+//                 CU's registers free - the background-decode experiment of profiles/r03_ar_overlap.md)
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks; };
+extern SfmiTune g_sfmi_tune;

@@ -56,7 +56,28 @@ def main():
         print(s, flush=True)
         out.write(s + "\n"); out.flush()
     say(f"# ar_sweep: model built in {time.time() - t0:.1f}s; default rows {a.rows} chains {a.chains} steps {a.steps}")
-    defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad")}
+    defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad", "sdf_blocks")}
+    bgst = {}        # background SDF-query load (`bgsdf=<shapes per launch>[:<launches>]`): the MFMA-bound decode stage of a previous batch
+
+    def bg_setup(nshape):
+        if "vq" not in bgst:
+            from shapeformer_amd.vqdif import VQDIF
+            bgst["vq"] = VQDIF(res=16, device=dev)
+            bgst["stream"] = torch.cuda.Stream(device=dev)
+            bgst["axis"] = torch.linspace(-1, 1, 128, device=dev)
+        if bgst.get("n") != nshape:
+            bgst["grid"] = torch.randn(nshape, 64, 64, 64, 32, device=dev)
+            bgst["out"] = torch.empty(nshape, 128 ** 3, 1, device=dev)
+            bgst["n"] = nshape
+
+    def bg_launch(k):
+        from shapeformer_amd import ops
+        evs = []
+        with torch.cuda.stream(bgst["stream"]):
+            for _ in range(k):
+                ops.sdf_query_grid(bgst["axis"], bgst["grid"], bgst["vq"].sdf_w, sigmoid=True, out=bgst["out"])
+                e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+        return evs
     cache = {}
     for line in sys.stdin:
         line = line.strip()
@@ -68,6 +89,7 @@ def main():
         lclo, lchi = int(kv.pop("lclo", 100)), int(kv.pop("lchi", 216))     # condition lengths (short traces: start near the mid-run length)
         gpt._ablate = kv.pop("ablate", "")
         gpt.ATTN_LANES = int(kv.pop("lanes", "0"))
+        bg = kv.pop("bgsdf", None)
         for k, v in defaults.items():
             L.check(lib.sfmi_tune_set(k.encode(), int(kv.pop(k, v))), f"tune {k}")
         for k, v in kv.items():
@@ -78,21 +100,43 @@ def main():
         tok, Lc = cache[(rows, lclo, lchi)]
         ms = []
         try:
+            bginfo = ""
+            if bg:
+                nshape, nl = (int(v) for v in (bg.split(":") + ["60"])[:2])
+                bg_setup(nshape)
+                bgst["stream"].synchronize()
+                t_alone = []
+                for _ in range(2):          # the same launch with the chip to itself
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(bgst["stream"])
+                    e1 = bg_launch(3)[-1]; e1.synchronize(); t_alone.append(e0.elapsed_time(e1) / 3)
             for rep in range(a.reps + 1):
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-                kw = dict(max_steps=a.steps, stop_early=False, seed=rep, after_prefill=lambda: ev[0].record())
+                bgev = []
+
+                def started():
+                    ev[0].record()
+                    if bg and rep:
+                        bgst["stream"].wait_event(ev[0])
+                        bgev.extend(bg_launch(nl))
+                kw = dict(max_steps=a.steps, stop_early=False, seed=rep, after_prefill=started)
                 if chains > 1:
                     r = gpt.sample_microbatched(tok, Lc, n_micro=chains, **kw)
                 else:
                     r = gpt.sample(tok, Lc, to_host=False, **kw)
                 ev[1].record()
+                ev[1].synchronize()
+                done_bg = sum(1 for e in bgev if e.query())
                 torch.cuda.synchronize()
                 assert int(r["steps"]) == a.steps
                 if rep:
                     ms.append(ev[0].elapsed_time(ev[1]) / a.steps)
+                    if bg:
+                        ar_ms = ev[0].elapsed_time(ev[1])
+                        bginfo = (f"   bg SDF {nshape} shapes/launch: alone {min(t_alone):.2f} ms, {done_bg} of {nl} launches done inside the {ar_ms:.0f} ms loop "
+                                  f"= {done_bg * min(t_alone):.0f} ms of decode work hidden ({done_bg * nshape / ar_ms * 1e3:.0f} shapes/s of SDF)")
             sem = gpt._sem.cpu().tolist()
             say(f"{name:28s} rows {rows} chains {chains} {' '.join(kvs):50s} ms/step " + " ".join(f"{m:.3f}" for m in ms)
-                + f"   rows/ms {rows / min(ms):.1f}" + (f"   turnstile tickets {sem[0]} time-outs {sem[2]}" if gpt.ATTN_LANES else ""))
+                + f"   rows/ms {rows / min(ms):.1f}" + (f"   turnstile tickets {sem[0]} time-outs {sem[2]}" if gpt.ATTN_LANES else "") + bginfo)
         except Exception as e:   # keep sweeping
             say(f"{name:28s} FAILED: {type(e).__name__}: {e}")
             torch.cuda.synchronize()
