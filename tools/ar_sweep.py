@@ -35,6 +35,61 @@ def synth_cond(seed, B, lo=100, hi=216, Lpad=406):
     return torch.from_numpy(tok), torch.from_numpy(Lc)
 
 
+class PowerProbe:
+    """Samples the GPU's package power and shader clock from sysfs (hwmon) in a thread while a configuration runs: is the loop
+    power / clock limited when HBM-bound and MFMA-bound kernels run together?"""
+
+    def __init__(self):
+        import glob
+        hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.files = {}
+        for h in hw:
+            for key, names in (("power_uW", ("power1_average", "power1_input")), ("sclk_Hz", ("freq1_input",)), ("mclk_Hz", ("freq2_input",)),
+                               ("temp_mC", ("temp1_input",))):
+                for n in names:
+                    f = os.path.join(h, n)
+                    if key not in self.files and os.path.exists(f):
+                        self.files[key] = f
+            if self.files:
+                break
+        self.samples, self._stop, self._th = [], False, None
+
+    def _read(self):
+        out = {}
+        for k, f in self.files.items():
+            try:
+                out[k] = float(open(f).read().strip())
+            except Exception:
+                pass
+        return out
+
+    def start(self):
+        import threading
+        self.samples, self._stop = [], False
+
+        def run():
+            while not self._stop:
+                self.samples.append(self._read())
+                time.sleep(0.02)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th:
+            self._th.join()
+        if not self.samples or not self.files:
+            return ""
+        def mean(k, sc):
+            v = [s[k] for s in self.samples if k in s]
+            return f"{sum(v) / len(v) / sc:.0f}" if v else "-"
+        def mx(k, sc):
+            v = [s[k] for s in self.samples if k in s]
+            return f"{max(v) / sc:.0f}" if v else "-"
+        return (f"   power {mean('power_uW', 1e6)} W (max {mx('power_uW', 1e6)}), sclk {mean('sclk_Hz', 1e6)} MHz, mclk {mean('mclk_Hz', 1e6)} MHz, "
+                f"temp {mean('temp_mC', 1e3)} C [{len(self.samples)} samples]")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/r3/ar_sweep.txt")
@@ -57,6 +112,8 @@ def main():
         out.write(s + "\n"); out.flush()
     say(f"# ar_sweep: model built in {time.time() - t0:.1f}s; default rows {a.rows} chains {a.chains} steps {a.steps}")
     defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad", "sdf_blocks")}
+    probe = PowerProbe()
+    say(f"# power probe files: {probe.files}")
     bgst = {}        # background SDF-query load (`bgsdf=<shapes per launch>[:<launches>]`): the MFMA-bound decode stage of a previous batch
 
     def bg_setup(nshape):
@@ -119,12 +176,15 @@ def main():
                         bgst["stream"].wait_event(ev[0])
                         bgev.extend(bg_launch(nl))
                 kw = dict(max_steps=a.steps, stop_early=False, seed=rep, after_prefill=started)
+                if rep:
+                    probe.start()
                 if chains > 1:
                     r = gpt.sample_microbatched(tok, Lc, n_micro=chains, **kw)
                 else:
                     r = gpt.sample(tok, Lc, to_host=False, **kw)
                 ev[1].record()
                 ev[1].synchronize()
+                pw = probe.stop() if rep else ""
                 done_bg = sum(1 for e in bgev if e.query())
                 torch.cuda.synchronize()
                 assert int(r["steps"]) == a.steps
@@ -136,7 +196,7 @@ def main():
                                   f"= {done_bg * min(t_alone):.0f} ms of decode work hidden ({done_bg * nshape / ar_ms * 1e3:.0f} shapes/s of SDF)")
             sem = gpt._sem.cpu().tolist()
             say(f"{name:28s} rows {rows} chains {chains} {' '.join(kvs):50s} ms/step " + " ".join(f"{m:.3f}" for m in ms)
-                + f"   rows/ms {rows / min(ms):.1f}" + (f"   turnstile tickets {sem[0]} time-outs {sem[2]}" if gpt.ATTN_LANES else "") + bginfo)
+                + f"   rows/ms {rows / min(ms):.1f}" + (f"   turnstile tickets {sem[0]} time-outs {sem[2]}" if gpt.ATTN_LANES else "") + bginfo + pw)
         except Exception as e:   # keep sweeping
             say(f"{name:28s} FAILED: {type(e).__name__}: {e}")
             torch.cuda.synchronize()
