@@ -41,11 +41,20 @@ class PowerProbe:
 
     def __init__(self):
         import glob
-        hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        hw = []
+        try:        # the hwmon node of THE device this process computes on (a box shows several cards; only one is ours)
+            pr = torch.cuda.get_device_properties(0)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            hw = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*"))
+            self.bdf = bdf
+        except Exception as e:
+            self.bdf = f"? ({e})"
+        if not hw:
+            hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
         self.files = {}
         for h in hw:
             for key, names in (("power_uW", ("power1_average", "power1_input")), ("sclk_Hz", ("freq1_input",)), ("mclk_Hz", ("freq2_input",)),
-                               ("temp_mC", ("temp1_input",))):
+                               ("temp_mC", ("temp1_input", "temp2_input"))):
                 for n in names:
                     f = os.path.join(h, n)
                     if key not in self.files and os.path.exists(f):
@@ -113,7 +122,7 @@ def main():
     say(f"# ar_sweep: model built in {time.time() - t0:.1f}s; default rows {a.rows} chains {a.chains} steps {a.steps}")
     defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad", "sdf_blocks")}
     probe = PowerProbe()
-    say(f"# power probe files: {probe.files}")
+    say(f"# power probe: device {probe.bdf}, files {probe.files}")
     bgst = {}        # background SDF-query load (`bgsdf=<shapes per launch>[:<launches>]`): the MFMA-bound decode stage of a previous batch
 
     def bg_setup(nshape):
