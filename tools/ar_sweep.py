@@ -129,7 +129,10 @@ def main():
         if "vq" not in bgst:
             from shapeformer_amd.vqdif import VQDIF
             bgst["vq"] = VQDIF(res=16, device=dev)
-            bgst["stream"] = torch.cuda.Stream(device=dev)
+            # a stream that shares NO hardware queue with the chains (probed like the chain streams; needs GPU_MAX_HW_QUEUES > chains)
+            ss = gpt._chain_streams(a.chains + 1)
+            bgst["stream"] = ss[a.chains]
+            say(f"# background stream: probed set of {len(ss)} streams, shared_queue={getattr(gpt, '_mb_shared_queue', False)}, probe ms {getattr(gpt, '_chain_probe', [])[-12:]}")
             bgst["axis"] = torch.linspace(-1, 1, 128, device=dev)
         if bgst.get("n") != nshape:
             bgst["grid"] = torch.randn(nshape, 64, 64, 64, 32, device=dev)
