@@ -54,7 +54,7 @@ class PowerProbe:
         self.files = {}
         for h in hw:
             for key, names in (("power_uW", ("power1_average", "power1_input")), ("sclk_Hz", ("freq1_input",)), ("mclk_Hz", ("freq2_input",)),
-                               ("temp_mC", ("temp1_input", "temp2_input"))):
+                               ("temp_mC", ("temp1_input", "temp2_input")), ("cap_uW", ("power1_cap",))):
                 for n in names:
                     f = os.path.join(h, n)
                     if key not in self.files and os.path.exists(f):
@@ -95,7 +95,7 @@ class PowerProbe:
         def mx(k, sc):
             v = [s[k] for s in self.samples if k in s]
             return f"{max(v) / sc:.0f}" if v else "-"
-        return (f"   power {mean('power_uW', 1e6)} W (max {mx('power_uW', 1e6)}), sclk {mean('sclk_Hz', 1e6)} MHz, mclk {mean('mclk_Hz', 1e6)} MHz, "
+        return (f"   power {mean('power_uW', 1e6)} W (max {mx('power_uW', 1e6)}, cap {mx('cap_uW', 1e6)}), sclk {mean('sclk_Hz', 1e6)} MHz, mclk {mean('mclk_Hz', 1e6)} MHz, "
                 f"temp {mean('temp_mC', 1e3)} C [{len(self.samples)} samples]")
 
 
