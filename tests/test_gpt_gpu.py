@@ -338,3 +338,29 @@ def test_more_rows_than_the_chains_hold_run_as_rounds(dev):
     seq = want["seq"].cpu()
     for r in (0, 57, 133, 199):
         assert torch.equal(h["samples"][r], seq[r, int(Lc[r]):int(Lc[r]) + steps].long())
+
+
+def test_large_batches_keep_the_single_chain_features(dev):
+    """More than 96 rows in one `sample` call run as interleaved chains; the features of the single-chain path must survive the
+    split: shared-prefix KV (every chain prefills the common condition once) and a non-empty z prefix, both bit-identical to the
+    plain expanded run of the same rows."""
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    kw = dict(n_embd=128, n_layers=(2, 1), block_size=400)
+    g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=400, device=dev)
+    rs = np.random.RandomState(9)
+    S, Lc, steps = 120, 14, 7
+    c = np.full((1, Lc, 2), 4096, np.int32)
+    c[0, :Lc - 1, 0] = np.sort(rs.choice(4096, Lc - 1, replace=False)); c[0, :Lc - 1, 1] = rs.randint(0, 4096, Lc - 1)
+    ct = torch.from_numpy(np.repeat(c, S, 0)); lt = torch.full((S,), Lc, dtype=torch.int32)
+    a = g.sample(ct, lt, max_steps=steps, seed=6, stop_early=False, shared_prefix=False)
+    b = g.sample(ct, lt, max_steps=steps, seed=6, stop_early=False, shared_prefix=True)
+    assert a["samples"].shape == (S, steps, 2) and torch.equal(a["samples"], b["samples"]) and torch.equal(a["log_prob"], b["log_prob"])
+    assert len({tuple(r.flatten().tolist()) for r in a["samples"][1:]}) > 1       # the stochastic rows really differ from each other
+    z = a["samples"][:, :3].to(torch.int32)                                        # continue every row after its own first 3 tokens
+    zc = g.sample(ct, lt, max_steps=steps - 3, seed=8, stop_early=False, z_tokens=z)
+    assert zc["samples"].shape == (S, steps, 2) and torch.equal(zc["samples"][:, :3], a["samples"][:, :3])
+    one = g.sample(ct[:5], lt[:5], max_steps=steps - 3, seed=8, stop_early=False, z_tokens=z[:5])
+    # rows 0..4 as a 5-row batch: row 0 is greedy in both; rows 1..4 draw with uniforms indexed by (global row, rows_total), so only
+    # the greedy row is comparable across batch sizes
+    assert torch.equal(one["samples"][0], zc["samples"][0])
