@@ -156,6 +156,11 @@ def test_get_indices_contract_and_random_cind_masking_gate(dev):
     rep.random_cind_masking = False
     ct2, _, _, _ = rep.get_indices(Xct, Xbd, stage="train")
     assert torch.equal(ct2, c)
+    # no_val_ind=True (representers.py:75-76): the value column is zeroed, end-token row included; positions are untouched
+    rep.no_val_ind = True
+    c3, z3, _, _ = rep.get_indices(Xct, Xbd, stage="test")
+    rep.no_val_ind = False
+    assert bool((c3[..., 1] == 0).all()) and bool((z3[..., 1] == 0).all()) and torch.equal(c3[..., 0], c[..., 0])
 
 
 def test_missing_vqdif_checkpoint_raises_and_shapeformer_checkpoint_restores_the_frozen_vqdif(dev, tmp_path):
