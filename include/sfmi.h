@@ -124,7 +124,9 @@ int sfmi_sgemm_mfma_f32(int transA, int transB, int M, int N, int K, const float
                         int ldc, int accumulate, const float* bias, int act, const float* resid, float* ws, long long ws_floats,
                         void* stream);
 int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream); /* shapeformer.py:132-140 */
-/* decode step (M = B <= 96 rows per launch - larger batches run as several chains; packed x/out/resid hold ceil(M/16)*16 rows) */
+/* decode step (M = B <= 192 rows per launch: workgroups of up to 6 row tiles, more rows = row groups in grid.z; larger batches run as
+ * several chains; packed x/out/resid hold sfmi_decode_gemm_padded_rows(M) rows) */
+int sfmi_decode_gemm_padded_rows(int M);
 size_t sfmi_skinny16_pack_floats(int N, int K);
 int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out); /* [host] (N,K) -> [N/16][K/16][64][4] */
 size_t sfmi_decode_gemm_slab_floats(int M, int N, int S);

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "sfmi_ar_n_extra_i32": (i32, [c_ptr, c_ptr, c_ptr, i32, i32, i32, i32, c_ptr]),
     # transformer
     "sfmi_gemm_f32": (i32, [c_ptr] * 5 + [i64, i32, i32, i32, i64, i64, c_ptr]),
+    "sfmi_decode_gemm_padded_rows": (i32, [i32]),
     "sfmi_skinny16_pack_floats": (sz, [i32, i32]),
     "sfmi_skinny16_pack_weight": (i32, [c_ptr, i32, i32, c_ptr]),
     "sfmi_gpt_embed_f32": (i32, [c_ptr] * 15 + [i32] * 5 + [c_ptr, i32, c_ptr]),

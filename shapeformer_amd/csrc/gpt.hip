@@ -194,6 +194,12 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   __shared__ float st1[NW][MT][16], st2[NW][MT][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, ml = lane & 15;
   const int nt = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+  // ROW GROUPS (gridDim.z > 1): a launch of more than 96 rows is cut into groups of MT row tiles; group g = blockIdx.z owns the row
+  // tiles t0 .. t0+MT-1 of the fragment-packed operands (row tiles are the outermost dimension of that layout, so a group is a
+  // contiguous slab).  Every row keeps the arithmetic of the one-group kernel; the groups of an n-tile stream the same weight
+  // slice (the later ones from the XCD's L2 / the Infinity Cache), so one launch serves up to 192 rows per chain with ONE set of
+  // launch boundaries and one HBM pass over the weights.
+  const int t0 = blockIdx.z * MT;
   const int kslice = a.K / S;
   const int kw = kslice / NW;
   const int k0 = sp * kslice + wave * kw;
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)nt * (a.K / 16) + k0 / 16) * 64;
   const f32x4* xr[MT];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) xr[j] = reinterpret_cast<const f32x4*>(a.x) + ((long long)j * (a.K / 16) + k0 / 16) * 64;
+  for (int j = 0; j < MT; ++j) xr[j] = reinterpret_cast<const f32x4*>(a.x) + ((long long)(t0 + j) * (a.K / 16) + k0 / 16) * 64;
   const unsigned lo = (unsigned)lane;
   f32x4 acc[MT][2];
   float s1[MT], s2[MT];
@@ -212,8 +218,8 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   // after the weight stream: the memory system is saturated by then and a late load costs ~1.5 us.
   f32x4 pc1 = {0.f, 0.f, 0.f, 0.f}, pc2 = pc1, pres = pc1;
   const int n_ep = nt * 16 + 4 * q;
-  const long long off_ep = a.out_packed ? (((long long)wave * (a.N >> 4) + nt) * 64 + lane) * 4
-                                        : (long long)min(wave * 16 + ml, a.M - 1) * a.ldo + n_ep;
+  const long long off_ep = a.out_packed ? (((long long)(t0 + wave) * (a.N >> 4) + nt) * 64 + lane) * 4
+                                        : (long long)min((t0 + wave) * 16 + ml, a.M - 1) * a.ldo + n_ep;
   if (wave < MT && n_ep < a.N) {
     if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
     if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     if (S > 1) {
       // split-K: publish this slice's slab write-through, take a ticket; the last arriver of the (nt, j) tile
       // sums the S slabs in slice order (deterministic) and runs the epilogue.
-      const long long tile = (long long)j * gridDim.x + nt;
+      const long long tile = (long long)(t0 + j) * gridDim.x + nt;
       float* slab = a.slab + (tile * S + sp) * 320;          // 256 acc floats + 64 stat floats
       st_sc1(slab + lane * 4, r);
       if (a.ln && q == 0) {
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
           if (s + u < S) { r = r + tv[u]; t1 += u1[u]; t2 += u2[u]; }
       }
     }
-    const int m = j * 16 + ml;
+    const int m = (t0 + j) * 16 + ml;
     const int n = nt * 16 + 4 * q;
     if ((a.out_packed || m < a.M) && n < a.N) {
       if (a.ln) {
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
       }
-      const long long off = a.out_packed ? (((long long)j * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
+      const long long off = a.out_packed ? (((long long)(t0 + j) * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
       if (a.resid) r = r + pres;
       *reinterpret_cast<f32x4*>(a.out + off) = r;
     }
@@ -993,22 +999,29 @@ int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out) {
 // x (and out/resid when out_packed) are fragment-packed [ceil(M/16)][N/16][64][4] (see pk_off); out_packed == 0
 // writes row-major (M,ldo) (used for the logits handed to the sampler).  S > 1 splits K across S workgroups per
 // n-tile with an in-kernel deterministic last-arriver reduction (slab/cnt scratch, cnt zero-initialised ONCE).
-size_t sfmi_decode_gemm_slab_floats(int M, int N, int S) { return (size_t)((M + 63) / 64 * 4) * ((N + 15) / 16) * S * 320; }
+size_t sfmi_decode_gemm_slab_floats(int M, int N, int S) { return (size_t)((M + 63) / 64 * 4 + 2) * ((N + 15) / 16) * S * 320; }
+// rows the fragment-packed operands of sfmi_decode_gemm_f32 must hold for M rows: groups * MT * 16 (M <= 96: ceil(M/16)*16)
+int sfmi_decode_gemm_padded_rows(int M) {
+  const int tiles = (M + 15) / 16, groups = (tiles + 5) / 6, MT = (tiles + groups - 1) / groups;
+  return groups * MT * 16;
+}
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
                          float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
                          int* cnt, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 96 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;   // larger batches: several chains (gpt.py)
+  if (!x || !Wp16 || !out || M <= 0 || M > 192 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;   // larger batches: several chains (gpt.py)
   if (out_packed && N % 16) return SFMI_EINVAL;
   if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
   const int kslice = K / S;
+  // up to 6 row tiles per workgroup; more rows = row groups (grid.z), each of MT tiles: the packed operands must hold groups * MT * 16 rows
+  const int tiles = (M + 15) / 16, groups = (tiles + 5) / 6, MT = (tiles + groups - 1) / groups;
 #ifdef DG_FORCE_NW    // tuning hook of tools/ubench/dgemm_chain.hip
   const int NWv = DG_FORCE_NW;
 #else
-  int NWv = (kslice >= 2048 && M <= 64) ? 16 : 8;
+  int NWv = (kslice >= 2048 && MT <= 4) ? 16 : 8;
   // run-time tuning hooks (tools/sweep_dgemm.sh): waves per workgroup (4 / 8 / 16 k-parts) and k16-steps of loads in flight
   static const int env_nw = getenv("SFMI_DGEMM_NW") ? atoi(getenv("SFMI_DGEMM_NW")) : 0;
   static const int env_un = getenv("SFMI_DGEMM_UN") ? atoi(getenv("SFMI_DGEMM_UN")) : 0;
-  if ((env_nw == 4 || env_nw == 8 || env_nw == 16) && kslice % (16 * env_nw) == 0 && (M + 15) / 16 <= (env_nw == 4 ? 4 : 6)) NWv = env_nw;
+  if ((env_nw == 4 || env_nw == 8 || env_nw == 16) && kslice % (16 * env_nw) == 0 && MT <= (env_nw == 4 ? 4 : 6)) NWv = env_nw;
   if (kslice % (16 * NWv)) NWv = kslice % 64 == 0 ? 4 : 1;   // narrow models (K-slice not a multiple of 128): fewer k-parts
 #endif
   if (kslice % (16 * NWv)) return SFMI_EINVAL;
@@ -1016,8 +1029,7 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
   a.out_packed = out_packed; a.slab = slab; a.cnt = cnt;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((N + 15) / 16, S);
-  const int MT = (M + 15) / 16;
+  dim3 grid((N + 15) / 16, S, groups);
   const int steps = kslice / NWv / 16;
   int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 5 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave (5 row tiles: 128 VGPRs; 6: 138 with two)
 #ifdef DG_FORCE_UN

@@ -184,8 +184,9 @@ class CondTupleGPT:
             return cur
         dev, D = self.dev, self.D
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
-        # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off)
-        Bp = (B + 15) // 16 * 16
+        # decode activations are fragment-packed in 16-row tiles (csrc/gpt.hip pk_off); above 96 rows the decode GEMM works on
+        # row groups of equal tile counts, so the buffers hold groups x tiles-per-group x 16 rows
+        Bp = int(L.lib().sfmi_decode_gemm_padded_rows(B))
         st = dict(key=key,
                   seq=torch.zeros(B, self.Lmax + 1, 2, device=dev, dtype=torch.int32),
                   len=torch.zeros(B, device=dev, dtype=torch.int32), Lc=torch.zeros(B, device=dev, dtype=torch.int32),
@@ -393,7 +394,8 @@ class CondTupleGPT:
     # Two lanes measured best with four chains (6.48 against 6.68 ms per 320-row step ungated, 6.98 with one lane;
     # profiles/r03_ar_overlap.md).
     ATTN_LANES = 2
-    MAX_CHAIN_ROWS = 96    # rows per decode launch (6 row tiles of csrc/gpt.hip:dgemm_kernel); larger batches = several chains
+    MAX_CHAIN_ROWS = 192   # rows per decode chain: row groups of up to 6 row tiles (96 rows) per decode-GEMM workgroup; larger batches = several chains
+    SINGLE_CHAIN_ROWS = 96  # `sample` keeps a batch in ONE chain up to here and interleaves chains above (a lone chain cannot overlap anything)
 
     def decode_step(self, st, B, sp):
         """Position t = len[b]-1 of every row through both stages; st["resid"] must hold its embedding on entry
@@ -542,8 +544,8 @@ class CondTupleGPT:
         Returns dict(samples (B,L_z+steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
         Mirrors ShapeFormer.sample_indices (shapeformer.py:54-123); torch.multinomial is replaced by an
         inverse-CDF draw on counter-hash uniforms (oracle/gpt_oracle.py:uniforms)."""
-        if c_tokens.shape[0] > self.MAX_CHAIN_ROWS:
-            # more rows than one decode launch holds: the same rows as interleaved chains (identical tokens - uniforms and the
+        if c_tokens.shape[0] > self.SINGLE_CHAIN_ROWS:
+            # more rows than one chain should hold: the same rows as interleaved chains (identical tokens - uniforms and the
             # greedy row are indexed by global row), results gathered as for one chain
             n_micro = min(4, -(-c_tokens.shape[0] // 80))      # up to 4 chains of <= 96 rows; beyond 384 rows: successive rounds
             r = self.sample_microbatched(c_tokens, Lc, n_micro=n_micro, max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature,

@@ -314,14 +314,15 @@ def test_attention_turnstile_is_scheduling_only(dev):
 
 
 def test_more_rows_than_the_chains_hold_run_as_rounds(dev):
-    """200 rows on 2 chains (2 x 96 rows at most) = two successive rounds of 2 x 50-row chains; the same rows as 3 chains in one
-    round must give the same tokens / log-probs (uniforms and the greedy row are indexed by GLOBAL row in every round)."""
+    """400 rows on 2 chains (2 x 192 rows at most) = two successive rounds of 2 x 100-row chains (each two row groups of the decode
+    GEMM); the same rows as 3 chains in one round must give the same tokens / log-probs (uniforms and the greedy row are indexed
+    by GLOBAL row in every round)."""
     from shapeformer_amd import weights as W
     from shapeformer_amd.gpt import CondTupleGPT
     kw = dict(n_embd=128, n_layers=(2, 1), block_size=400)
     g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=400, device=dev)
     rs = np.random.RandomState(8)
-    B, steps = 200, 6
+    B, steps = 400, 6
     Lc = rs.randint(6, 20, B).astype(np.int32)
     tok = np.full((B, 32, 2), 4096, np.int32)
     for b in range(B):
@@ -333,10 +334,10 @@ def test_more_rows_than_the_chains_hold_run_as_rounds(dev):
     assert b2["steps"] == steps and b2["state"]["seq"].shape[0] == B
     for k in ("seq", "len", "Lc", "logp"):
         assert torch.equal(b2["state"][k], want[k]), k
-    # and through `sample` (host result), which splits 200 rows into 3 chains of <= 80
+    # and through `sample` (host result), which splits the rows into 4 chains
     h = g.sample(ct, lt, max_steps=steps, stop_early=False, seed=4)
     seq = want["seq"].cpu()
-    for r in (0, 57, 133, 199):
+    for r in (0, 57, 133, 399):
         assert torch.equal(h["samples"][r], seq[r, int(Lc[r]):int(Lc[r]) + steps].long())
 
 
