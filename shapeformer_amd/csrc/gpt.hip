@@ -518,10 +518,14 @@ __global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : 4) void attn_decode_kernel(A
 // vector register of every CU, and the other chains' GEMM workgroups cannot be placed until one of them drains: HBM-bound and
 // MFMA-bound phases then time-share the chip instead of overlapping (profiles/r03_ar_overlap.md).  With at most `lanes` KV
 // streams resident - each sized to saturate HBM with half of a CU's registers - a GEMM workgroup always fits beside them.
-// Carries no data (pure scheduling): a wrong order can only cost time.  A wait longer than 20 ms gives up and counts in sem[2].
+// Carries no data (pure scheduling): a wrong order can only cost time.  A wait longer than 20 ms gives up, counts in sem[2] and
+// disarms the turnstile until the caller re-arms it (zeroes sem).
 __global__ __launch_bounds__(64) void attn_gate_kernel(int* sem, int lanes) {
   if (threadIdx.x != 0) return;
   const int my = __hip_atomic_fetch_add(sem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a gate that ever timed out (two chains on one hardware queue after all: the gate would be holding up the very launch it waits
+  // for) switches the turnstile off for the rest of the run - the chains then run ungated, as in round 2, instead of paying 20 ms each
+  if (__hip_atomic_load(sem + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
   while (__hip_atomic_load(sem + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + lanes <= my) {
     __builtin_amdgcn_s_sleep(8);

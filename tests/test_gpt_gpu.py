@@ -198,15 +198,21 @@ def test_chain_streams_run_concurrently(dev):
     cur = torch.cuda.current_stream()
     for i in range(3):
         for j in range(i + 1, 3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur)
-            for s in (S[i], S[j]):
-                s.wait_event(e0)
-                L.check(L.lib().sfmi_stream_spin(20000, s.cuda_stream), "spin")
-                cur.wait_stream(s)
-            e1.record(cur)
-            e1.synchronize()
-            assert 0.19 < e0.elapsed_time(e1) < 0.32, (i, j, e0.elapsed_time(e1))
+            ts = []
+            for _ in range(4):       # best of four: a one-off hiccup (clock ramp, a straggling launch of an earlier test) is not a shared queue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record(cur)
+                for s in (S[i], S[j]):
+                    s.wait_event(e0)
+                    L.check(L.lib().sfmi_stream_spin(20000, s.cuda_stream), "spin")
+                    cur.wait_stream(s)
+                e1.record(cur)
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+                if 0.19 < ts[-1] < 0.32:
+                    break
+            assert 0.19 < min(ts) < 0.32, (i, j, ts)     # two 200 us spins side by side; ~0.43 ms when the streams share a queue
     assert L.lib().sfmi_stream_spin(-1, None) == -1            # SFMI_EINVAL
 
 
