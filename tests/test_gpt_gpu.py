@@ -194,25 +194,30 @@ def test_chain_streams_run_concurrently(dev):
     torch.cuda.synchronize()
     S = g._chain_streams(3)
     assert len(S) == 3 and len({s.cuda_stream for s in S}) == 3
-    assert g._chain_streams(2)[0] is S[0]                            # cached
     cur = torch.cuda.current_stream()
-    for i in range(3):
-        for j in range(i + 1, 3):
-            ts = []
-            for _ in range(4):       # best of four: a one-off hiccup (clock ramp, a straggling launch of an earlier test) is not a shared queue
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                e0.record(cur)
-                for s in (S[i], S[j]):
-                    s.wait_event(e0)
-                    L.check(L.lib().sfmi_stream_spin(20000, s.cuda_stream), "spin")
-                    cur.wait_stream(s)
-                e1.record(cur)
-                e1.synchronize()
-                ts.append(e0.elapsed_time(e1))
-                if 0.19 < ts[-1] < 0.32:
-                    break
-            assert 0.19 < min(ts) < 0.32, (i, j, ts)     # two 200 us spins side by side; ~0.43 ms when the streams share a queue
+
+    def pair_ms(a, b):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(cur)
+        for s in (a, b):
+            s.wait_event(e0)
+            L.check(L.lib().sfmi_stream_spin(20000, s.cuda_stream), "spin")
+            cur.wait_stream(s)
+        e1.record(cur)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    # The set is re-validated at EVERY use (the stream -> queue binding is not static: a set that passed the probe can come back
+    # with two streams on one queue after sitting idle); what the product relies on is that the set `_chain_streams` hands out is
+    # concurrent when it hands it out.  Two 200 us spins side by side take ~0.23 ms, ~0.43 ms on a shared queue.
+    ok = False
+    for attempt in range(4):
+        S = g._chain_streams(3)
+        ts = [pair_ms(S[i], S[j]) for i in range(3) for j in range(i + 1, 3)]
+        if all(0.19 < t < 0.32 for t in ts):
+            ok = True
+            break
+    assert ok, (ts, getattr(g, "_chain_reprobes", 0), g._chain_probe[-12:])
     assert L.lib().sfmi_stream_spin(-1, None) == -1            # SFMI_EINVAL
 
 
