@@ -200,9 +200,10 @@ def test_chain_streams_run_concurrently(dev):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record(cur)
+        for s in (a, b):         # BOTH spins are enqueued before the current stream waits for either: a wait on the current stream is a
+            s.wait_event(e0)     # barrier in ITS hardware queue, and a chain stream that happens to share that queue would queue its
+            L.check(L.lib().sfmi_stream_spin(20000, s.cuda_stream), "spin")   # spin behind it (measured: 0.43 ms for such a pair)
         for s in (a, b):
-            s.wait_event(e0)
-            L.check(L.lib().sfmi_stream_spin(20000, s.cuda_stream), "spin")
             cur.wait_stream(s)
         e1.record(cur)
         e1.synchronize()
