@@ -188,13 +188,19 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
 #ifndef DG_MFMA
 #define DG_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 #endif
-template <int MT, int NW, int UN>
+template <int MT, int NW, int UN, int NT = 1>
 __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[NW][MT][4][64];
+  // NT n-tiles per wave (NT = 2: an activation fragment feeds two weight tiles - 5 operand loads per 24 MFMAs instead of 7 for the
+  // same 6 accumulator tiles - and the 96-row launch becomes two row groups of MT = 3, whose batch of two k16-steps fits 128 VGPRs,
+  // which the 6-row-tile instance does not).  VT = MT * NT "virtual tiles" (row tile j, column tile nn) per wave.
+  constexpr int VT = MT * NT;
+  __shared__ __attribute__((aligned(16))) float red[NW][VT][4][64];
   __shared__ float st1[NW][MT][16], st2[NW][MT][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, ml = lane & 15;
-  const int nt = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
-  // ROW GROUPS (gridDim.z > 1): a launch of more than 96 rows is cut into groups of MT row tiles; group g = blockIdx.z owns the row
+  const int sp = blockIdx.y, S = gridDim.y;
+  const int ntiles = (a.N + 15) >> 4;
+  const int nt0 = blockIdx.x * NT;             // first n-tile of this workgroup (an odd tile count: the last workgroup's second tile is masked)
+  // ROW GROUPS (gridDim.z > 1): a launch of more than MT row tiles is cut into groups of MT row tiles; group g = blockIdx.z owns the row
   // tiles t0 .. t0+MT-1 of the fragment-packed operands (row tiles are the outermost dimension of that layout, so a group is a
   // contiguous slab).  Every row keeps the arithmetic of the one-group kernel; the groups of an n-tile stream the same weight
   // slice (the later ones from the XCD's L2 / the Infinity Cache), so one launch serves up to 192 rows per chain with ONE set of
@@ -205,22 +211,30 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   const int k0 = sp * kslice + wave * kw;
   // operand addresses = wave-uniform base (scalar registers) + one 32-bit per-lane offset: the six activation pointers of a
   // 96-row launch would otherwise cost 12 vector registers, the difference between one and two resident workgroups
-  const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)nt * (a.K / 16) + k0 / 16) * 64;
+  const f32x4* wp[NT];
+#pragma unroll
+  for (int nn = 0; nn < NT; ++nn)
+    wp[nn] = reinterpret_cast<const f32x4*>(a.Wp) + ((long long)min(nt0 + nn, ntiles - 1) * (a.K / 16) + k0 / 16) * 64;
   const f32x4* xr[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) xr[j] = reinterpret_cast<const f32x4*>(a.x) + ((long long)(t0 + j) * (a.K / 16) + k0 / 16) * 64;
   const unsigned lo = (unsigned)lane;
-  f32x4 acc[MT][2];
+  f32x4 acc[MT][NT][2];
   float s1[MT], s2[MT];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = acc[j][0]; s1[j] = 0.f; s2[j] = 0.f; }
-  // epilogue operands are fetched NOW (wave j owns m-tile j) so that no dependent global round trip is left
+  for (int j = 0; j < MT; ++j) {
+    s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) { acc[j][nn][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][nn][1] = acc[j][nn][0]; }
+  }
+  // epilogue operands are fetched NOW (wave v owns virtual tile v) so that no dependent global round trip is left
   // after the weight stream: the memory system is saturated by then and a late load costs ~1.5 us.
   f32x4 pc1 = {0.f, 0.f, 0.f, 0.f}, pc2 = pc1, pres = pc1;
-  const int n_ep = nt * 16 + 4 * q;
-  const long long off_ep = a.out_packed ? (((long long)(t0 + wave) * (a.N >> 4) + nt) * 64 + lane) * 4
-                                        : (long long)min((t0 + wave) * 16 + ml, a.M - 1) * a.ldo + n_ep;
-  if (wave < MT && n_ep < a.N) {
+  const int ej = wave / NT, enn = wave % NT, ent = nt0 + enn;       // (row tile, column tile) this wave finishes first
+  const int n_ep = ent * 16 + 4 * q;
+  const long long off_ep = a.out_packed ? (((long long)(t0 + ej) * (a.N >> 4) + ent) * 64 + lane) * 4
+                                        : (long long)min((t0 + ej) * 16 + ml, a.M - 1) * a.ldo + n_ep;
+  if (wave < VT && ent < ntiles && n_ep < a.N) {
     if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
     if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
     if (a.resid) pres = *reinterpret_cast<const f32x4*>(a.resid + off_ep);
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   // software pipeline over batches of UN k16-steps: the loads of batch b+1 are issued BEFORE the MFMAs of batch b
   // (two register sets, statically indexed), and every load of a batch is pinned ahead of the first MFMA that
   // follows (sched_barrier) - hipcc otherwise sinks loads next to their uses and the kernel turns latency-bound.
-  auto mfma_step = [&](const f32x4& wv, const f32x4 (&xs)[MT]) {
+  auto mfma_step = [&](const f32x4 (&wv)[NT], const f32x4 (&xs)[MT]) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
       const f32x4 xv = xs[j];
@@ -245,20 +259,23 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
         s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
-        acc[j][e & 1] = DG_MFMA(wv[e], xv[e], acc[j][e & 1]);
+      for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
+          acc[j][nn][e & 1] = DG_MFMA(wv[nn][e], xv[e], acc[j][nn][e & 1]);
     }
   };
-  // batches of UN k16-steps: UN weight + UN*MT activation loads in flight, all pinned ahead of the MFMAs
+  // batches of UN k16-steps: UN*NT weight + UN*MT activation loads in flight, all pinned ahead of the MFMAs
   // (measured alternatives for MT > 1 — two-deep register pipeline, up-front weight preload — were 4-6 % slower in isolation; round 3:
   //  the wave's whole weight slice by LDS-DMA at t = 0 + double-buffered activations, built to make the launch tolerant of the
   //  3-4x memory latency beside a KV stream, was slower alone (1.65 vs 1.50 ms per 80-row chain step) AND beside the stream:
   //  profiles/r03_ar_overlap.md)
   for (int s0 = 0; s0 < steps; s0 += UN) {
-    f32x4 w[UN], xb[UN][MT];
+    f32x4 w[UN][NT], xb[UN][MT];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      w[u] = DG_WLOAD(wp + (s0 + u) * 64 + lo);
+#pragma unroll
+      for (int nn = 0; nn < NT; ++nn) w[u][nn] = DG_WLOAD(wp[nn] + (s0 + u) * 64 + lo);
 #pragma unroll
       for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][XIDX((s0 + u) * 64) + lo];
     }
@@ -270,16 +287,19 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   {
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < MT; ++j) t = t + acc[j][0] + acc[j][1];
+    for (int j = 0; j < MT; ++j) t = t + acc[j][0][0] + acc[j][0][1];
     if (t[0] == 1.2345f) a.out[tid] = t[1] + s1[0] + s2[0] + pc1[0] + pc2[0] + pres[0];
     return;
   }
 #endif
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
-    const f32x4 t = acc[j][0] + acc[j][1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][j][r][lane] = t[r];
+    for (int nn = 0; nn < NT; ++nn) {
+      const f32x4 t = acc[j][nn][0] + acc[j][nn][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][j * NT + nn][r][lane] = t[r];
+    }
     if (a.ln) {
       float t1 = s1[j], t2 = s2[j];
       t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
@@ -288,13 +308,15 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     }
   }
   __syncthreads();
-  // epilogue: wave w finishes m-tiles j = w, w+NW, ...
-  for (int j = wave; j < MT; j += NW) {
+  // epilogue: wave w finishes the virtual tiles v = w, w+NW, ...
+  for (int v = wave; v < VT; v += NW) {
+    const int j = v / NT, nt = nt0 + v % NT;
+    if (nt >= ntiles) continue;          // masked second tile of an odd tile count (wave-uniform)
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] += red[w][j][e][lane];
+      for (int e = 0; e < 4; ++e) r[e] += red[w][v][e][lane];
     float t1 = 0.f, t2 = 0.f;
     if (a.ln) {
 #pragma unroll
@@ -303,7 +325,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     if (S > 1) {
       // split-K: publish this slice's slab write-through, take a ticket; the last arriver of the (nt, j) tile
       // sums the S slabs in slice order (deterministic) and runs the epilogue.
-      const long long tile = (long long)(t0 + j) * gridDim.x + nt;
+      const long long tile = (long long)(t0 + j) * ntiles + nt;
       float* slab = a.slab + (tile * S + sp) * 320;          // 256 acc floats + 64 stat floats
       st_sc1(slab + lane * 4, r);
       if (a.ln && q == 0) {
@@ -337,19 +359,26 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     const int m = (t0 + j) * 16 + ml;
     const int n = nt * 16 + 4 * q;
     if ((a.out_packed || m < a.M) && n < a.N) {
+      // the operands fetched ahead belong to this wave's FIRST virtual tile; later ones (VT > NW only) are fetched here
+      f32x4 qc1 = pc1, qc2 = pc2, qres = pres;
+      const long long off = a.out_packed ? (((long long)(t0 + j) * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
+      if (v != wave) {
+        qc1 = a.ln ? *reinterpret_cast<const f32x4*>(a.c1 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        qc2 = a.c2 ? *reinterpret_cast<const f32x4*>(a.c2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        qres = a.resid ? *reinterpret_cast<const f32x4*>(a.resid + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       if (a.ln) {
         const float mean = t1 / (float)a.K;
         const float var = fmaxf(t2 / (float)a.K - mean * mean, 0.f);
         const float rstd = rsqrtf(var + 1e-5f);
-        r = (r - pc1 * mean) * rstd;
+        r = (r - qc1 * mean) * rstd;
       }
-      if (a.c2) r = r + pc2;
+      if (a.c2) r = r + qc2;
       if (a.act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = 0.5f * r[e] * (1.0f + erff(r[e] * 0.70710678118654752f));
       }
-      const long long off = a.out_packed ? (((long long)(t0 + j) * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
-      if (a.resid) r = r + pres;
+      if (a.resid) r = r + qres;
       *reinterpret_cast<f32x4*>(a.out + off) = r;
     }
   }
@@ -1007,7 +1036,8 @@ size_t sfmi_decode_gemm_slab_floats(int M, int N, int S) { return (size_t)((M + 
 // rows the fragment-packed operands of sfmi_decode_gemm_f32 must hold for M rows: groups * MT * 16 (M <= 96: ceil(M/16)*16)
 int sfmi_decode_gemm_padded_rows(int M) {
   const int tiles = (M + 15) / 16, groups = (tiles + 5) / 6, MT = (tiles + groups - 1) / groups;
-  return groups * MT * 16;
+  const int g2 = (tiles + 2) / 3, MT2 = (tiles + g2 - 1) / g2;       // the two-n-tile form (dgemm_nt2): groups of <= 3 row tiles
+  return max(groups * MT, g2 * MT2) * 16;
 }
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
                          float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
@@ -1033,6 +1063,17 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
   a.out_packed = out_packed; a.slab = slab; a.cnt = cnt;
   hipStream_t st = (hipStream_t)stream;
+  if (g_tune.dgemm_nt2 == 1 && NWv == 8 && (kslice / 8 / 16) % 2 == 0 && tiles >= 3) {
+    // two n-tiles per wave, row groups of <= 3 row tiles, batches of two k16-steps: 5 operand loads per 24 MFMAs (7 in the one-tile
+    // form) with the same 6 accumulator tiles per wave; same per-element arithmetic (k ascending, two chains): bit-identical
+    const int g2 = (tiles + 2) / 3, MT2 = (tiles + g2 - 1) / g2;
+    dim3 grid2(((N + 15) / 16 + 1) / 2, S, g2);
+#define DG2(MT_) hipLaunchKernelGGL((dgemm_kernel<MT_, 8, 2, 2>), grid2, dim3(512), 0, st, a)
+    if (MT2 == 1) DG2(1); else if (MT2 == 2) DG2(2); else DG2(3);
+#undef DG2
+    SFMI_CHECK_LAUNCH();
+    return SFMI_OK;
+  }
   dim3 grid((N + 15) / 16, S, groups);
   const int steps = kslice / NWv / 16;
   int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 5 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave (5 row tiles: 128 VGPRs; 6: 138 with two)

@@ -377,3 +377,49 @@ def test_large_batches_keep_the_single_chain_features(dev):
     # rows 0..4 as a 5-row batch: row 0 is greedy in both; rows 1..4 draw with uniforms indexed by (global row, rows_total), so only
     # the greedy row is comparable across batch sizes
     assert torch.equal(one["samples"][0], zc["samples"][0])
+
+
+@pytest.mark.parametrize("M", [48, 80, 96, 130, 192])
+def test_decode_gemm_two_n_tile_form_and_row_groups_are_bit_identical(dev, M):
+    """csrc/gpt.hip dgemm_kernel<MT,8,2,NT=2> (two n-tiles per wave, row groups of <= 3 row tiles; tuning knob dgemm_nt2) against
+    the one-tile form (row groups of <= 6 row tiles above 96 rows) on the decode step's GEMM shapes (LN fold, GELU, residual,
+    split-K 4, the odd 257-tile head): same k order and accumulator chains, so every output bit must agree; rows >= M untouched
+    in the row-major head output."""
+    from shapeformer_amd import _lib as L
+    from shapeformer_amd.gpt import pack_skinny16
+    lib = L.lib()
+    g = torch.Generator(device="cpu").manual_seed(M)
+    Mp = int(lib.sfmi_decode_gemm_padded_rows(M))
+    assert Mp >= M and Mp % 16 == 0
+    try:
+        for (N, K, ln, act, use_res, S) in [(3072, 1024, 1, 0, False, 1), (1024, 1024, 0, 0, True, 1), (4096, 1024, 1, 1, False, 1),
+                                            (1024, 4096, 0, 0, True, 4), (4097, 1024, 1, 0, False, 1)]:
+            Np = (N + 15) // 16 * 16
+            wp = pack_skinny16(torch.randn(N, K, generator=g) * 0.05).to(dev)
+            x = torch.randn(Mp * K, generator=g).to(dev)                  # fragment-packed activations: any values do
+            c1, c2 = torch.randn(Np, generator=g).to(dev), torch.randn(Np, generator=g).to(dev)
+            packed = 0 if N == 4097 else 1
+            ldo = 4128 if N == 4097 else N
+            res = torch.randn(Mp * N, generator=g).to(dev) if use_res else None
+            slab = torch.empty(lib.sfmi_decode_gemm_slab_floats(Mp, 4096, 4), device=dev)
+            cnt = torch.zeros(Mp // 16 * 260, device=dev, dtype=torch.int32)
+            outs = []
+            for nt2 in (0, 1):
+                L.check(lib.sfmi_tune_set(b"dgemm_nt2", nt2), "tune")
+                out = torch.full((Mp * max(N, ldo),), 7.0, device=dev)
+                L.check(lib.sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1) if ln else None, L.ptr(c2), L.ptr(res), L.ptr(out), M, N, K, ldo,
+                                                 ln, act, packed, S, L.ptr(slab) if S > 1 else None, L.ptr(cnt) if S > 1 else None,
+                                                 L.stream_ptr()), "sfmi_decode_gemm_f32")
+                torch.cuda.synchronize()
+                outs.append(out.cpu())
+            a, b = outs
+            if packed:      # padded row tiles hold garbage of the padded inputs in both forms; compare the tiles that contain real rows
+                nt_real = (M + 15) // 16 * (N // 16) * 256
+                a, b = a[:nt_real], b[:nt_real]
+            else:
+                a, b = a[:M * ldo], b[:M * ldo]
+                assert bool((outs[1][M * ldo:Mp * ldo] == 7.0).all()), "rows beyond M must not be written in the row-major form"
+            assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+            assert torch.equal(a, b), (M, N, K, float((a - b).abs().max()))
+    finally:
+        L.check(lib.sfmi_tune_set(b"dgemm_nt2", 0), "tune")

@@ -120,7 +120,7 @@ def main():
         print(s, flush=True)
         out.write(s + "\n"); out.flush()
     say(f"# ar_sweep: model built in {time.time() - t0:.1f}s; default rows {a.rows} chains {a.chains} steps {a.steps}")
-    defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad", "sdf_blocks")}
+    defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad", "sdf_blocks", "dgemm_nt2")}
     probe = PowerProbe()
     say(f"# power probe: device {probe.bdf}, files {probe.files}")
     bgst = {}        # background SDF-query load (`bgsdf=<shapes per launch>[:<launches>]`): the MFMA-bound decode stage of a previous batch
