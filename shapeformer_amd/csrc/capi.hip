@@ -2,7 +2,7 @@
 #include "sfmi_common.h"
 #include <string>
 
-SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512, 0};
+SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512, 1};
 
 // One wavefront that waits `ticks` of the constant 100 MHz wall clock: the probe `shapeformer_amd/gpt.py:_chain_streams` uses to
 // find HIP streams that really run concurrently (streams mapped to one hardware queue serialise; the runtime hands out only a few
@@ -23,7 +23,7 @@ int sfmi_tune_set(const char* name, int value) {
   else if (n == "attn_waves" && (value == 8 || value == 16)) t.attn_waves = value;
   else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) t.attn_lds_pad = value;
   else if (n == "sdf_blocks" && value >= 1 && value <= 512) t.sdf_blocks = value;
-  else if (n == "dgemm_nt2" && (value == 0 || value == 1)) t.dgemm_nt2 = value;
+  else if (n == "dgemm_nt2" && value >= 0 && value <= 2) t.dgemm_nt2 = value;
   else return SFMI_EINVAL;
   return SFMI_OK;
 }

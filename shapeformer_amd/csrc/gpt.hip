@@ -1063,9 +1063,11 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
   a.out_packed = out_packed; a.slab = slab; a.cnt = cnt;
   hipStream_t st = (hipStream_t)stream;
-  if (g_tune.dgemm_nt2 == 1 && NWv == 8 && (kslice / 8 / 16) % 2 == 0 && tiles >= 3) {
+  if ((g_tune.dgemm_nt2 == 2 || (g_tune.dgemm_nt2 == 1 && tiles % 3 == 0)) && NWv == 8 && (kslice / 8 / 16) % 2 == 0 && tiles >= 3) {
     // two n-tiles per wave, row groups of <= 3 row tiles, batches of two k16-steps: 5 operand loads per 24 MFMAs (7 in the one-tile
-    // form) with the same 6 accumulator tiles per wave; same per-element arithmetic (k ascending, two chains): bit-identical
+    // form) with the same 6 accumulator tiles per wave; same per-element arithmetic (k ascending, two chains): bit-identical.
+    // Default (knob 1) when the row tiles divide into groups of exactly 3 (48 / 96 / 144 / 192 rows: no padded tile): GEMM phase of
+    // 4 x 96 rows 3.06 -> 2.72 ms per step, loop 7.83 -> 7.53; with a padded tile (80 rows = 2 x 3 tiles for 5) it loses 1 %.
     const int g2 = (tiles + 2) / 3, MT2 = (tiles + g2 - 1) / g2;
     dim3 grid2(((N + 15) / 16 + 1) / 2, S, g2);
 #define DG2(MT_) hipLaunchKernelGGL((dgemm_kernel<MT_, 8, 2, 2>), grid2, dim3(512), 0, st, a)

@@ -62,6 +62,7 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   attn_lds_pad: extra dynamic LDS bytes per attention workgroup (caps resident workgroups per CU)
 //   sdf_blocks  : cap of the SDF-query kernel's persistent grid (default 512 = two workgroups per CU; 256 leaves half of every
 //                 CU's registers free - the background-decode experiment of profiles/r03_ar_overlap.md)
-//   dgemm_nt2   : 1 = decode GEMM with two n-tiles per wave and row groups of <= 3 row tiles (from 48 rows on; bit-identical)
+//   dgemm_nt2   : decode GEMM with two n-tiles per wave and row groups of <= 3 row tiles (bit-identical to the one-tile form):
+//                 0 = never, 1 = when the row tiles divide by 3 (default: 48 / 96 / 144 / 192 rows), 2 = from 48 rows on
 struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2; };
 extern SfmiTune g_sfmi_tune;

@@ -404,7 +404,7 @@ def test_decode_gemm_two_n_tile_form_and_row_groups_are_bit_identical(dev, M):
             slab = torch.empty(lib.sfmi_decode_gemm_slab_floats(Mp, 4096, 4), device=dev)
             cnt = torch.zeros(Mp // 16 * 260, device=dev, dtype=torch.int32)
             outs = []
-            for nt2 in (0, 1):
+            for nt2 in (0, 2):          # 0 = one n-tile per wave, 2 = two n-tiles whenever possible (the default, 1, picks per shape)
                 L.check(lib.sfmi_tune_set(b"dgemm_nt2", nt2), "tune")
                 out = torch.full((Mp * max(N, ldo),), 7.0, device=dev)
                 L.check(lib.sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1) if ln else None, L.ptr(c2), L.ptr(res), L.ptr(out), M, N, K, ldo,
@@ -422,4 +422,4 @@ def test_decode_gemm_two_n_tile_form_and_row_groups_are_bit_identical(dev, M):
             assert torch.isfinite(a).all() and float(a.abs().max()) > 0
             assert torch.equal(a, b), (M, N, K, float((a - b).abs().max()))
     finally:
-        L.check(lib.sfmi_tune_set(b"dgemm_nt2", 0), "tune")
+        L.check(lib.sfmi_tune_set(b"dgemm_nt2", 1), "tune")
