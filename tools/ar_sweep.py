@@ -158,6 +158,7 @@ def main():
         lclo, lchi = int(kv.pop("lclo", 100)), int(kv.pop("lchi", 216))     # condition lengths (short traces: start near the mid-run length)
         gpt._ablate = kv.pop("ablate", "")
         gpt.ATTN_LANES = int(kv.pop("lanes", "0"))
+        gpt.S_PROJ_M, gpt.S_FC2 = int(kv.pop("sproj", "1")), int(kv.pop("sfc2", "4"))      # in-kernel split-K of proj / fc2 (part of the graph key)
         bg = kv.pop("bgsdf", None)
         for k, v in defaults.items():
             L.check(lib.sfmi_tune_set(k.encode(), int(kv.pop(k, v))), f"tune {k}")
