@@ -51,6 +51,9 @@ def parse():
                     help="TEST ONLY: initialise the RCCL process group even for one rank (exercises init / barrier / all-reduce of the "
                          "N-rank path on a 1-GPU box; run under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--train-batch", type=int, default=1, help="--mode train: sequences per GPU per step (shapenet_scale.yaml: 1)")
+    ap.add_argument("--grad-sync", default="ring", choices=["ring", "rs_ag"],
+                    help="--mode train: ring = per-bucket all-reduce, every rank updates everything; rs_ag = per-bucket reduce-scatter, "
+                         "AdamW on the rank's 1/N shard, all-gather of the updated parameters (north_star's path)")
     ap.add_argument("--train-lc", type=int, default=200)
     ap.add_argument("--train-lz", type=int, default=300)
     return ap.parse_args()
@@ -456,13 +459,13 @@ def main_train(a, rank, world, dev, dist):
     from shapeformer_amd.gpt import CondTupleGPT
     from shapeformer_amd.train import GPTTrainer
     g = CondTupleGPT(device=dev)
-    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist)
+    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist, grad_sync=a.grad_sync, profile_waits=True)
     c, z = synth_tokens(1000 + rank, a.train_batch, a.train_lc, a.train_lz)
     losses = []
     for _ in range(a.warmup):
         losses.append(float(tr.training_step(c, z).item()))
     torch.cuda.synchronize()
-    tr.buckets.wait_ms()                  # drop the warm-up steps' records
+    tr.buckets.wait_ms(); tr.buckets.gather_ms()     # drop the warm-up steps' records
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -480,6 +483,7 @@ def main_train(a, rank, world, dev, dist):
         dt = float(tt.item())
     losses.append(float(loss.item()))
     wait_ms = tr.buckets.wait_ms()        # mean stall of the compute stream in GradBuckets.finish() over the timed steps
+    gather_ms = tr.buckets.gather_ms()    # rs_ag: mean wait for the all-gather of the updated parameters
     if rank == 0:
         tok = world * a.train_batch * (a.train_lc + a.train_lz - 1) * a.steps
         print(json.dumps({
@@ -488,11 +492,15 @@ def main_train(a, rank, world, dev, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ShapeFormer DDP training step, synthetic IMNet-style token batches (BASELINE config 5)",
                        "batch_per_gpu": a.train_batch, "L_c": a.train_lc, "L_z": a.train_lz, "parallelism": f"dp{world}",
-                       "grad_sync": "26 gradient buckets (one per block) all-reduced under the backward pass"},
+                       "grad_sync_mode": a.grad_sync,
+                       "grad_sync": ("26 gradient buckets (one per block) all-reduced under the backward pass" if a.grad_sync == "ring" else
+                                     "26 gradient buckets reduce-scattered under the backward pass, AdamW on the rank's 1/N shard, updated "
+                                     "parameters all-gathered in place through the same flat buffer")},
             "allreduce_wait_ms": None if wait_ms is None else round(wait_ms, 3),
             "allreduce_wait_note": ("time per step the compute stream waits in GradBuckets.finish() for gradient collectives that are still "
                                     "running after the last backward kernel = the EXPOSED communication (ms_per_step - this = compute); "
                                     "null without a process group"),
+            "param_allgather_wait_ms": None if gather_ms is None else round(gather_ms, 3),
             "grad_bytes_per_step": int(tr.flat_grad.numel() * 4),
             "model_TFLOPs": round(6 * 324.95e6 * tok / dt / 1e12, 2),
             "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}), flush=True)

@@ -36,6 +36,8 @@ int sfmi_stream_spin(long long ticks, void* stream);
  * counterpart.  sfmi_tune_get returns -1 for an unknown name. */
 int sfmi_tune_set(const char* name, int value);
 int sfmi_tune_get(const char* name);
+/* [host] number of successful sfmi_tune_set calls so far: callers that cache captured hipGraphs key them on it */
+int sfmi_tune_generation(void);
 
 /* ---- VQDIF encoder, per-point path: enc.py:95-140 (LocalPoolPointnet.forward up to scatter_mean), layers.py:39-48,
  *      vqdif/common.py:260-321, torch_scatter.scatter_max / scatter_mean call sites enc.py:70-74,103-110 ---------- */
@@ -132,6 +134,12 @@ int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out); /* [hos
 size_t sfmi_decode_gemm_slab_floats(int M, int N, int S);
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
                          int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, void* stream);
+/* the same with in-situ launch timing (bench.py `roofline`; no reference counterpart): prof = 3 device u64 {earliest start (armed as
+ * ~0), sum of launch durations, launches} in ticks of the 100 MHz wall clock, one sink per chain; pblk = 1 zeroed device int per chain.
+ * The launch's last workgroup adds (its end - earliest workgroup start).  prof == NULL: identical to sfmi_decode_gemm_f32. */
+int sfmi_decode_gemm_prof_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
+                              int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, int* pblk,
+                              unsigned long long* prof, void* stream);
 /* embedding of the token at t = len[b]-1 into the fragment-packed residual buffer (input of the first decode step) */
 int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                               const int* seq, const int* len, const int* Lc, float* resid, int B, int D, int Lmax, int end0,
@@ -144,9 +152,11 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_packed, const float* unused, float
 /* the same behind the attention turnstile of the interleaved decode chains (no reference counterpart: the reference runs one
  * chain): sem = 3 device ints {next ticket, finished launches, gate time-outs} shared by all chains, zeroed by the caller while
  * nothing is in flight; blk = 1 zeroed device int per chain; at most `lanes` gated launches stream their KV cache at a time, in
- * ticket order.  Scheduling only - results are those of sfmi_gpt_attn_decode_f32.  sem == NULL: no turnstile. */
+ * ticket order.  Scheduling only - results are those of sfmi_gpt_attn_decode_f32.  sem == NULL: no turnstile.
+ * prof (optional, needs blk): in-situ launch timing sink of this chain, as in sfmi_decode_gemm_prof_f32. */
 int sfmi_gpt_attn_decode_gated_f32(const float* qkv_packed, float* Kc, float* Vc, const int* len, float* y_packed, int B, int D, int H,
-                                   int Lmax, const int* shared_len, int* sem, int* blk, int lanes, void* stream);
+                                   int Lmax, const int* shared_len, int* sem, int* blk, int lanes, unsigned long long* prof,
+                                   void* stream);
 /* one tuple element of one sampling step per row: sampling_masker (representers.py:120-155) + filter_sampling_logits /
  * sample_logits (models/common.py:260-299: temperature, top-k with ties, top-p) + inverse-CDF draw from counter-hash uniforms
  * indexed (step, tuple, row_offset + b) + best_in_first greedy row + log-prob + optional masked-logit history; writes the
@@ -192,6 +202,15 @@ int sfmi_adamw_f32(float* p, const float* g, float* m, float* v, long long n, fl
 int sfmi_adamw_multi_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
                          const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                          float eps, int step, void* stream);
+/* optimizer-sharded data parallelism (north_star: reduce-scatter -> update of the rank's 1/N shard -> all-gather; the reference
+ * delegates this to Lightning's DDP, trainer.py:22,93): the same update over chunk tables that cover only this rank's shard, the
+ * updated parameters ALSO written to pflat[flat index] (may alias g: the gradient buffer becomes the all-gather send buffer);
+ * sfmi_unflatten_multi_f32 then copies the all-gathered flat buffer back into the parameter tensors */
+int sfmi_adamw_multi_shard_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
+                               const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                               float eps, int step, float* pflat, void* stream);
+int sfmi_unflatten_multi_f32(float* const* p, const long long* foff, const int* ctensor, const long long* coff, const int* clen,
+                             int nchunks, const float* flat, void* stream);
 
 /* ---- Implicit decoder SDF/occupancy query: dec.py:62-100 (grid_sample + 5-block conditioned MLP), layers.py:39-48 - */
 size_t sfmi_sdf_pack_floats(void);

@@ -23,6 +23,7 @@ PROTOTYPES = {
     "sfmi_stream_spin": (i32, [i64, c_ptr]),
     "sfmi_tune_set": (i32, [C.c_char_p, i32]),
     "sfmi_tune_get": (i32, [C.c_char_p]),
+    "sfmi_tune_generation": (i32, []),
     # SDF query
     "sfmi_relu_bwd_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_lincomb_f32": (i32, [f32, c_ptr, f32, c_ptr, c_ptr, i64, c_ptr]),
@@ -91,11 +92,12 @@ PROTOTYPES = {
     "sfmi_sgemm_mfma_f32": (i32, [i32] * 5 + [c_ptr, i32, c_ptr, i32, c_ptr, i32, i32, c_ptr, i32, c_ptr, c_ptr, i64, f32, C.c_uint, c_ptr]),
     "sfmi_ce_rows_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr]),
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr, c_ptr]),
-    "sfmi_gpt_attn_decode_gated_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [c_ptr, c_ptr, c_ptr, i32, c_ptr]),
+    "sfmi_gpt_attn_decode_gated_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [c_ptr, c_ptr, c_ptr, i32, c_ptr, c_ptr]),
     "sfmi_gpt_attn_prefill_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, f32, C.c_uint, c_ptr]),
     "sfmi_gpt_sample_f32": (i32, [c_ptr] * 12 + [i32] * 10 + [C.c_float, C.c_float] + [i32] * 4 + [C.c_uint, c_ptr, i32, i32, i32, i32, c_ptr]),
     "sfmi_gpt_mask_logits_f32": (i32, [c_ptr] * 5 + [i32] * 9 + [c_ptr]),
     "sfmi_decode_gemm_f32": (i32, [c_ptr] * 6 + [i32] * 8 + [c_ptr, c_ptr, c_ptr]),
+    "sfmi_decode_gemm_prof_f32": (i32, [c_ptr] * 6 + [i32] * 8 + [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "sfmi_decode_gemm_slab_floats": (sz, [i32, i32, i32]),
     "sfmi_gpt_embed_packed_f32": (i32, [c_ptr] * 9 + [i32] * 4 + [c_ptr]),
     "sfmi_set_len_i32": (i32, [c_ptr, c_ptr, i32, i32, c_ptr]),
@@ -116,6 +118,8 @@ PROTOTYPES = {
     "sfmi_add_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_adamw_f32": (i32, [c_ptr] * 4 + [i64] + [C.c_float] * 5 + [i32, c_ptr]),
     "sfmi_adamw_multi_f32": (i32, [c_ptr] * 6 + [i32, c_ptr, c_ptr, c_ptr, f32, f32, f32, f32, i32, c_ptr]),
+    "sfmi_adamw_multi_shard_f32": (i32, [c_ptr] * 6 + [i32, c_ptr, c_ptr, c_ptr, f32, f32, f32, f32, i32, c_ptr, c_ptr]),
+    "sfmi_unflatten_multi_f32": (i32, [c_ptr] * 5 + [i32, c_ptr, c_ptr]),
 }
 
 

@@ -2,7 +2,8 @@
 #include "sfmi_common.h"
 #include <string>
 
-SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512, 1};
+SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512, 1, 0, 0};
+static int g_sfmi_tune_generation = 0;
 
 // One wavefront that waits `ticks` of the constant 100 MHz wall clock: the probe `shapeformer_amd/gpt.py:_chain_streams` uses to
 // find HIP streams that really run concurrently (streams mapped to one hardware queue serialise; the runtime hands out only a few
@@ -24,7 +25,10 @@ int sfmi_tune_set(const char* name, int value) {
   else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) t.attn_lds_pad = value;
   else if (n == "sdf_blocks" && value >= 1 && value <= 512) t.sdf_blocks = value;
   else if (n == "dgemm_nt2" && value >= 0 && value <= 2) t.dgemm_nt2 = value;
+  else if (n == "dgemm_nw" && (value == 0 || value == 4 || value == 8 || value == 16)) t.dgemm_nw = value;
+  else if (n == "dgemm_un" && value >= 0 && value <= 8) t.dgemm_un = value;
   else return SFMI_EINVAL;
+  ++g_sfmi_tune_generation;
   return SFMI_OK;
 }
 int sfmi_tune_get(const char* name) {
@@ -37,8 +41,11 @@ int sfmi_tune_get(const char* name) {
   if (n == "attn_lds_pad") return t.attn_lds_pad;
   if (n == "sdf_blocks") return t.sdf_blocks;
   if (n == "dgemm_nt2") return t.dgemm_nt2;
+  if (n == "dgemm_nw") return t.dgemm_nw;
+  if (n == "dgemm_un") return t.dgemm_un;
   return -1;
 }
+int sfmi_tune_generation(void) { return g_sfmi_tune_generation; }
 int sfmi_stream_spin(long long ticks, void* stream) {
   if (ticks < 0 || ticks > 100000000LL) return SFMI_EINVAL;   // <= 1 s
   hipLaunchKernelGGL(stream_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);

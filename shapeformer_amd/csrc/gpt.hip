@@ -15,7 +15,6 @@
 //             common.py:260-299) fused per row: radix-select top-k, bitonic sort of the candidates,
 //             top-p cut, counter-hash uniforms (no host RNG, no per-step D2H of (B,4097) logits)
 #include "sfmi_common.h"
-#include <stdlib.h>
 #include <mutex>
 #include <string>
 
@@ -148,10 +147,28 @@ __global__ __launch_bounds__(256) void rowprep_kernel(RowPrepArgs a) {
 //           are final (deterministic: one workgroup owns each output element).
 //   Weights: Wp16 fragment order [N/16][K/16][64][4]; NW waves split K; UN loads per wave in flight.
 // ------------------------------------------------------------------------------------------------
+// In-situ launch timing (bench.py `roofline`): when a launch is given a `prof` sink {t0, sum of durations, launches} (3 x u64, ticks of
+// the constant 100 MHz wall clock) and a finished-workgroup counter, every 64th workgroup records the earliest start with an atomic min
+// and the LAST workgroup to finish adds (now - earliest start) - the launch's duration as a kernel trace sees it, minus the dispatch
+// ramp - and re-arms the slot.  One sink per chain (launches of one chain never overlap).  prof == NULL: no code runs.
+__device__ __forceinline__ void prof_begin(unsigned long long* prof, unsigned wg) {
+  if (prof && threadIdx.x == 0 && (wg & 63u) == 0u)
+    __hip_atomic_fetch_min(prof, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void prof_end_last(unsigned long long* prof) {   // called by ONE thread of the launch's last workgroup
+  const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __hip_atomic_exchange(prof, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t0 != ~0ull && t1 > t0) {
+    __hip_atomic_fetch_add(prof + 1, t1 - t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(prof + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 struct DGemmArgs {
   const float* x; const float* Wp; const float* c1; const float* c2; const float* resid; float* out;
   int M, N, K, ldo /*row stride when out is row-major (out_packed == 0)*/, ln, act, out_packed;
   float* slab; int* cnt;   // split-K scratch: ceil(M/16)*ceil(N/16)*S*320 floats, ceil(M/16)*ceil(N/16) ints (zeroed once)
+  int* pblk; unsigned long long* prof;   // optional in-situ launch timing (prof_begin / prof_end_last)
 };
 
 // Decode activations live in MFMA-fragment-packed layout: an (M x N) tensor is stored as
@@ -179,16 +196,18 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
 
 // UN = loads in flight per wave per operand; the host picks UN | steps so the unrolled batches carry NO per-element
 // conditions (a runtime select around a load makes hipcc wait vmcnt(0) per element - guide §5 trap 4c).
-#ifndef XIDX
-#define XIDX(i) (i)
-#endif
-#ifndef DG_WLOAD   // weight stream of the 64..96-row kernel: plain loads allocate in the Infinity Cache, so the second and third
-#define DG_WLOAD(p_) (*(p_))   // interleaved chain re-read a layer's weights from there (tools/ubench/mall_probe.hip: 8.3 vs 5.1-5.6 TB/s)
-#endif
-#ifndef DG_MFMA
-#define DG_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
-#endif
-template <int MT, int NW, int UN, int NT = 1>
+//
+// Operand / instruction policy of dgemm_kernel.  The product instantiates DgProduct only.  tools/ubench/dg_ablation.h supplies
+// timing-only ablation policies (operands not loaded, MFMA replaced, statistics or epilogue skipped) for the micro-benchmarks
+// without touching this file; nothing here reads the environment or a build-time switch.
+struct DgProduct {
+  static constexpr bool kStatsOnlyIfLn = false, kNoStats = false, kSkipEpilogue = false;
+  // plain loads: the weight stream allocates in the Infinity Cache, so the other interleaved chains re-read a layer's weights from there
+  static __device__ __forceinline__ f32x4 wload(const f32x4* p) { return *p; }
+  static __device__ __forceinline__ int xidx(int i) { return i; }
+  static __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+template <int MT, int NW, int UN, int NT = 1, class P = DgProduct>
 __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   // NT n-tiles per wave (NT = 2: an activation fragment feeds two weight tiles - 5 operand loads per 24 MFMAs instead of 7 for the
   // same 6 accumulator tiles - and the 96-row launch becomes two row groups of MT = 3, whose batch of two k16-steps fits 128 VGPRs,
@@ -198,6 +217,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   __shared__ float st1[NW][MT][16], st2[NW][MT][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, ml = lane & 15;
   const int sp = blockIdx.y, S = gridDim.y;
+  prof_begin(a.prof, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
   const int ntiles = (a.N + 15) >> 4;
   const int nt0 = blockIdx.x * NT;             // first n-tile of this workgroup (an odd tile count: the last workgroup's second tile is masked)
   // ROW GROUPS (gridDim.z > 1): a launch of more than MT row tiles is cut into groups of MT row tiles; group g = blockIdx.z owns the row
@@ -248,13 +268,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
     for (int j = 0; j < MT; ++j) {
       const f32x4 xv = xs[j];
       // LayerNorm statistics (a few VALU ops; computed unconditionally, only used when a.ln)
-#ifdef DG_STATS_IF_LN   // ablation (tools/ubench/run_streams_ablation.sh): skip them in the launches without a fused LayerNorm
-      if (a.ln)
-#endif
-#ifdef DG_NO_STATS      // ablation: never (results of the LayerNorm-fused launches are then wrong; timing only)
-      if (false)
-#endif
-      {
+      if (!P::kNoStats && (!P::kStatsOnlyIfLn || a.ln)) {
         s1[j] += (xv[0] + xv[1]) + (xv[2] + xv[3]);
         s2[j] += (xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3]);
       }
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
       for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
         for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
-          acc[j][nn][e & 1] = DG_MFMA(wv[nn][e], xv[e], acc[j][nn][e & 1]);
+          acc[j][nn][e & 1] = P::mfma(wv[nn][e], xv[e], acc[j][nn][e & 1]);
     }
   };
   // batches of UN k16-steps: UN*NT weight + UN*MT activation loads in flight, all pinned ahead of the MFMAs
@@ -275,23 +289,21 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn) w[u][nn] = DG_WLOAD(wp[nn] + (s0 + u) * 64 + lo);
+      for (int nn = 0; nn < NT; ++nn) w[u][nn] = P::wload(wp[nn] + (s0 + u) * 64 + lo);
 #pragma unroll
-      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][XIDX((s0 + u) * 64) + lo];
+      for (int j = 0; j < MT; ++j) xb[u][j] = xr[j][P::xidx((s0 + u) * 64) + lo];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < UN; ++u) mfma_step(w[u], xb[u]);
   }
-#ifdef DG_SKIP_EPI   // ablation: main loop only (one store per lane keeps the accumulators alive)
-  {
+  if (P::kSkipEpilogue) {   // ablation policies only: main loop alone (one store per lane keeps the accumulators alive)
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < MT; ++j) t = t + acc[j][0][0] + acc[j][0][1];
     if (t[0] == 1.2345f) a.out[tid] = t[1] + s1[0] + s2[0] + pc1[0] + pc2[0] + pres[0];
     return;
   }
-#endif
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
 #pragma unroll
@@ -382,6 +394,11 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
       *reinterpret_cast<f32x4*>(a.out + off) = r;
     }
   }
+  if (a.prof && tid == 0 &&
+      __hip_atomic_fetch_add(a.pblk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y * gridDim.z) - 1) {
+    __hip_atomic_store(a.pblk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prof_end_last(a.prof);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,6 +420,7 @@ struct AttnArgs {
   int B, H, D, Lmax, HD; float scale;
   int* sem;      // optional turnstile words {next ticket, finished launches, gate time-outs}: the LAST workgroup of a launch bumps sem[1]
   int* blk;      // this chain's finished-workgroup counter (re-armed by the last workgroup)
+  unsigned long long* prof;   // optional in-situ launch timing sink of this chain (prof_begin / prof_end_last; needs blk)
 };
 template <int NWV>
 struct AttnLds {
@@ -528,15 +546,17 @@ template <int NWV, int U>
 __global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : 4) void attn_decode_kernel(AttnArgs a) {   // U <= 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128
   __shared__ AttnLds<NWV> s;
   const int nitems = a.B * a.H;
+  prof_begin(a.prof, blockIdx.x);
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int h = __builtin_amdgcn_readfirstlane(it / a.B);   // wave-uniform: keeps the cache bases in scalar registers
     attn_decode_item<NWV, U>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
     if (it + (int)gridDim.x < nitems) __syncthreads();   // the next item rewrites the hand-off tiles
   }
-  if (a.sem && threadIdx.x == 0) {     // turnstile release: the launch's last workgroup to finish admits the next KV stream
+  if ((a.sem || a.prof) && threadIdx.x == 0) {     // turnstile release: the launch's last workgroup to finish admits the next KV stream
     if (__hip_atomic_fetch_add(a.blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
       __hip_atomic_store(a.blk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(a.sem + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.sem) __hip_atomic_fetch_add(a.sem + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.prof) prof_end_last(a.prof);
     }
   }
 }
@@ -1008,6 +1028,72 @@ __global__ void set_len_kernel(int* len, const int* src, int B, int delta) {
   if (i < B) len[i] = src[i] + delta;
 }
 
+// Host side of sfmi_decode_gemm_f32: picks the instantiation from the launch shape (and the explicit sfmi_tune_set knobs dgemm_nw /
+// dgemm_un / dgemm_nt2 - nothing is read from the environment).  Only instantiations the default rules can reach exist: UN (k16-steps
+// of loads in flight) is at most 8 / 4 / 2 / 2 / 2 / 1 for 1 .. 6 row tiles, which keeps every one of them free of scratch.
+template <class P>
+static int decode_gemm_launch(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out, int M,
+                              int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, int* pblk,
+                              unsigned long long* prof, void* stream) {
+  if (!x || !Wp16 || !out || M <= 0 || M > 192 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;   // larger batches: several chains (gpt.py)
+  if (out_packed && N % 16) return SFMI_EINVAL;
+  if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
+  if (prof && !pblk) return SFMI_EINVAL;
+  const int kslice = K / S;
+  // up to 6 row tiles per workgroup; more rows = row groups (grid.z), each of MT tiles: the packed operands must hold groups * MT * 16 rows
+  const int tiles = (M + 15) / 16, groups = (tiles + 5) / 6, MT = (tiles + groups - 1) / groups;
+  int NWv = (kslice >= 2048 && MT <= 4) ? 16 : 8;
+  const int knob_nw = g_tune.dgemm_nw;     // 0 = the rule above; 4 / 8 / 16 k-parts per workgroup where the shape allows it
+  if ((knob_nw == 4 || knob_nw == 8 || knob_nw == 16) && kslice % (16 * knob_nw) == 0 && MT <= (knob_nw == 8 ? 6 : 4)) NWv = knob_nw;
+  if (kslice % (16 * NWv)) NWv = kslice % 64 == 0 ? 4 : 1;   // narrow models (K-slice not a multiple of 128): fewer k-parts
+  if (kslice % (16 * NWv)) return SFMI_EINVAL;
+  DGemmArgs a;
+  a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
+  a.out_packed = out_packed; a.slab = slab; a.cnt = cnt; a.pblk = pblk; a.prof = prof;
+  hipStream_t st = (hipStream_t)stream;
+  if ((g_tune.dgemm_nt2 == 2 || (g_tune.dgemm_nt2 == 1 && tiles % 3 == 0)) && NWv == 8 && (kslice / 8 / 16) % 2 == 0 && tiles >= 3) {
+    // two n-tiles per wave, row groups of <= 3 row tiles, batches of two k16-steps: 5 operand loads per 24 MFMAs (7 in the one-tile
+    // form) with the same 6 accumulator tiles per wave; same per-element arithmetic (k ascending, two chains): bit-identical.
+    // Default (knob 1) when the row tiles divide into groups of exactly 3 (48 / 96 / 144 / 192 rows: no padded tile): GEMM phase of
+    // 4 x 96 rows 3.06 -> 2.72 ms per step, loop 7.83 -> 7.53; with a padded tile (80 rows = 2 x 3 tiles for 5) it loses 1 %.
+    const int g2 = (tiles + 2) / 3, MT2 = (tiles + g2 - 1) / g2;
+    dim3 grid2(((N + 15) / 16 + 1) / 2, S, g2);
+#define DG2(MT_) hipLaunchKernelGGL((dgemm_kernel<MT_, 8, 2, 2, P>), grid2, dim3(512), 0, st, a)
+    if (MT2 == 1) DG2(1); else if (MT2 == 2) DG2(2); else DG2(3);
+#undef DG2
+    SFMI_CHECK_LAUNCH();
+    return SFMI_OK;
+  }
+  dim3 grid((N + 15) / 16, S, groups);
+  const int steps = kslice / NWv / 16;
+  int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 5 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave (5 row tiles: 128 VGPRs; 6: 138 with two)
+  if (g_tune.dgemm_un > 0 && g_tune.dgemm_un < un) un = g_tune.dgemm_un;   // the knob can only lower it (deeper forms would spill)
+  while (un > 1 && steps % un) un >>= 1;
+#define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_, 1, P>), grid, dim3(64 * NW_), 0, st, a)
+#define DGU8(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
+#define DGU4(MT_, NW_) do { if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
+#define DGU2(MT_, NW_) do { if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
+  if (NWv == 16) { if (MT == 1) DGU8(1, 16); else if (MT == 2) DGU4(2, 16); else if (MT == 3) DGU2(3, 16); else DGU2(4, 16); }
+  // (the epilogue operands are prefetched for row tile == wave, so a narrow launch needs MT <= NW)
+  else if (NWv == 4) {
+    if (MT == 1) DG(1, 4, 1); else if (MT == 2) DG(2, 4, 1);
+    else if (MT == 3) DGU2(3, 4);
+    else if (MT == 4) DGU2(4, 4);
+    else return SFMI_EINVAL;
+  }
+  else if (NWv == 1) { if (MT == 1) DG(1, 1, 1); else return SFMI_EINVAL; }
+  else if (MT == 1) DGU8(1, 8);
+  else if (MT == 2) DGU4(2, 8);
+  else if (MT <= 5) { if (MT == 3) DGU2(3, 8); else if (MT == 4) DGU2(4, 8); else DGU2(5, 8); }   // 65..96 rows: still the 8-wave kernel
+  else DG(6, 8, 1);
+#undef DGU8
+#undef DGU4
+#undef DGU2
+#undef DG
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
 extern "C" {
 
 // host: Linear weight (N,K) row-major -> 16x16x4-MFMA fragment order Wp16 = [ceil(N/16)][K/16][64][4] (rows >= N zero)
@@ -1039,70 +1125,15 @@ int sfmi_decode_gemm_padded_rows(int M) {
   const int g2 = (tiles + 2) / 3, MT2 = (tiles + g2 - 1) / g2;       // the two-n-tile form (dgemm_nt2): groups of <= 3 row tiles
   return max(groups * MT, g2 * MT2) * 16;
 }
+int sfmi_decode_gemm_prof_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
+                              float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
+                              int* cnt, int* pblk, unsigned long long* prof, void* stream) {
+  return decode_gemm_launch<DgProduct>(x, Wp16, c1, c2, resid, out, M, N, K, ldo, ln, act, out_packed, S, slab, cnt, pblk, prof, stream);
+}
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid,
                          float* out, int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab,
                          int* cnt, void* stream) {
-  if (!x || !Wp16 || !out || M <= 0 || M > 192 || S <= 0 || K % S || (ln && !c1)) return SFMI_EINVAL;   // larger batches: several chains (gpt.py)
-  if (out_packed && N % 16) return SFMI_EINVAL;
-  if (S > 1 && (!slab || !cnt)) return SFMI_EINVAL;
-  const int kslice = K / S;
-  // up to 6 row tiles per workgroup; more rows = row groups (grid.z), each of MT tiles: the packed operands must hold groups * MT * 16 rows
-  const int tiles = (M + 15) / 16, groups = (tiles + 5) / 6, MT = (tiles + groups - 1) / groups;
-#ifdef DG_FORCE_NW    // tuning hook of tools/ubench/dgemm_chain.hip
-  const int NWv = DG_FORCE_NW;
-#else
-  int NWv = (kslice >= 2048 && MT <= 4) ? 16 : 8;
-  // run-time tuning hooks (tools/sweep_dgemm.sh): waves per workgroup (4 / 8 / 16 k-parts) and k16-steps of loads in flight
-  static const int env_nw = getenv("SFMI_DGEMM_NW") ? atoi(getenv("SFMI_DGEMM_NW")) : 0;
-  static const int env_un = getenv("SFMI_DGEMM_UN") ? atoi(getenv("SFMI_DGEMM_UN")) : 0;
-  if ((env_nw == 4 || env_nw == 8 || env_nw == 16) && kslice % (16 * env_nw) == 0 && MT <= (env_nw == 4 ? 4 : 6)) NWv = env_nw;
-  if (kslice % (16 * NWv)) NWv = kslice % 64 == 0 ? 4 : 1;   // narrow models (K-slice not a multiple of 128): fewer k-parts
-#endif
-  if (kslice % (16 * NWv)) return SFMI_EINVAL;
-  DGemmArgs a;
-  a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
-  a.out_packed = out_packed; a.slab = slab; a.cnt = cnt;
-  hipStream_t st = (hipStream_t)stream;
-  if ((g_tune.dgemm_nt2 == 2 || (g_tune.dgemm_nt2 == 1 && tiles % 3 == 0)) && NWv == 8 && (kslice / 8 / 16) % 2 == 0 && tiles >= 3) {
-    // two n-tiles per wave, row groups of <= 3 row tiles, batches of two k16-steps: 5 operand loads per 24 MFMAs (7 in the one-tile
-    // form) with the same 6 accumulator tiles per wave; same per-element arithmetic (k ascending, two chains): bit-identical.
-    // Default (knob 1) when the row tiles divide into groups of exactly 3 (48 / 96 / 144 / 192 rows: no padded tile): GEMM phase of
-    // 4 x 96 rows 3.06 -> 2.72 ms per step, loop 7.83 -> 7.53; with a padded tile (80 rows = 2 x 3 tiles for 5) it loses 1 %.
-    const int g2 = (tiles + 2) / 3, MT2 = (tiles + g2 - 1) / g2;
-    dim3 grid2(((N + 15) / 16 + 1) / 2, S, g2);
-#define DG2(MT_) hipLaunchKernelGGL((dgemm_kernel<MT_, 8, 2, 2>), grid2, dim3(512), 0, st, a)
-    if (MT2 == 1) DG2(1); else if (MT2 == 2) DG2(2); else DG2(3);
-#undef DG2
-    SFMI_CHECK_LAUNCH();
-    return SFMI_OK;
-  }
-  dim3 grid((N + 15) / 16, S, groups);
-  const int steps = kslice / NWv / 16;
-  int un = MT == 1 ? 8 : (MT == 2 ? 4 : (MT <= 5 ? 2 : 1));   // UN weight + UN*MT activation float4 loads in flight per wave (5 row tiles: 128 VGPRs; 6: 138 with two)
-#ifdef DG_FORCE_UN
-  un = DG_FORCE_UN;
-#else
-  if (env_un > 0) un = env_un;
-#endif
-  while (un > 1 && steps % un) un >>= 1;
-#define DG(MT_, NW_, UN_) hipLaunchKernelGGL((dgemm_kernel<MT_, NW_, UN_>), grid, dim3(64 * NW_), 0, st, a)
-#define DGU(MT_, NW_) do { if (un >= 8) DG(MT_, NW_, 8); else if (un >= 4) DG(MT_, NW_, 4); else if (un >= 2) DG(MT_, NW_, 2); else DG(MT_, NW_, 1); } while (0)
-  if (NWv == 16) { if (MT == 1) DGU(1, 16); else if (MT == 2) DGU(2, 16); else if (MT == 3) DGU(3, 16); else DGU(4, 16); }
-  // (the epilogue operands are prefetched for row tile == wave, so a narrow launch needs MT <= NW)
-  else if (NWv == 4) {
-    if (MT == 1) DG(1, 4, 1); else if (MT == 2) DG(2, 4, 1);
-    else if (MT == 3) { if (un >= 2) DG(3, 4, 2); else DG(3, 4, 1); }
-    else if (MT == 4) { if (un >= 2) DG(4, 4, 2); else DG(4, 4, 1); }
-    else return SFMI_EINVAL;
-  }
-  else if (NWv == 1) { if (MT == 1) DG(1, 1, 1); else return SFMI_EINVAL; }
-  else if (MT <= 4) { if (MT == 1) DGU(1, 8);  else if (MT == 2) DGU(2, 8);  else if (MT == 3) DGU(3, 8);  else DGU(4, 8); }
-  else if (MT == 5) { if (un >= 2) DG(5, 8, 2); else DG(5, 8, 1); }   // 65..96 rows: still the 8-wave kernel
-  else { if (un >= 2) DG(6, 8, 2); else DG(6, 8, 1); }
-#undef DGU
-#undef DG
-  SFMI_CHECK_LAUNCH();
-  return SFMI_OK;
+  return decode_gemm_launch<DgProduct>(x, Wp16, c1, c2, resid, out, M, N, K, ldo, ln, act, out_packed, S, slab, cnt, nullptr, nullptr, stream);
 }
 
 // replaces get_embeddings (mingpt.py:256-286) + the AR_N extra index (representers.py:188-196,432-442)
@@ -1143,13 +1174,14 @@ int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* 
 // sem (optional, 3 device ints zeroed by the caller while no launch is in flight) + blk (1 device int, zero; one per chain):
 // the launch passes the attention turnstile first (at most `lanes` gated launches stream at a time, FIFO).
 int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, const int* len, float* y, int B, int D, int H,
-                                   int Lmax, const int* shared_len, int* sem, int* blk, int lanes, void* stream) {
+                                   int Lmax, const int* shared_len, int* sem, int* blk, int lanes, unsigned long long* prof, void* stream) {
   if (!qkv_part || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
   if (sem && (!blk || lanes <= 0)) return SFMI_EINVAL;
+  if (prof && !blk) return SFMI_EINVAL;
   AttnArgs a;
   a.qkv = qkv_part; a.Kc = Kc; a.Vc = Vc; a.len = len; a.y = y; a.shared_len = shared_len;
   a.B = B; a.H = H; a.D = D; a.Lmax = Lmax; a.HD = D / H; a.scale = 1.0f / sqrtf((float)a.HD);
-  a.sem = sem; a.blk = blk;
+  a.sem = sem; a.blk = blk; a.prof = prof;
   const int nitems = B * H;
   const int grid = g_tune.attn_blocks > 0 ? min(g_tune.attn_blocks, nitems) : nitems;
   const size_t pad = (size_t)g_tune.attn_lds_pad;
@@ -1173,7 +1205,7 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
 int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc, float* Vc, const int* len, float* y,
                              int S, int B, int D, int H, int Lmax, const int* shared_len, void* stream) {
   if (!bqkv) return SFMI_EINVAL;
-  return sfmi_gpt_attn_decode_gated_f32(qkv_part, Kc, Vc, len, y, B, D, H, Lmax, shared_len, nullptr, nullptr, 0, stream);
+  return sfmi_gpt_attn_decode_gated_f32(qkv_part, Kc, Vc, len, y, B, D, H, Lmax, shared_len, nullptr, nullptr, 0, nullptr, stream);
 }
 
 // causal self-attention over the conditioning prefix (positions 0..Lc[b]-2), also fills the KV caches

@@ -76,28 +76,31 @@ __global__ __launch_bounds__(512, 4) void sdf_query_kernel(
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 5;
   const int pl = lane & 31;
-  const long long tiles_per_shape = (N + 31) >> 5;
-  const long long total_tiles = tiles_per_shape * B;
-  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  const long long wave_gid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // tile indices are 32-bit (the host entries bound B * ceil(N/32) < 2^31): no 64-bit division in the persistent loop
+  const unsigned tiles_per_shape = (unsigned)((N + 31) >> 5);
+  const unsigned total_tiles = tiles_per_shape * (unsigned)B;
+  const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
+  const unsigned wave_gid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 
   const f32x4* ldsW = reinterpret_cast<const f32x4*>(lds + SDF_OFF_W);
   const float wp0 = lds[SDF_OFF_FCP + lane];
   const float wp1 = lds[SDF_OFF_FCP + 64 + lane];
 
-  for (long long tile = wave_gid; tile < total_tiles; tile += nwaves) {
+  for (unsigned tile = wave_gid; tile < total_tiles; tile += nwaves) {
     const int b = (int)(tile / tiles_per_shape);
-    long long pt = (tile - (long long)b * tiles_per_shape) * 32 + pl;
+    long long pt = (long long)(tile - (unsigned)b * tiles_per_shape) * 32 + pl;
     const bool valid = pt < N;
     if (!valid) pt = N - 1;
 
     float px, py, pz;
     if (GRID_MODE) {
       // nputil.makeGrid 'ij' flatten: x slowest, z fastest (xgutils/nputil.py:618-654)
-      int iz = (int)(pt % Q);
-      long long r = pt / Q;
-      int iy = (int)(r % Q);
-      int ixx = (int)(r / Q);
+      // 32-bit index arithmetic (the host entry bounds Q^3 < 2^31): the 64-bit divisions cost the registers that used to spill
+      const unsigned p32 = (unsigned)pt, uq = (unsigned)Q;
+      const unsigned r = p32 / uq;
+      const int iz = (int)(p32 - r * uq);
+      const int ixx = (int)(r / uq);
+      const int iy = (int)(r - (unsigned)ixx * uq);
       px = axis[ixx]; py = axis[iy]; pz = axis[iz];
     } else {
       const float* p = xyz + ((long long)b * N + pt) * 3;
@@ -242,6 +245,7 @@ int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpac
                        long long N, int G, int apply_sigmoid, void* stream) {
   if (!xyz || !grid_cl || !wpack || !out || B <= 0 || N <= 0 || G < 2) return SFMI_EINVAL;
   long long tiles = ((N + 31) >> 5) * B;
+  if (tiles >= (1ll << 31)) return SFMI_EINVAL;
   hipLaunchKernelGGL(sdf_query_kernel<false>, dim3(sdf_grid_dim(tiles)), dim3(512),
                      SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, xyz, nullptr, grid_cl, wpack,
                      out, B, N, G, 0, apply_sigmoid);
@@ -253,9 +257,10 @@ int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpac
 // coordinates synthesised from the Q-entry axis table -> 4 B/pt of HBM traffic.
 int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, const float* wpack, float* out,
                             int B, int G, int apply_sigmoid, void* stream) {
-  if (!axis || !grid_cl || !wpack || !out || B <= 0 || Q <= 0 || G < 2) return SFMI_EINVAL;
+  if (!axis || !grid_cl || !wpack || !out || B <= 0 || Q <= 0 || Q > 1024 || G < 2) return SFMI_EINVAL;   // Q^3 < 2^31 (32-bit lattice index)
   long long N = (long long)Q * Q * Q;
   long long tiles = ((N + 31) >> 5) * B;
+  if (tiles >= (1ll << 31)) return SFMI_EINVAL;
   hipLaunchKernelGGL(sdf_query_kernel<true>, dim3(sdf_grid_dim(tiles)), dim3(512),
                      SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, nullptr, axis, grid_cl, wpack,
                      out, B, N, G, Q, apply_sigmoid);

@@ -64,5 +64,8 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //                 CU's registers free - the background-decode experiment of profiles/r03_ar_overlap.md)
 //   dgemm_nt2   : decode GEMM with two n-tiles per wave and row groups of <= 3 row tiles (bit-identical to the one-tile form):
 //                 0 = never, 1 = when the row tiles divide by 3 (default: 48 / 96 / 144 / 192 rows), 2 = from 48 rows on
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2; };
+//   dgemm_nw    : k-parts (waves) per decode-GEMM workgroup: 0 = by shape (default), 4 / 8 / 16 where the K-slice allows it
+//   dgemm_un    : cap on the k16-steps of loads in flight per wave: 0 = by shape (8 / 4 / 2 / 2 / 2 / 1 for 1 .. 6 row tiles); can only lower it
+// sfmi_tune_generation() counts successful sfmi_tune_set calls: callers that cache captured hipGraphs key them on it.
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un; };
 extern SfmiTune g_sfmi_tune;

@@ -491,6 +491,7 @@ struct AdamMultiArgs {
   const int* ctensor; const long long* coff; const int* clen;
   const float* g; float* m; float* v;
   float lr, b1, b2, eps, bc1, bc2;
+  float* pflat;   // optional: the updated parameter is ALSO written to pflat[flat index] (may alias g: the all-gather send buffer of the sharded update)
 };
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
   const int c = blockIdx.x, t = a.ctensor[c];
@@ -503,8 +504,20 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
     const float mi = a.b1 * a.m[fo + i] + (1.0f - a.b1) * gi;
     const float vi = a.b2 * a.v[fo + i] + (1.0f - a.b2) * gi * gi;
     a.m[fo + i] = mi; a.v[fo + i] = vi;
-    p[i] = p[i] * decay - step * (mi / (sqrtf(vi) / sb2 + a.eps));
+    const float pn = p[i] * decay - step * (mi / (sqrtf(vi) / sb2 + a.eps));
+    p[i] = pn;
+    if (a.pflat) a.pflat[fo + i] = pn;
   }
+}
+
+// flat buffer -> parameter tensors over the same chunk tables (after the all-gather of the sharded update)
+__global__ __launch_bounds__(256) void unflatten_multi_kernel(float* const* p, const long long* foff, const int* ctensor, const long long* coff,
+                                                              const int* clen, const float* __restrict__ flat) {
+  const int c = blockIdx.x, t = ctensor[c];
+  const long long o = coff[c], fo = foff[t] + o;
+  const int n = clen[c];
+  float* dst = p[t] + o;
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = flat[fo + i];
 }
 
 extern "C" {
@@ -631,15 +644,31 @@ int sfmi_adamw_f32(float* p, const float* g, float* m, float* v, long long n, fl
 
 // the same update for a table of tensors in ONE launch.  Device tables: p (T pointers), foff (T flat offsets), wd (T),
 // chunk tables ctensor / coff / clen (nchunks; any partition of every tensor into chunks, e.g. 16384 elements each).
-int sfmi_adamw_multi_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
-                         const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
-                         float eps, int step, void* stream) {
+// pflat (optional, may alias g): the updated parameters are also written to pflat[flat index] - the optimizer-sharded step
+// (reduce-scatter -> this update on the rank's shard -> all-gather of pflat -> sfmi_unflatten_multi_f32) sends them from there.
+int sfmi_adamw_multi_shard_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
+                               const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                               float eps, int step, float* pflat, void* stream) {
   if (!p || !foff || !wd || !ctensor || !coff || !clen || !g || !m || !v || nchunks <= 0 || step <= 0) return SFMI_EINVAL;
   AdamMultiArgs a;
+  a.pflat = pflat;
   a.p = p; a.foff = foff; a.wd = wd; a.ctensor = ctensor; a.coff = coff; a.clen = clen; a.g = g; a.m = m; a.v = v;
   a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
   a.bc1 = 1.0f - powf(beta1, (float)step); a.bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+int sfmi_adamw_multi_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
+                         const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                         float eps, int step, void* stream) {
+  return sfmi_adamw_multi_shard_f32(p, foff, wd, ctensor, coff, clen, nchunks, g, m, v, lr, beta1, beta2, eps, step, nullptr, stream);
+}
+// parameter tensors <- flat buffer, chunk tables as in sfmi_adamw_multi_f32 (all-gathered parameters of the sharded update)
+int sfmi_unflatten_multi_f32(float* const* p, const long long* foff, const int* ctensor, const long long* coff, const int* clen,
+                             int nchunks, const float* flat, void* stream) {
+  if (!p || !foff || !ctensor || !coff || !clen || !flat || nchunks <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(unflatten_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, foff, ctensor, coff, clen, flat);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -60,57 +60,122 @@ def allreduce_mean_(flat: torch.Tensor, dist):
     return flat
 
 
+class _StagedWork:
+    """reduce_scatter_tensor / all_gather_into_tensor of a DEVICE buffer over gloo, staged through host memory (test path)."""
+
+    def __init__(self, dist, kind, flat, whole, part, op):
+        (lo, hi), (slo, shi) = whole, part
+        if kind == "rs":
+            src = flat[lo:hi].cpu()
+            out = torch.empty(shi - slo, dtype=flat.dtype)
+            dist.reduce_scatter_tensor(out, src, op=op)
+            flat[slo:shi].copy_(out)
+        else:
+            out = torch.empty(hi - lo, dtype=flat.dtype)
+            dist.all_gather_into_tensor(out, flat[slo:shi].cpu())
+            flat[lo:hi].copy_(out)
+
+    def wait(self):
+        return True
+
+
 class GradBuckets:
-    """Bucketed gradient all-reduce overlapped with the backward pass (DDP training).
+    """Bucketed gradient synchronisation overlapped with the backward pass (DDP training).
 
     The trainer's gradients live in ONE flat buffer laid out layer by layer; a bucket is a contiguous [lo, hi) slice of
     it.  `ready(name)` is called by the backward pass the moment the last gradient of that bucket has been enqueued on
-    the compute stream and launches an asynchronous all-reduce of the slice (RCCL runs it on its own stream, ordered
+    the compute stream and launches an asynchronous collective on the slice (RCCL runs it on its own stream, ordered
     after the work already enqueued on the caller's stream), so the collective of layer l rides under the backward
     kernels of layers l-1, l-2, ...  `finish()` waits for every pending collective and applies the 1/world mean.
     Bucket = one transformer block (12.6 M floats = 50 MB): 26 collectives per step instead of 400 per-tensor ones,
-    each large enough to run the ring at xGMI link rate.  gloo (CPU tests) takes the same path with SUM + scale.
+    each large enough to run at xGMI link rate.  gloo (CPU tests) takes the same path with SUM + scale.
+
+    mode "ring"  : `all_reduce` per bucket - every rank ends up with the whole mean gradient and updates every parameter.
+    mode "rs_ag" : north_star's path - `reduce_scatter_tensor` per bucket IN PLACE (rank r's output is its own 1/N slice of
+                   the bucket), the optimizer updates only that slice (`shard_ranges()`), and `all_gather_params()` sends the
+                   updated parameters back through the same flat buffer (`all_gather_into_tensor`, in place).  Half the bytes
+                   of a ring all-reduce cross the links before the optimizer can start, the other half after it; AdamW work
+                   and moment traffic drop to 1/N per rank.  A bucket whose length the world size does not divide falls back
+                   to "ring" (every rank then updates it in full).
     """
 
-    def __init__(self, flat: torch.Tensor, ranges: dict, dist, single_rank_collectives=False):
+    def __init__(self, flat: torch.Tensor, ranges: dict, dist, single_rank_collectives=False, mode="ring", profile_waits=False):
         """single_rank_collectives: run the collectives even in a 1-rank process group (a no-op numerically; bench.py --force-dist
-        uses it to exercise the RCCL ReduceOp.AVG bucket path on a 1-GPU box)."""
-        self.flat, self.ranges, self.dist = flat, dict(ranges), dist
+        uses it to exercise the RCCL bucket path on a 1-GPU box).  profile_waits: bracket the waits of finish() /
+        all_gather_params() with HIP events for `wait_ms()` (bench.py only: a training run would grow the list without bound)."""
+        assert mode in ("ring", "rs_ag")
+        self.flat, self.ranges, self.dist, self.mode = flat, dict(ranges), dist, mode
         inited = dist is not None and dist.is_initialized()
         self.world = dist.get_world_size() if inited else 1
+        self.rank = dist.get_rank() if inited else 0
         self.active = inited and (self.world > 1 or single_rank_collectives)
         self.pending, self.done = [], set()
         self.avg = False
         if self.active:
             self.avg = dist.get_backend() == "nccl"     # RCCL averages in the collective; gloo has no AVG
-        self._wait_events = []                           # (before, after) HIP-event pairs around the waits of finish()
+        self.profile_waits = bool(profile_waits)
+        self._wait_events = []                           # (before, after) HIP-event pairs around the waits (profile_waits only)
+
+    def _staged(self):
+        """gloo has no device path for reduce_scatter_tensor / all_gather_into_tensor: device buffers go through the host
+        (the 2-process tests on a 1-GPU box; RCCL runs them in place on the device)."""
+        return self.flat.is_cuda and self.dist.get_backend() == "gloo"
+
+    def sharded(self, name):
+        """True when bucket `name` is reduce-scattered (mode rs_ag and the world size divides its length)."""
+        lo, hi = self.ranges[name]
+        return self.active and self.mode == "rs_ag" and (hi - lo) % self.world == 0
+
+    def shard(self, name):
+        """[lo, hi) of the part of bucket `name` this rank owns (the whole bucket unless it is reduce-scattered)."""
+        lo, hi = self.ranges[name]
+        if not self.sharded(name):
+            return lo, hi
+        n = (hi - lo) // self.world
+        return lo + self.rank * n, lo + (self.rank + 1) * n
+
+    def shard_ranges(self):
+        """The flat ranges this rank must update, in bucket order."""
+        return [self.shard(name) for name in self.ranges]
 
     def ready(self, name):
         if not self.active or name in self.done:
             return
         lo, hi = self.ranges[name]
         op = self.dist.ReduceOp.AVG if self.avg else self.dist.ReduceOp.SUM
-        self.pending.append((name, self.dist.all_reduce(self.flat[lo:hi], op=op, async_op=True)))
+        if self.sharded(name):
+            slo, shi = self.shard(name)
+            if self._staged():
+                work = _StagedWork(self.dist, "rs", self.flat, (lo, hi), (slo, shi), op)
+            else:
+                work = self.dist.reduce_scatter_tensor(self.flat[slo:shi], self.flat[lo:hi], op=op, async_op=True)
+        else:
+            work = self.dist.all_reduce(self.flat[lo:hi], op=op, async_op=True)
+        self.pending.append((name, work))
         self.done.add(name)
 
+    def _bracket(self):
+        if self.profile_waits and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            return ev
+        return None
+
     def finish(self):
-        """Launch whatever was never marked ready, wait for everything, return the bucket names in launch order.  On a HIP
-        device the compute stream's stall in these waits (collectives still running when the backward's last kernel is done
-        = the EXPOSED communication of the step) is bracketed by two events; `wait_ms()` reads them."""
+        """Launch whatever was never marked ready, wait for everything, return the bucket names in launch order.  With
+        profile_waits the compute stream's stall in these waits (collectives still running when the backward's last kernel is
+        done = the EXPOSED communication of the step) is bracketed by two events; `wait_ms()` reads them."""
         if not self.active:
             return []
         for name in self.ranges:
             self.ready(name)
-        ev = None
-        if self.flat.is_cuda:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
+        ev = self._bracket()
         order = []
         for name, work in self.pending:
             work.wait()
             order.append(name)
             if not self.avg:
-                lo, hi = self.ranges[name]
+                lo, hi = self.shard(name)
                 self.flat[lo:hi].div_(self.world)
         if ev is not None:
             ev[1].record()
@@ -118,13 +183,44 @@ class GradBuckets:
         self.pending, self.done = [], set()
         return order
 
+    def all_gather_params(self):
+        """mode rs_ag, after the sharded optimizer step wrote the updated parameters of this rank's slices into the flat buffer:
+        all-gather every reduce-scattered bucket in place (all launched, then all waited for)."""
+        if not self.active or self.mode != "rs_ag":
+            return
+        works = []
+        for name, (lo, hi) in self.ranges.items():
+            if self.sharded(name):
+                slo, shi = self.shard(name)
+                if self._staged():
+                    works.append(_StagedWork(self.dist, "ag", self.flat, (lo, hi), (slo, shi), None))
+                else:
+                    works.append(self.dist.all_gather_into_tensor(self.flat[lo:hi], self.flat[slo:shi], async_op=True))
+        ev = self._bracket()
+        for w in works:
+            w.wait()
+        if ev is not None:
+            ev[1].record()
+            self._gather_events = getattr(self, "_gather_events", []) + [ev]
+
     def wait_ms(self, reset=True):
         """Mean time per finish() the compute stream spent waiting for gradient collectives since the last reset (ms); None
-        when nothing was recorded (CPU tensors / inactive).  Synchronises."""
+        when nothing was recorded (CPU tensors / inactive / profile_waits off).  Synchronises."""
         if not self._wait_events:
             return None
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in self._wait_events) / len(self._wait_events)
         if reset:
             self._wait_events = []
+        return ms
+
+    def gather_ms(self, reset=True):
+        """The same for the parameter all-gathers of mode rs_ag."""
+        evs = getattr(self, "_gather_events", [])
+        if not evs:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        if reset:
+            self._gather_events = []
         return ms

@@ -75,6 +75,10 @@ class CondTupleGPT:
         #   _ablate     : TIMING-ONLY ablation of decode_step, "gemm" / "attn" / "gemm@0,attn@1" (per chain): the named kernel
         #                 family is not launched, sampled tokens are garbage; part of the hipGraph cache key
         self._ablate = ""
+        #   _profile    : in-situ launch timing of the decode step (csrc/gpt.hip:prof_begin / prof_end_last), "" / "attn" /
+        #                 "attn,gemm": the named kernel families add their launch durations to the chain's st["prof"] sink;
+        #                 results are untouched; part of the hipGraph cache key.  Read with `launch_profile()`.
+        self._profile = ""
         self._sem = torch.zeros(4, device=self.dev, dtype=torch.int32)   # attention turnstile {next ticket, finished, time-outs}
 
     def get_block_size(self):
@@ -196,6 +200,8 @@ class CondTupleGPT:
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32),
                   blk=torch.zeros(1, device=dev, dtype=torch.int32),      # attention turnstile: this chain's finished-workgroup counter
+                  pblk=torch.zeros(1, device=dev, dtype=torch.int32),     # in-situ launch timing: finished workgroups of the decode-GEMM launch
+                  prof=self._prof_zero(dev),                              # in-situ launch timing sinks {t0, sum, launches, -} x {attn, gemm}
                   shared=torch.zeros(1, device=dev, dtype=torch.int32),  # shared-prefix length of the sample_n mode (device-resident)
                   seed=torch.zeros(1, device=dev, dtype=torch.int32))   # sampler seed (device-resident: graphs are seed-independent)
         self._state = st
@@ -203,14 +209,42 @@ class CondTupleGPT:
         self._graphs.pop(slot, None)
         return st
 
+    # ------------------------------------------------------------------ in-situ launch timing (bench.py `roofline`)
+    @staticmethod
+    def _prof_zero(dev):
+        t = torch.zeros(8, device=dev, dtype=torch.int64)
+        t[0] = -1
+        t[4] = -1       # the "earliest start" slots are armed as ~0 (csrc/gpt.hip:prof_end_last re-arms them)
+        return t
+
+    def launch_profile(self, reset=True):
+        """Launch durations the decode kernels recorded themselves since the last reset (self._profile selects the families):
+        {"attn": (launches, mean us), "gemm": (launches, mean us)} summed over all chain states; ticks are 10 ns."""
+        out = {}
+        sts = [st for st in self._states.values() if "prof" in st]
+        for i, fam in enumerate(("attn", "gemm")):
+            n = sum(int(st["prof"][4 * i + 2].item()) for st in sts)
+            tk = sum(int(st["prof"][4 * i + 1].item()) for st in sts)
+            out[fam] = (n, tk * 0.01 / n if n else 0.0)
+        if reset:
+            for st in sts:
+                st["prof"].copy_(self._prof_zero(self.dev))
+                st["pblk"].zero_()
+        return out
+
     # ------------------------------------------------------------------ C-ABI wrappers
-    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act, packed=1, S=1, st=None):
+    def _dgemm(self, x, wp, c1, c2, resid, out, M, N, K, ldo, ln, act, packed=1, S=1, st=None, prof=False):
         st = st or self._state
         while S > 1 and (K // S) % 128:
             S //= 2
+        slab, cnt = (L.ptr(st["slab"]), L.ptr(st["cnt"])) if S > 1 else (None, None)
+        if prof:
+            L.check(L.lib().sfmi_decode_gemm_prof_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
+                                                      ln, act, packed, S, slab, cnt, L.ptr(st["pblk"]), L.ptr(st["prof"][4:]),
+                                                      L.stream_ptr()), "sfmi_decode_gemm_prof_f32")
+            return
         L.check(L.lib().sfmi_decode_gemm_f32(L.ptr(x), L.ptr(wp), L.ptr(c1), L.ptr(c2), L.ptr(resid), L.ptr(out), M, N, K, ldo,
-                                             ln, act, packed, S, L.ptr(st["slab"]) if S > 1 else None,
-                                             L.ptr(st["cnt"]) if S > 1 else None, L.stream_ptr()), "sfmi_decode_gemm_f32")
+                                             ln, act, packed, S, slab, cnt, L.stream_ptr()), "sfmi_decode_gemm_f32")
 
     def _rowprep(self, resid_in, part, bias, S, M, resid_out, xn, ln, Eadd=None, P=0, st=None):
         L.check(L.lib().sfmi_gpt_rowprep_f32(L.ptr(resid_in), L.ptr(part), L.ptr(bias), L.ptr(Eadd),
@@ -407,21 +441,22 @@ class CondTupleGPT:
         if "@" in skip:      # per-chain form "gemm@0,attn@1,attn@2": chain index = micro-batch slot
             skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
         lanes = int(sp.get("gate_lanes", 0))
+        pa, pg = "attn" in self._profile, "gemm" in self._profile      # in-situ launch timing (results untouched)
         # in-kernel split-K per GEMM (only the K = 4 n_embd product, and proj at <= 16 rows, use it)
         Sqkv, Sproj, Sfc1, Sfc2, Shead = 1, self.S_PROJ if B <= 16 else self.S_PROJ_M, 1, self.S_FC2, 1
         for li, ly in enumerate(self.layers):
             if "gemm" not in skip:
-                self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st)
+                self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st, prof=pg)
             if "attn" not in skip:
                 L.check(lib.sfmi_gpt_attn_decode_gated_f32(L.ptr(st["qkv"]), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
                                                            L.ptr(st["len"]), L.ptr(st["y"]), B, D, self.H, self.Lmax + 1,
                                                            L.ptr(st["shared"]) if sp.get("shared_prefix") else None,
-                                                           L.ptr(self._sem) if lanes else None, L.ptr(st["blk"]) if lanes else None, lanes,
-                                                           L.stream_ptr()), "sfmi_gpt_attn_decode_gated_f32")
+                                                           L.ptr(self._sem) if lanes else None, L.ptr(st["blk"]) if (lanes or pa) else None, lanes,
+                                                           L.ptr(st["prof"]) if pa else None, L.stream_ptr()), "sfmi_gpt_attn_decode_gated_f32")
             if "gemm" not in skip:
-                self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st)
-                self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st)
-                self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=Sfc2, st=st)
+                self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st, prof=pg)
+                self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st, prof=pg)
+                self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=Sfc2, st=st, prof=pg)
             if li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage:
                 s = ly.stage
                 hp, hc1, hc2 = self.head_f[s]
@@ -505,7 +540,8 @@ class CondTupleGPT:
         graph = None
         if use_graph and steps > 1:
             gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force", "seed"))), return_logits,
-                    self._ablate, self.S_PROJ, self.S_PROJ_M, self.S_FC2)
+                    self._ablate, self._profile, self.S_PROJ, self.S_PROJ_M, self.S_FC2,
+                    int(L.lib().sfmi_tune_generation()))      # launch-shape knobs are baked into a captured graph: re-capture when one changed
             cached = self._graphs.get(slot)
             if cached is None or cached[0] != gkey or return_logits:
                 side = torch.cuda.Stream(device=self.dev)
@@ -547,7 +583,8 @@ class CondTupleGPT:
         if c_tokens.shape[0] > self.SINGLE_CHAIN_ROWS:
             # more rows than one chain should hold: the same rows as interleaved chains (identical tokens - uniforms and the
             # greedy row are indexed by global row), results gathered as for one chain
-            n_micro = min(4, -(-c_tokens.shape[0] // 80))      # up to 4 chains of <= 96 rows; beyond 384 rows: successive rounds
+            n_micro = min(4, -(-c_tokens.shape[0] // 80))      # up to 4 chains; a chain holds up to MAX_CHAIN_ROWS (192) rows, so one round
+                                                               # takes 768 rows (measured best: 4 x 96); beyond that: successive rounds
             r = self.sample_microbatched(c_tokens, Lc, n_micro=n_micro, max_steps=max_steps, top_k=top_k, top_p=top_p, temperature=temperature,
                                          best_in_first=best_in_first, mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion,
                                          seed=seed, stop_early=stop_early, check_every=check_every, after_prefill=after_prefill,
@@ -622,9 +659,16 @@ class CondTupleGPT:
             e1.synchronize()
             ms = e0.elapsed_time(e1)
             self._chain_probe.append(round(ms, 3))
+            del self._chain_probe[:-32]          # diagnostics only: keep the last 32 probe times (a long-lived service probes forever)
             return ms < 1.5 * ticks * 1e-5
 
         chosen = list(getattr(self, "_mb_streams", []))
+        if len(chosen) >= n and getattr(self, "_mb_shared_queue", False):
+            # the last probe found no set of distinct queues: try again from scratch every 64th use (queues free up when other
+            # streams of the process die) instead of staying ungated for the life of the process
+            self._mb_uses = getattr(self, "_mb_uses", 0) + 1
+            if self._mb_uses % 64 == 0:
+                chosen, self._mb_streams, self._mb_shared_queue = [], [], False
         if len(chosen) >= n:
             # the cached set is re-checked at every use (one joint 0.2 ms spin): the stream -> queue binding has been seen to change
             # while the streams sat idle between batches (a set that passed the pairwise probe measured 0.43 ms for one pair a few
@@ -650,6 +694,8 @@ class CondTupleGPT:
             warnings.warn(f"only {len(chosen)} of {n} decode chains get a hardware queue of their own; the others share one")
             chosen += spare[:n - len(chosen)]
             self._mb_shared_queue = True
+        else:
+            self._mb_shared_queue = False    # a successful (re-)probe re-enables the turnstile
         self._mb_streams = chosen
         return chosen[:n]
 
@@ -675,7 +721,21 @@ class CondTupleGPT:
                                               return_logits=return_logits, force_tokens=sl(force_tokens, lo, hi), shared_prefix=shared_prefix,
                                               z_tokens=sl(z_tokens, lo, hi), use_graph=use_graph, _row0=_row0 + lo, _rows_total=rows_total)
                      for lo, hi in zip(rb[:-1], rb[1:])]
-            res = dict(state={k: torch.cat([p["state"][k] for p in parts], 0) for k in parts[0]["state"]}, steps=max(p["steps"] for p in parts))
+            # the rounds stop early independently; a single run (shapeformer.py:110-115) keeps stepping every row until ALL rows have
+            # ended, and a row that has ended can only draw end-token pairs from then on (sampling_masker leaves nothing else, with
+            # log-probability 0): pad the rounds that stopped sooner with exactly those tokens up to the longest round's step count
+            nmax = max(p["steps"] for p in parts)
+            for p_ in parts:
+                short = nmax - p_["steps"]
+                if short > 0 and mask_invalid:
+                    stp = p_["state"]
+                    room = (self.Lmax - stp["len"]).clamp(min=0, max=short).long()
+                    pos = stp["len"].long()[:, None] + torch.arange(short, device=self.dev)[None, :]
+                    ok = torch.arange(short, device=self.dev)[None, :] < room[:, None]
+                    rows = torch.arange(stp["len"].shape[0], device=self.dev)[:, None].expand_as(pos)
+                    stp["seq"][rows[ok], pos[ok]] = torch.tensor(self.end, device=self.dev, dtype=torch.int32)
+                    stp["len"] = stp["len"] + room.to(torch.int32)
+            res = dict(state={k: torch.cat([p["state"][k] for p in parts], 0) for k in parts[0]["state"]}, steps=nmax)
             if return_logits:
                 res["logits_history"] = [torch.cat([p["logits_history"][i] for p in parts], 0) for i in range(2)]
             return res

@@ -18,7 +18,7 @@ def default_chains(B):
     GPU_MAX_HW_QUEUES=8, or 6 chains are slower; profiles/r02_decode_step_experiments.md).  4 x 48 rows: 4.19 ms/step against 4.29
     for 3 x 64; 4 x 80 rows (320 shapes) is the best rows-per-launch trade measured: 78.8 shapes/s against 76.0 at 192."""
     if B >= 192:
-        return 4                        # a chain holds up to 96 rows; more than 384 rows run as successive rounds (gpt.sample_microbatched)
+        return 4                        # 4 x 96 rows measured best; a chain holds up to 192 rows, more than 768 rows run as successive rounds (gpt.sample_microbatched)
     return -(-B // 64) if B > 64 else (2 if B >= 32 else 1)
 
 

@@ -286,13 +286,22 @@ class ARNRepresenter:
         """logits (B,V) -> masked copy; idx (B,L+1,2): idx[:, -1] is the position being sampled.  Runs the masking stage of the
         fused sampler kernel (csrc/gpt.hip:sample_kernel - the code the decode step uses) on a scratch copy of `idx`."""
         from . import _lib as L
-        if L_cond is None or tuple_i is None:
-            raise ValueError("sampling_masker needs L_cond and tuple_i (representers.py:120: the masks depend on both)")
         dev = self.dev
         lg = torch.as_tensor(logits).to(dev, torch.float32).contiguous()
         seq = torch.as_tensor(idx).to(dev, torch.int32).contiguous()
         B, V = lg.shape
         Lt = seq.shape[1]
+        # the reference's defaults (representers.py:120): tuple_i=None takes the position path (`tuple_i == 1` is False); L_cond is
+        # only read by the completion mask, and the step counter only by the invalid-position mask - derive whichever is missing
+        # from the other (step_j == idx.shape[1] - 1 - L_cond, shapeformer.py:86-93) and refuse only what the reference cannot run
+        tuple_i = 0 if tuple_i is None else int(tuple_i)
+        if L_cond is None:
+            if step_j is not None:
+                L_cond = Lt - 1 - int(step_j)
+            elif tuple_i == 1 or not (self.mask_invalid or self.mask_invalid_completion):
+                L_cond = Lt - 1           # unused by the masks that run
+            else:
+                raise ValueError("sampling_masker: give L_cond or step_j (the position masks need the step counter / the condition length)")
         if step_j is not None and tuple_i == 0 and step_j != Lt - 1 - int(L_cond):
             raise ValueError("sampling_masker: step_j must equal idx.shape[1] - 1 - L_cond (shapeformer.py:86-93)")
         ln = torch.full((B,), Lt - 1, device=dev, dtype=torch.int32)

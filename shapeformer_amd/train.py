@@ -26,7 +26,9 @@ def _ru(x, m):
 
 class GPTTrainer:
     def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0,
-                 single_rank_collectives=False):
+                 single_rank_collectives=False, grad_sync="ring", profile_waits=False):
+        """grad_sync: "ring" = per-bucket all-reduce, every rank updates every parameter; "rs_ag" = per-bucket reduce-scatter,
+        AdamW on the rank's 1/N shard, all-gather of the updated parameters (dist.GradBuckets).  Same weights either way."""
         self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
         # (embd_pdrop, resid_pdrop, attn_pdrop): the model's (CondTupleGPT ctor kwargs / YAML) unless given
         self.pdrop = tuple(float(v) for v in (pdrop if pdrop is not None else getattr(gpt, "pdrop", (0.0, 0.0, 0.0))))
@@ -69,7 +71,8 @@ class GPTTrainer:
         rng["heads"] = (off["head0.ln.w"][0], off["head1.w"][1])
         rng["emb"] = (off["E0"][0], off["cond_pos_emb"][1])
         from .dist import GradBuckets
-        self.buckets = GradBuckets(self.flat_grad, rng, dist, single_rank_collectives=single_rank_collectives)
+        self.buckets = GradBuckets(self.flat_grad, rng, dist, single_rank_collectives=single_rank_collectives, mode=grad_sync,
+                                   profile_waits=profile_waits)
         self._sync = False
 
     # ------------------------------------------------------------------ small wrappers
@@ -339,24 +342,44 @@ class GPTTrainer:
         """torch.optim.AdamW over the two reference groups (shapeformer.py:198-206)."""
         self.step_count += 1
         if not hasattr(self, "_adam_tab"):      # device tables for the one-launch update (built once)
-            CH = 16384
-            ptrs, foff, wd, ct, co, cl = [], [], [], [], [], []
-            o = 0
-            for ti, (name, t, decay) in enumerate(self.params):
-                n = t.numel()
-                ptrs.append(t.data_ptr()); foff.append(o); wd.append(self.wd if decay else 0.0)
-                for c0 in range(0, n, CH):
-                    ct.append(ti); co.append(c0); cl.append(min(CH, n - c0))
-                o += n
-            dev = self.dev
-            self._adam_tab = dict(p=torch.tensor(ptrs, dtype=torch.int64, device=dev), foff=torch.tensor(foff, dtype=torch.int64, device=dev),
-                                  wd=torch.tensor(wd, dtype=torch.float32, device=dev), ct=torch.tensor(ct, dtype=torch.int32, device=dev),
-                                  co=torch.tensor(co, dtype=torch.int64, device=dev), cl=torch.tensor(cl, dtype=torch.int32, device=dev), n=len(ct))
+            self._adam_tab = self._chunk_table([(0, self.flat_grad.numel())])
         tb = self._adam_tab
-        L.check(L.lib().sfmi_adamw_multi_f32(L.ptr(tb["p"]), L.ptr(tb["foff"]), L.ptr(tb["wd"]), L.ptr(tb["ct"]), L.ptr(tb["co"]), L.ptr(tb["cl"]),
-                                             tb["n"], L.ptr(self.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), self.lr, self.betas[0],
-                                             self.betas[1], self.eps, self.step_count, L.stream_ptr()), "adamw_multi")
+        sharded = self.buckets.active and self.buckets.mode == "rs_ag"
+        if sharded:
+            # optimizer sharding: after the reduce-scatter this rank holds the mean gradient of ITS slice of every bucket only;
+            # it updates those elements (and their moments), writes the new parameter values over the consumed gradients in the
+            # flat buffer, all-gathers the buckets in place and copies the gathered parameters back into the tensors
+            if not hasattr(self, "_adam_tab_shard"):
+                self._adam_tab_shard = self._chunk_table(self.buckets.shard_ranges())
+            tb = self._adam_tab_shard
+        L.check(L.lib().sfmi_adamw_multi_shard_f32(L.ptr(tb["p"]), L.ptr(tb["foff"]), L.ptr(tb["wd"]), L.ptr(tb["ct"]), L.ptr(tb["co"]), L.ptr(tb["cl"]),
+                                                   tb["n"], L.ptr(self.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), self.lr, self.betas[0],
+                                                   self.betas[1], self.eps, self.step_count, L.ptr(self.flat_grad) if sharded else None,
+                                                   L.stream_ptr()), "adamw_multi")
+        if sharded:
+            self.buckets.all_gather_params()
+            fb = self._adam_tab
+            L.check(L.lib().sfmi_unflatten_multi_f32(L.ptr(fb["p"]), L.ptr(fb["foff"]), L.ptr(fb["ct"]), L.ptr(fb["co"]), L.ptr(fb["cl"]), fb["n"],
+                                                     L.ptr(self.flat_grad), L.stream_ptr()), "unflatten_multi")
         self.g.mark_decode_weights_stale()  # LN-folded / fragment-packed decode weights are rebuilt at the next decode use
+
+    def _chunk_table(self, ranges, CH=16384):
+        """Device chunk tables of sfmi_adamw_multi_shard_f32 / sfmi_unflatten_multi_f32 for the elements of the flat ranges
+        `ranges` (sorted, disjoint): every parameter tensor's overlap with a range, cut into chunks of <= CH elements."""
+        ptrs, foff, wd, ct, co, cl = [], [], [], [], [], []
+        o = 0
+        for ti, (name, t, decay) in enumerate(self.params):
+            n = t.numel()
+            ptrs.append(t.data_ptr()); foff.append(o); wd.append(self.wd if decay else 0.0)
+            for lo, hi in ranges:
+                a, b = max(lo, o), min(hi, o + n)
+                for c0 in range(a, b, CH):
+                    ct.append(ti); co.append(c0 - o); cl.append(min(CH, b - c0))
+            o += n
+        dev = self.dev
+        return dict(p=torch.tensor(ptrs, dtype=torch.int64, device=dev), foff=torch.tensor(foff, dtype=torch.int64, device=dev),
+                    wd=torch.tensor(wd, dtype=torch.float32, device=dev), ct=torch.tensor(ct, dtype=torch.int32, device=dev),
+                    co=torch.tensor(co, dtype=torch.int64, device=dev), cl=torch.tensor(cl, dtype=torch.int32, device=dev), n=len(ct))
 
     def optimizer_state(self):
         """Resume state: AdamW moments (flat, in parameter-table order) and the step count."""

@@ -39,6 +39,22 @@ def main():
     loss2 = tr.training_step(c, z)                     # second full step through the public entry point
     out["gpt_loss2"] = np.float64(loss2.item())
     out["gpt_w"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr.params[:24]])
+    out["gpt_w_all"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr.params])
+    # ---- the same two steps with north_star's gradient path: reduce-scatter per bucket, AdamW on this rank's shard, all-gather
+    # of the updated parameters (GradBuckets mode "rs_ag") - must leave bit-identical weights
+    g2 = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    tr2 = GPTTrainer(g2, lr=1e-3, dist=dist, grad_sync="rs_ag")
+    assert all(tr2.buckets.sharded(n) for n in tr2.buckets.ranges), "every bucket of this model divides by 2"
+    tr2.training_step(c, z)
+    slo, shi = tr2.buckets.shard("L1")
+    lo, hi = tr2.buckets.ranges["L1"]
+    out["rsag_shard_frac"] = np.float64((shi - slo) / (hi - lo))
+    out["rsag_table_chunks"] = np.int64(tr2._adam_tab_shard["n"])
+    out["ring_table_chunks"] = np.int64(tr2._adam_tab["n"])
+    tr2.training_step(c, z)
+    out["gpt_w_rsag"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr2.params])
+    out["gpt_m_rsag"] = tr2.flat_m.detach().cpu().numpy().copy()     # moments exist only on the rank's shard
+    out["gpt_m_ring"] = tr.flat_m.detach().cpu().numpy().copy()
     # ---- VQDIF autoencoder: item r of a 2-item batch; gradients averaged, EMA statistics summed over ranks ------
     T = np.load(os.path.join(G, "vqdif_train.npz"))
     Xbd = np.concatenate([T["Xbd"], T["Xbd"][:, ::-1] * np.float32(0.9)], 0)      # two different clouds

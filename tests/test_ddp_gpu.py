@@ -70,6 +70,23 @@ def test_gpt_trainer_two_ranks_equal_one_process_batch_two(dev, ranks):
     assert float(np.abs(r0["gpt_w"] - w).max()) <= 2 * 2 * 1e-3 + 1e-6
 
 
+def test_gpt_trainer_reduce_scatter_all_gather_equals_ring(ranks):
+    """north_star's gradient path (GradBuckets mode "rs_ag": reduce-scatter per bucket under the backward, AdamW on the rank's
+    half of every bucket, all-gather of the updated parameters) leaves, after two optimizer steps, the SAME weights bit for bit as
+    the ring all-reduce mode on both ranks; each rank updated (and holds moments for) only its own half."""
+    r0, r1 = ranks
+    for r in (r0, r1):
+        assert np.array_equal(r["gpt_w_rsag"], r["gpt_w_all"])
+        assert float(r["rsag_shard_frac"]) == 0.5
+        assert 0.45 < int(r["rsag_table_chunks"]) / int(r["ring_table_chunks"]) < 0.62      # half of the update work per rank
+    assert np.array_equal(r0["gpt_w_rsag"], r1["gpt_w_rsag"])
+    # first moments: each rank's rs_ag buffer is non-zero only where it equals the ring mode's, and the two ranks tile the whole
+    m0, m1, mr = r0["gpt_m_rsag"], r1["gpt_m_rsag"], r0["gpt_m_ring"]
+    own0, own1 = m0 != 0, m1 != 0
+    assert not np.any(own0 & own1) and np.array_equal(np.where(own0, m0, m1), np.where(own0 | own1, mr, 0))
+    assert np.count_nonzero(own0 | own1) > 0.5 * np.count_nonzero(mr)
+
+
 def test_vqdif_trainer_two_ranks_gradient_mean_and_shared_ema_codebook(dev, ranks):
     from shapeformer_amd import weights as W
     from shapeformer_amd.train_vqdif import VQDIFTrainer
@@ -110,6 +127,12 @@ def test_bench_launches_its_own_ranks(dev):
     line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1 and line[0]["n_gpus"] == 2 and line[0]["config"]["parallelism"] == "dp2" and line[0]["unit"] == "tokens/s"
     assert line[0]["allreduce_wait_ms"] is not None and line[0]["allreduce_wait_ms"] >= 0 and line[0]["grad_bytes_per_step"] > 1.2e9
+    # north_star's gradient path through the same launcher
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--mode", "train", "--steps", "2",
+                        "--warmup", "1", "--train-lc", "24", "--train-lz", "40", "--grad-sync", "rs_ag"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and line[0]["config"]["grad_sync_mode"] == "rs_ag" and line[0]["param_allgather_wait_ms"] is not None
     # and the guard: asking for more ranks than GPUs is an error, never a silent 1-rank run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "only" in (r.stdout + r.stderr)

@@ -1,5 +1,7 @@
 // Apples-to-apples: the production decode GEMM (csrc/gpt.hip) in the same C++ hipGraph chain as stream_chain.hip
 #include "../../shapeformer_amd/csrc/gpt.hip"
+#include "../../shapeformer_amd/csrc/capi.hip"
+#include "dg_ablation.h"
 #include <cstdio>
 #include <vector>
 template <typename F>
@@ -33,7 +35,7 @@ int main(int argc, char** argv) {
       {"fc2 S1", 1024, 4096, 0, 0, 1, 1}, {"fc2 S2", 1024, 4096, 0, 0, 2, 1}, {"fc2 S4", 1024, 4096, 0, 0, 4, 1}, {"fc2 S8", 1024, 4096, 0, 0, 8, 1}, {"proj S1", 1024, 1024, 0, 0, 1, 1}, {"proj S2", 1024, 1024, 0, 0, 2, 1}, {"proj S4", 1024, 1024, 0, 0, 4, 1}, {"head", 4097, 1024, 1, 0, 1, 0}};
   for (auto c : cs) {
     float t = time_graph(st, 48, 10, [&](int i) {
-      sfmi_decode_gemm_f32(x, bufs[i % NBUF], c.ln ? c1 : nullptr, c2, c.resid ? out : nullptr, out, M, c.N, c.K, c.N, c.ln, c.act, 1, c.S, slab, cnt, st);
+      dg_call(x, bufs[i % NBUF], c.ln ? c1 : nullptr, c2, c.resid ? out : nullptr, out, M, c.N, c.K, c.N, c.ln, c.act, 1, c.S, slab, cnt, st);
     });
     printf("%-12s M=%d: %.2f us  (%.2f TB/s weights, %.1f TFLOP/s)\n", c.nm, M, t, (double)c.N * c.K * 4 / t / 1e6, 2.0 * M * c.N * c.K / t / 1e6);
   }

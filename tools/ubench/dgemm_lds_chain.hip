@@ -2,6 +2,8 @@
 // operands, then both in the same hipGraph chain of 48 launches over 24 different weight matrices.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../shapeformer_amd/csrc dgemm_lds_chain.hip -o /tmp/dlc && /tmp/dlc 64
 #include "../../shapeformer_amd/csrc/gpt.hip"
+#include "../../shapeformer_amd/csrc/capi.hip"
+#include "dg_ablation.h"
 #include "dgemm_lds.hip"
 #include <cmath>
 #include <cstdio>
@@ -55,7 +57,7 @@ int main(int argc, char** argv) {
   for (auto c : cs) {
     const int ldo = c.packed ? c.N : 4128;
     auto base = [&](int i, float* o) {
-      return sfmi_decode_gemm_f32(x, bufs[i % NBUF], c.ln ? c1 : nullptr, c2, c.resid ? res : nullptr, o, M, c.N, c.K, ldo, c.ln, c.act, c.packed, c.S0, slab, cnt, st);
+      return dg_call(x, bufs[i % NBUF], c.ln ? c1 : nullptr, c2, c.resid ? res : nullptr, o, M, c.N, c.K, ldo, c.ln, c.act, c.packed, c.S0, slab, cnt, st);
     };
     (void)hipMemsetAsync(out, 0, 16 * MB, st);
     int rc = base(0, out);

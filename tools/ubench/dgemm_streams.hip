@@ -1,6 +1,8 @@
 // Throughput of the decode GEMM phase under chain interleave: NS streams, each a hipGraph of 24 "layers" (qkv, proj, fc1, fc2 at M rows)
 // replayed back to back - the r1 kernel (csrc/gpt.hip) against LDS-staged shapes (dgemm_lds.hip).  us per chain-layer.
 #include "../../shapeformer_amd/csrc/gpt.hip"
+#include "../../shapeformer_amd/csrc/capi.hip"
+#include "dg_ablation.h"
 #include "dgemm_lds.hip"
 #include <cstdio>
 #include <vector>
@@ -35,7 +37,7 @@ int main(int argc, char** argv) {
       (void)hipMemset(r[s], 0, MB); (void)hipMemset(y[s], 0, MB); (void)hipMemset(h[s], 0, 2 * MB);
       (void)hipMalloc(&slab[s], 32 * MB); (void)hipMalloc(&cnt[s], MB); (void)hipMemset(cnt[s], 0, MB);
       auto G = [&](const int* v, const float* X, const float* W, const float* C1, const float* Rs, float* O, int N, int K, int ln, int act) {
-        if (v[0] == 0) sfmi_decode_gemm_f32(X, W, C1, c2, Rs, O, M, N, K, N, ln, act, 1, v[2], slab[s], cnt[s], st[s]);
+        if (v[0] == 0) dg_call(X, W, C1, c2, Rs, O, M, N, K, N, ln, act, 1, v[2], slab[s], cnt[s], st[s]);
         else sfmi_decode_gemm_lds_f32(X, W, C1, c2, Rs, O, M, N, K, N, ln, act, 1, v[2], v[0], v[1], slab[s], cnt[s], st[s]);
       };
       hipGraph_t g;

@@ -4,10 +4,10 @@
 cd "$(dirname "$0")"
 F="--offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../shapeformer_amd/csrc -DDGS_R1_ONLY"
 hipcc $F dgemm_streams.hip -o /tmp/s_base 2>/dev/null &
-hipcc $F '-DDG_MFMA(a,b,c)=((c)[0]+=(a)*(b),(c))' dgemm_streams.hip -o /tmp/s_nomfma 2>/dev/null &
-hipcc $F '-DXIDX(i)=0' dgemm_streams.hip -o /tmp/s_nox 2>/dev/null &
-hipcc $F '-DDG_WLOAD(p)=(f32x4{1.f,2.f,3.f,4.f})' dgemm_streams.hip -o /tmp/s_nowload 2>/dev/null &
-hipcc $F '-DXIDX(i)=0' '-DDG_WLOAD(p)=(f32x4{1.f,2.f,3.f,4.f})' dgemm_streams.hip -o /tmp/s_noloads 2>/dev/null &
+hipcc $F -DDG_NO_MFMA dgemm_streams.hip -o /tmp/s_nomfma 2>/dev/null &
+hipcc $F -DDG_NO_XLOAD dgemm_streams.hip -o /tmp/s_nox 2>/dev/null &
+hipcc $F -DDG_NO_WLOAD dgemm_streams.hip -o /tmp/s_nowload 2>/dev/null &
+hipcc $F -DDG_NO_XLOAD -DDG_NO_WLOAD dgemm_streams.hip -o /tmp/s_noloads 2>/dev/null &
 hipcc $F -DDG_STATS_IF_LN dgemm_streams.hip -o /tmp/s_statsifln 2>/dev/null &
 wait
 for ns in ${2:-1 2 3 4}; do
