@@ -224,7 +224,7 @@ def pmc_traffic(kernel, B):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic_B64.json: FETCH_SIZE
     doubled per the gfx950 correction + WRITE_SIZE); only valid for the configuration it was collected on."""
     f = None
-    for r in ("r03", "r02", "r01"):                                      # newest collection for this launch shape (tools/pmc_run.sh)
+    for r in ("r04", "r03", "r02", "r01"):                               # newest collection for this launch shape (tools/pmc_run.sh)
         c = os.path.join(ROOT, "profiles", f"{r}_pmc_traffic_B{B}.json")
         if os.path.exists(c):
             f = c
@@ -240,7 +240,7 @@ def pmc_traffic(kernel, B):
 
 def pmc_traffic_source(B):
     """Where `roofline.traffic` comes from: it is NOT measured in this run (PMC passes need rocprofv3 around the process)."""
-    for r in ("r03", "r02", "r01"):
+    for r in ("r04", "r03", "r02", "r01"):
         f = os.path.join("profiles", f"{r}_pmc_traffic_B{B}.json")
         if os.path.exists(os.path.join(ROOT, f)):
             return (f"{f}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled per the gfx950 correction) of "
@@ -438,6 +438,33 @@ def train_record(gpt, a, batches=(1, 8), steps=5, warm=2):
     return rec
 
 
+CHECK_SEED = 1000
+
+
+def token_checksums(r, B, a):
+    """CRC-32 of the tokens the AR loop sampled in the fixed-seed pass (row 0 and all rows: int32 (pos, val) pairs of the `ar_steps`
+    generated positions), compared with the value committed in tests/golden/bench_token_checksums.json for this exact workload
+    (the run is deterministic: counter-hash uniforms, no float atomics, fixed summation orders).  A mismatch means the sampled
+    sequences changed - a kernel's rounding, the sampler, or the input selection - and is reported in the line, never hidden."""
+    import zlib
+    st = r["state"]
+    seq, lc = st["seq"].cpu().numpy(), st["Lc"].cpu().numpy()
+    rows = [np.ascontiguousarray(seq[b, lc[b]:lc[b] + a.ar_steps]).astype(np.int32) for b in range(seq.shape[0])]
+    crc0 = zlib.crc32(rows[0].tobytes())
+    crc_all = 0
+    for x in rows:
+        crc_all = zlib.crc32(x.tobytes(), crc_all)
+    key = f"batch{B}_arsteps{a.ar_steps}_points{a.points}_seed{CHECK_SEED}"
+    path = os.path.join(ROOT, "tests", "golden", "bench_token_checksums.json")
+    want = json.load(open(path)).get(key) if os.path.exists(path) else None
+    out = {"token_crc32_row0": crc0, "token_crc32_all_rows": crc_all, "token_crc_key": key,
+           "token_crc_committed": want, "token_crc_ok": None if want is None else bool(want == [crc0, crc_all])}
+    if want is not None and want != [crc0, crc_all]:
+        print(f"bench.py: WARNING sampled tokens differ from the committed checksum for {key}: got {[crc0, crc_all]}, committed {want}",
+              file=sys.stderr, flush=True)
+    return out
+
+
 def synth_tokens(seed, B, Lc, Lz):
     """(pos,val) rows like the representer emits: ascending positions, end-token padded (representers.py:79-103)."""
     rs = np.random.RandomState(seed)
@@ -569,14 +596,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # in-situ launch timing of the decode attention (csrc/gpt.hip:prof_begin / prof_end_last): every launch of the TIMED region adds
+    # (last workgroup's end - earliest workgroup's start) to a device counter; two atomics per launch on top of the turnstile's
+    # finished-workgroup count that runs anyway.  `roofline` below is computed from this average, not from an isolated run.
+    gpt._profile = "" if a.no_roofline else "attn"
     for i in range(a.warmup):
         r = step(i)
     barrier()
+    gpt.launch_profile(reset=True)
     t0 = time.perf_counter()
     for i in range(a.steps):
         r = step(a.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    prof_timed = gpt.launch_profile(reset=True)
     if dist is not None:
         tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -605,7 +638,11 @@ def main():
         if not a.no_roofline:
             # one extra, untimed pass with stage marks: where the batch time goes, and the AR loop against its HBM stream
             tm = {}
-            step(a.warmup + a.steps, timings=tm)
+            gpt._profile = "attn,gemm"       # this extra pass also times the decode-GEMM launches in situ (one more atomic per workgroup)
+            rd = step(CHECK_SEED, timings=tm)    # fixed sampler seed: the tokens of this pass are checked against a committed checksum
+            line["sanity"].update(token_checksums(rd, B, a))
+            prof_diag = gpt.launch_profile(reset=True)
+            gpt._profile = ""
             lc = r["Lc"].float()
             kv_bytes = float((2 * (lc + (a.ar_steps - 1) / 2.0) * gpt.D * 4 * len(gpt.layers)).sum().item())   # mean over the steps
             n_chain = a.micro or default_chains(B)
@@ -645,22 +682,47 @@ def main():
                                                  "(sum ~ real), profiles/r02_decode_step_experiments.md")
             nm = a.micro or default_chains(B)
             Bk = -(-B // nm)     # rows per decode launch (micro-batch)
-        if not a.no_roofline and not a.no_kernels:
-            ks = kernel_rooflines(vq, gpt, Bk, dev, lc_mean=sanity["Lc_mean"])
-            # dominant kernel symbol of the decode step (>90 % of the run): the one with the larger per-layer time
-            cands = [k for k in ks if k["kernel"].startswith(("dgemm_kernel", "attn_decode_kernel"))]
-            dom = max(cands, key=lambda k: k["ms"])
+        if not a.no_roofline:
+            # ---- `roofline`: the dominant kernel of the timed configuration, IN SITU --------------------------------------
+            HBM, F32 = 8000.0, 157.3
+            n_lay = len(gpt.layers)
+            n_a, us_a = prof_timed["attn"]                  # every attention launch of the timed region
+            n_g, us_g = prof_diag["gemm"]                   # every decode-GEMM launch of the extra pass (same configuration)
+            _, us_a_diag = prof_diag["attn"]
+            attn_bytes = kv_bytes / (n_lay * n_chain)       # algorithmic bytes per launch: f32 K+V of the chain's rows at their mean cached length
+            gemm_launches_per_step = 4 * n_lay + 2          # qkv, proj, fc1, fc2 per block + the two heads
+            gemm_flop = 2.0 * Bk * (w_one / 4.0) / gemm_launches_per_step      # mean FLOP per launch (2 x rows x parameters / launches)
+            att = {"kernel": f"attn_decode_kernel ({Bk} rows x {gpt.H} heads per launch)", "bound": "hbm", "launches": n_a,
+                   "avg_us": round(us_a, 2), "algorithmic_bytes": int(attn_bytes),
+                   "achieved": round(attn_bytes / (us_a * 1e-6) / 1e9, 1) if n_a else None, "peak": HBM, "unit": "GB/s"}
+            att["frac"] = round(att["achieved"] / HBM, 4) if n_a else None
+            gem = {"kernel": f"dgemm_kernel ({Bk} rows per launch; qkv / proj / fc1 / fc2 / heads)", "bound": "mfma", "launches": n_g,
+                   "avg_us": round(us_g, 2), "algorithmic_flop": int(gemm_flop),
+                   "achieved": round(gemm_flop / (us_g * 1e-6) / 1e12, 2) if n_g else None, "peak": F32, "unit": "TFLOP/s",
+                   "timing": "in situ, extra untimed pass of the same configuration with the GEMM launches instrumented as well"}
+            gem["frac"] = round(gem["achieved"] / F32, 4) if n_g else None
+            dom_is_attn = n_a > 0 and (n_g == 0 or us_a_diag * prof_diag["attn"][0] >= us_g * n_g)
+            dom = att if dom_is_attn else gem
             line["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                                 "frac": dom["frac"], "traffic": pmc_traffic(dom["kernel"], Bk), "kernel": dom["kernel"],
-                                "traffic_source": pmc_traffic_source(Bk),
-                                "rows_per_launch": Bk,
-                                "timing": ("isolated: one chain, hipGraph of 24 consecutive layers, HIP events (the per-launch average of the "
-                                           "interleaved run is in profiles/: rocprofv3 --kernel-trace --stats)")}
-            if dom["kernel"].startswith("dgemm_kernel") and "gemm_only_TFLOPs" in line.get("ar_loop", {}):
-                # the same kernel with all chains in flight (attention launches disabled, measured live above): the launches of
-                # different chains overlap, so the chip-level rate of the GEMM phase is higher than one launch's own rate
-                line["roofline"]["all_chains_in_flight"] = {"achieved": line["ar_loop"]["gemm_only_TFLOPs"], "unit": "TFLOP/s",
-                                                            "frac": round(line["ar_loop"]["gemm_only_TFLOPs"] / 157.3, 4)}
+                                "traffic_source": pmc_traffic_source(Bk), "rows_per_launch": Bk, "launches": dom["launches"],
+                                "avg_us": dom["avg_us"],
+                                "timing": ("IN SITU: average over every launch of the timed region, measured by the kernel itself - last workgroup's "
+                                           "end minus earliest workgroup's start on the 100 MHz device clock (what a kernel trace reports minus the "
+                                           "dispatch ramp; rocprofv3 --kernel-trace --stats of this command: profiles/r04_bench_kernel_trace.txt)"),
+                                "dgemm_in_situ": gem if dom_is_attn else None, "attn_in_situ": None if dom_is_attn else att}
+        if not a.no_roofline and not a.no_kernels:
+            ks = kernel_rooflines(vq, gpt, Bk, dev, lc_mean=sanity["Lc_mean"])
+            iso = {k["kernel"].split(" ")[0]: k for k in ks if k["kernel"].startswith(("dgemm_kernel", "attn_decode_kernel"))}
+            ik = iso.get("attn_decode_kernel" if dom_is_attn else "dgemm_kernel")
+            if ik:
+                line["roofline"]["frac_isolated"] = ik["frac"]
+                line["roofline"]["isolated_note"] = "one chain alone, hipGraph of 24 consecutive layers, HIP events (kernels[] below)"
+            if "gemm_only_TFLOPs" in line.get("ar_loop", {}):
+                # all chains in flight, attention launches disabled: launches of different chains overlap, so the chip-level rate of
+                # the GEMM phase is higher than one launch's own rate
+                line["roofline"]["dgemm_all_chains_in_flight"] = {"achieved": line["ar_loop"]["gemm_only_TFLOPs"], "unit": "TFLOP/s",
+                                                                  "frac": round(line["ar_loop"]["gemm_only_TFLOPs"] / 157.3, 4)}
             line["kernels"] = ks
         if world == 1 and not a.no_subrecords:
             # BASELINE configs 2-5 in the same driver run (a few seconds each), so that their numbers are not builder-only

@@ -47,7 +47,9 @@ class VisCallback:
     def __init__(self, visual_indices=(0, 1, 2, 3, 4, 5), all_indices=False, force_visual_indices=False, every_n_epoch=3,
                  no_sanity_check=False, load_compute=False, load_visual=False, data_dir=None, output_name=None,
                  use_dloader=False, num_gpus=1, parallel_vis=False, single_vis=True, visall_after_training_end=True, **_):
-        self.visual_indices = "all" if (all_indices and not force_visual_indices) else list(visual_indices)
+        # plutil.py:177: the YAML value "all" (configs/demo/*.yaml) selects every item, like all_indices
+        self.visual_indices = "all" if ((all_indices and not force_visual_indices) or (isinstance(visual_indices, str) and visual_indices == "all")) \
+            else list(visual_indices)
         self.force_visual_indices, self.load_compute, self.num_gpus, self.parallel_vis = force_visual_indices, load_compute, num_gpus, parallel_vis
         self.output_name = output_name or type(self).__name__
         self.data_dir = data_dir or os.path.join("experiments", "temp", self.output_name)

@@ -23,6 +23,7 @@ def _usable_cores():
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock assertions on an idle MI355X (run explicitly with -m perf; never part of -m gpu)")
     import torch
     torch.set_num_threads(_usable_cores())
 

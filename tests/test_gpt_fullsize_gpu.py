@@ -211,3 +211,32 @@ def test_many_rows_at_long_cached_lengths(small812, B):
     worst, bad = _oracle_check(sd_t, cfg, c, [Lc] * B, got, hist, u, list(range(B)), pick_rows={0, 1, 64, B - 1})
     print(f"{B} rows at L 700..760: max |logit diff| {worst:.2e}, draw mismatches {bad}")
     assert worst < LOGIT_TOL and bad == 0
+
+
+def test_full_size_full_length_512_free_running_steps_to_the_block_limit(full):
+    """BASELINE config 3 at FULL length and REAL size in one run (shapeformer.py:54-123): d = 1024 / 20+4 layers, 4 ragged rows with
+    L_c = 300 / 291 / 300 / 291, all 512 free-running steps of the hipGraph decode loop up to L = 812 = block_size (cached lengths
+    299..811: up to four 256-key passes of the decode attention per launch, the last position of the positional table, the KV cache's
+    last row).  The masks are off so that every row stays alive and every one of the 4 x 512 x 2 draws is a real top-k / top-p draw.
+    The oracle (KV-cached, pinned to the reference) is driven teacher-forced on the HIP tokens: masked logits < 1e-3 at every step,
+    0 draw mismatches."""
+    from oracle import gpt_oracle as GO
+    g, sd_t, cfg = full
+    rs = np.random.RandomState(41)
+    Lc, steps, seed = [300, 291, 300, 291], 512, 23
+    B = len(Lc)
+    c = _cond(rs, Lc)
+    mask = dict(mask_invalid=False, mask_invalid_completion=False)
+    out = g.sample(torch.from_numpy(c), torch.tensor(Lc, dtype=torch.int32), max_steps=steps, seed=seed, stop_early=False,
+                   return_logits=True, **mask)
+    assert out["steps"] == steps, "Lmax - max(L_c) = 512: the run must take all 512 steps"
+    got, hist = out["samples"].numpy(), [h.numpy() for h in out["logits_history"]]
+    assert got.shape == (B, steps, 2)
+    ln = g._state["len"].cpu().numpy()
+    assert np.array_equal(ln, np.array(Lc) + steps) and int(ln.max()) == g.Lmax == 812
+    u = GO.uniforms(seed, steps, B)
+    worst, bad = _oracle_check(sd_t, cfg, c, Lc, got, hist, u, list(range(B)), **mask)
+    print(f"full size, full length: 4 ragged rows x {steps} steps to L = 812: max |logit diff| {worst:.2e}, draw mismatches {bad} of {B * steps * 2}")
+    assert worst < LOGIT_TOL and bad == 0
+    # the rows are alive to the end: the last 64 steps still draw many distinct tokens
+    assert len(np.unique(got[:, -64:, 1])) > 32

@@ -139,6 +139,24 @@ order = bk.finish()                                              # "emb" was nev
 ok = ok and order == ["heads", "L1", "L0", "emb"] and torch.allclose(flat, torch.arange(40, dtype=torch.float32) * (1 + world) / 2)
 flat.mul_(rank + 1); bk.ready("L0"); bk.finish()                 # reusable for the next step
 ok = ok and torch.allclose(flat, torch.arange(40, dtype=torch.float32) * (1 + world) / 2 * (1 + world) / 2)
+# north_star's path (mode "rs_ag"): in-place reduce-scatter per bucket, "optimizer" on the rank's slice only, in-place all-gather of
+# the updated values; a bucket the world size does not divide ("odd", 7 elements) falls back to the ring all-reduce
+base = torch.arange(47, dtype=torch.float32)
+flat = base * (rank + 1)
+rs = D.GradBuckets(flat, {"L0": (0, 12), "L1": (12, 24), "heads": (24, 30), "emb": (30, 40), "odd": (40, 47)}, dist, mode="rs_ag")
+ok = ok and [rs.sharded(n) for n in rs.ranges] == [True, True, True, True, False] and rs.shard("L1") == (12 + 6 * rank, 18 + 6 * rank)
+for name in ("heads", "L1", "L0"):
+    rs.ready(name)
+ok = ok and rs.finish() == ["heads", "L1", "L0", "emb", "odd"]
+mean = base * (1 + world) / 2
+mine = torch.zeros(47, dtype=torch.bool)
+for lo, hi in rs.shard_ranges():
+    mine[lo:hi] = True
+ok = ok and torch.allclose(flat[mine], mean[mine]) and int(mine.sum()) == 6 + 6 + 3 + 5 + 7    # own halves + the whole odd bucket
+flat[~mine] = -1.0                       # whatever the other rank's slices hold is never read ...
+flat[mine] = 10.0 - 0.5 * flat[mine]     # ... the "update" touches the own slices only
+rs.all_gather_params()
+ok = ok and torch.allclose(flat, 10.0 - 0.5 * mean)
 print("OK" if ok and t.item() == world else "FAIL", flush=True)
 dist.barrier(); dist.destroy_process_group()
 """
@@ -181,8 +199,8 @@ def test_default_chain_count_rule():
     from shapeformer_amd.pipeline import default_chains
     assert [default_chains(b) for b in (1, 16, 31, 32, 64, 65, 128, 191)] == [1, 1, 1, 2, 2, 2, 2, 3]
     assert [default_chains(b) for b in (192, 256, 320, 384, 1024)] == [4, 4, 4, 4, 4]
-    assert default_chains(1025) == 4      # never more chains than hardware queues: a chain holds <= 96 rows, larger batches run as
-                                          # successive rounds of 4 chains (gpt.sample_microbatched; GPU: test_pipeline_gpu)
+    assert default_chains(1025) == 4      # never more chains than hardware queues: a chain holds <= 192 rows, batches beyond 768 rows
+                                          # run as successive rounds of 4 chains (gpt.sample_microbatched; GPU: test_pipeline_gpu)
 
 
 def test_bench_refuses_inconsistent_rank_environment(monkeypatch):

@@ -200,3 +200,45 @@ def test_checkpoint_resume_is_bit_exact_for_both_models(dev, tmp_path):
     v3.trainer.step_count = 0
     v3.resume(p3)
     assert v3.trainer.step_count == ck3["global_step"]
+
+
+def test_config1_demo_yaml_through_listdataset_and_callback(dev, tmp_path, monkeypatch):
+    """BASELINE config 1 on the GPU box: `configs/demo/demo_vqdif.yaml` (its merged option tree, committed as
+    tests/golden/demo_ds/demo_vqdif.yaml by oracle/make_golden_demo.py) through OUR plugin loader -> DataModule -> ListDataset
+    (list_dataset.py:13-37) -> VisSparseRecon3D.process (vqdif.py:243-269) must reproduce what the REFERENCE's own ListDataset +
+    VisSparseRecon3D.compute_batch returned for the same two demo items (tests/golden/demo_vqdif_ref.npz): code indices, packed
+    sparse tokens and occupied-cell mask exactly, logits to fp32 tolerance; and leave the reference's result files behind."""
+    from shapeformer_amd import plugin as P
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ds_dir = os.path.join(gold, "demo_ds")
+    opt = P.get_opt(os.path.join(ds_dir, "demo_vqdif.yaml"))
+    assert opt["pl_model_opt"]["class"] == "shapeformer.models.vqdif.vqdif.VQDIF" and opt["datamodule_opt"]["kwargs"]["test_batch_size"] == 1
+    monkeypatch.chdir(ds_dir)                      # the YAML's `ditem_list` is relative to the working directory, as in the reference
+    model = P.instantiate_from_opt(opt["pl_model_opt"])
+    dm = P.instantiate_from_opt(opt["datamodule_opt"])
+    dm.setup("test")
+    assert type(dm.test_set).__name__ == "ListDataset" and len(dm.test_set) == 2 and dm.train_set is None
+    item = dm.test_set[0]
+    assert set(item) == {"Xbd", "Xct"} and item["Xbd"].shape == (2048, 3)          # subsample: False -> the stored points, in order
+    cbo = opt["callbacks"]["vis_recon"]
+    cbo["kwargs"]["data_dir"] = str(tmp_path / "demo_vqdif")
+    cb = P.instantiate_from_opt(cbo)
+    assert cb.visual_indices == "all"             # the YAML says `visual_indices: all` (plutil.py:177)
+    out = cb.process(model, dm.test_set)
+    ref = np.load(os.path.join(gold, "demo_vqdif_ref.npz"))
+    Q = int(ref["Q"])
+    assert sorted(out) == ["0", "1"]
+    worst = 0.0
+    for i, name in enumerate(ref["names"]):
+        comp = np.load(tmp_path / "demo_vqdif" / "computed" / f"{i}.npy", allow_pickle=True).item()
+        assert set(comp) == {"logits", "quant_ind", "sparse", "grid_mask", "batch"}
+        assert np.array_equal(comp["quant_ind"].astype(np.int64), ref[f"{name}_quant_ind"].astype(np.int64)), name
+        assert np.array_equal(comp["sparse"].astype(np.int64), ref[f"{name}_sparse"].astype(np.int64)), name
+        assert np.array_equal(np.packbits(comp["grid_mask"].astype(bool)), ref[f"{name}_grid_mask"]), name
+        got, want = comp["logits"].reshape(-1), ref[f"{name}_logits"]
+        assert got.shape == (Q ** 3,)
+        err = np.abs(got - want)
+        worst = max(worst, float(err.max()))
+        assert np.all(err <= 2e-4 + 1e-4 * np.abs(want)), (name, float(err.max()))
+        assert os.path.exists(tmp_path / "demo_vqdif" / "meshes" / f"{i}.ply") or len(out[str(i)]["recon_mesh"]["face"]) == 0
+    print(f"config 1 via YAML -> ListDataset -> VisSparseRecon3D: logits max |diff| vs the reference {worst:.2e}")
