@@ -432,7 +432,10 @@ struct AttnLds {
   __attribute__((aligned(16))) float yacc[NWV][64];
 };
 
-template <int NWV, int U>
+// EARLYV (small grids: <= 2 workgroups per CU, nothing to overlap with but the launch's own latency): the first batch of VALUES is
+// requested together with the first batch of keys, before any score exists, so a row of <= NWV*4*U cached positions costs ONE memory
+// round trip instead of two.  Which registers a value waits in does not change the arithmetic: bit-identical.
+template <int NWV, int U, bool EARLYV>
 __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs& a, const int b, const int h) {
   constexpr int KB = NWV * 4 * U;   // keys per batch of loads
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -459,8 +462,17 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
       if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Kb0 : Kb) + (long long)i * HD + 4 * c4));
     }
   };
-  f32x4 kf0[U];
+  auto load_v = [&](int i0, f32x4 (&vf)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
+      vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Vb0 : Vb) + (long long)i * HD + 4 * c4));
+    }
+  };
+  f32x4 kf0[U], vf0[U];
   load_k(0, kf0);
+  if (EARLYV) load_v(0, vf0);
   if (tid < HD) {
     const float q = a.qkv[pk_off(b, h * HD + tid, 3 * D)];
     const float k = a.qkv[pk_off(b, D + h * HD + tid, 3 * D)];
@@ -492,17 +504,8 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
     load_k(i0, kf);
     score(i0, kf);
   }
-  // same for the values: the first batch is requested before the softmax barrier
-  auto load_v = [&](int i0, f32x4 (&vf)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
-      vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Vb0 : Vb) + (long long)i * HD + 4 * c4));
-    }
-  };
-  f32x4 vf0[U];
-  load_v(0, vf0);
+  // same for the values: the first batch is requested before the softmax barrier (EARLYV: it already is in flight)
+  if (!EARLYV) load_v(0, vf0);
   lmax = wave_max(lmax);
   if (lane == 0) s.red[wave] = lmax;
   __syncthreads();
@@ -542,14 +545,14 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
   }
 }
 
-template <int NWV, int U>
+template <int NWV, int U, bool EARLYV = false>
 __global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : 4) void attn_decode_kernel(AttnArgs a) {   // U <= 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128
   __shared__ AttnLds<NWV> s;
   const int nitems = a.B * a.H;
   prof_begin(a.prof, blockIdx.x);
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int h = __builtin_amdgcn_readfirstlane(it / a.B);   // wave-uniform: keeps the cache bases in scalar registers
-    attn_decode_item<NWV, U>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
+    attn_decode_item<NWV, U, EARLYV>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
     if (it + (int)gridDim.x < nitems) __syncthreads();   // the next item rewrites the hand-off tiles
   }
   if ((a.sem || a.prof) && threadIdx.x == 0) {     // turnstile release: the launch's last workgroup to finish admits the next KV stream
@@ -740,11 +743,13 @@ struct SampleArgs {
 
 #define SMP_MAXC 512
 #define SMP_BIG 8192
+#define SMP_NPOS 1040   // token positions of one row staged in LDS (block_size + 1 <= 1025 on every shipped config)
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ float lg[4352];
   __shared__ unsigned hist[256];
   __shared__ __attribute__((aligned(16))) float cval_s[SMP_MAXC], cexp_s[SMP_MAXC];
   __shared__ int cidx_s[SMP_MAXC];
+  __shared__ int spos[SMP_NPOS];
   __shared__ float redf[8];
   __shared__ int redi[8];
   __shared__ unsigned s_prefix, s_need;
@@ -758,23 +763,43 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   int* cidx = big ? reinterpret_cast<int*>(dyn_lds + SMP_BIG) : cidx_s;
   float* cexp = big ? dyn_lds + 2 * SMP_BIG : cexp_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int L = a.len[b], lc = a.Lc[b];
-  const int j = L - lc - a.step_offset;  // step index of this row (the reference's loop counter, shapeformer.py:71)
+  // Everything the row needs from HBM is requested in ONE round trip: the logits (registers), the row's state words, and the
+  // POSITION column of its token row (LDS, when it fits: Lmax <= SMP_NPOS) - the masks' binary searches over the condition and the
+  // last / current positions are then LDS reads instead of chains of 8-10 dependent global loads (~1 us each: the sampler sits on
+  // the decode step's critical path twice per step).  Same values, same arithmetic.
   const int* row = a.seq + (long long)b * a.Lmax * 2;
-  const int last_pos = row[2 * (L - 1)];
-  const int cur_pos = row[2 * L];  // valid for tuple 1 (pos just sampled)
+  const bool staged = a.Lmax <= SMP_NPOS;
+  float xr[17];       // V <= 4352 = 17 x 256
+#pragma unroll
+  for (int r = 0; r < 17; ++r) {
+    const int v = tid + 256 * r;
+    xr[r] = v < a.V ? a.part[(long long)b * a.ldv + v] : 0.f;
+  }
+  if (staged)
+    for (int i = tid; i < a.Lmax; i += 256) spos[i] = row[2 * i];
+  const int L = a.len[b], lc = a.Lc[b];
+  __syncthreads();
+  auto pos_at = [&](int i) { return staged ? spos[i] : row[2 * i]; };
+  const int j = L - lc - a.step_offset;  // step index of this row (the reference's loop counter, shapeformer.py:71)
+  const int last_pos = pos_at(L - 1);
+  const int cur_pos = pos_at(L);  // valid for tuple 1 (pos just sampled)
+  // this draw's uniform (counter hash of (step, tuple, global row)): formed here so that the seed's load is off the serial tail
+  const float u_draw = sf_uniform(a.seed_dev ? *a.seed_dev : a.seed, (unsigned)((j * 2 + a.tuple_i) * a.rows_total + a.row_offset + b));
   // next cond position > last_pos (representers.py:141-150), cond list + [end0+1]
   int next_cond = a.end0 + 1;
   if (a.tuple_i == 0 && a.mask_completion) {
     int lo = 0, hi = lc;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (row[2 * mid] > last_pos) hi = mid; else lo = mid + 1; }
-    if (lo < lc) next_cond = row[2 * lo];
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (pos_at(mid) > last_pos) hi = mid; else lo = mid + 1; }
+    if (lo < lc) next_cond = pos_at(lo);
   }
   // ---- masked logits (sampling_masker) ------------------------------------------------------
   float lmax = -INFINITY;
   int amax = 0;
-  for (int v = tid; v < a.V; v += 256) {
-    float x = a.part[(long long)b * a.ldv + v];
+#pragma unroll
+  for (int r = 0; r < 17; ++r) {
+    const int v = tid + 256 * r;
+    if (v >= a.V) continue;
+    float x = xr[r];
     for (int s = 1; s < a.S; ++s) x += a.part[((long long)s * a.M + b) * a.ldv + v];
     if (a.tuple_i == 1) {
       if (cur_pos == a.end0) x = (v == a.end1) ? 1.0f : -INFINITY;
@@ -899,47 +924,66 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         __syncthreads();
       }
     }
-    // exps in parallel; the order-sensitive running sums stay sequential (oracle convention)
+    // exps in parallel; the order-sensitive running sums stay sequential (oracle convention), but only ONE sequential pass over
+    // all candidates is left: it also records the running sums (the candidate values are no longer needed, so they go to cval[]).
+    // The second sum of the old form (over the kept prefix) IS one of those running sums, the inverse-CDF scan is a search for the
+    // first running sum above the threshold (they are non-decreasing: done by all threads), and the top-p quotients are formed in
+    // parallel before their sequential accumulation - which stops at the first prefix above top_p, i.e. early.
     const float m0 = cval[0];
     for (int i = tid; i < C; i += 256) cexp[i] = __expf(cval[i] - m0);
     __syncthreads();
     if (tid == 0) {
-      float tot = 0.f;          // strictly sequential adds (the oracle's order); 4 elements per LDS round trip
+      float tot = 0.f;          // strictly sequential adds (the oracle's order); 16 elements per LDS round trip
       int i = 0;
-      for (; i + 4 <= C; i += 4) {
-        const f32x4 e = *reinterpret_cast<const f32x4*>(cexp + i);
-        tot += e[0]; tot += e[1]; tot += e[2]; tot += e[3];
+      for (; i + 16 <= C; i += 16) {
+        f32x4 e[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) e[q4] = *reinterpret_cast<const f32x4*>(cexp + i + 4 * q4);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          f32x4 pr;
+          tot += e[q4][0]; pr[0] = tot; tot += e[q4][1]; pr[1] = tot; tot += e[q4][2]; pr[2] = tot; tot += e[q4][3]; pr[3] = tot;
+          *reinterpret_cast<f32x4*>(cval + i + 4 * q4) = pr;
+        }
       }
-      for (; i < C; ++i) tot += cexp[i];
+      for (; i < C; ++i) { tot += cexp[i]; cval[i] = tot; }
       s_tot = tot;
     }
     __syncthreads();
+    const float tot = s_tot;
+    if (a.top_p > 0.f) {
+      for (int i = tid; i < C; i += 256) cexp[i] = cexp[i] / tot;      // softmax probabilities of the sorted candidates
+      __syncthreads();
+    }
     if (tid == 0) {
       // top-p (common.py:271-284): drop sorted i>=1 where cumsum(softmax)[i-1] > p
       int keep = C;
       if (a.top_p > 0.f) {
-        const float tot = s_tot;
         float cum = 0.f;
         keep = 1;
         for (int i = 0; i + 1 < C; ++i) {
-          cum += cexp[i] / tot;
+          cum += cexp[i];
           if (cum > a.top_p) break;
           keep = i + 2;
         }
       }
-      // inverse-CDF draw (oracle/tokens_oracle.py:sample_filtered convention)
-      const float u = sf_uniform(a.seed_dev ? *a.seed_dev : a.seed, (unsigned)((j * 2 + a.tuple_i) * a.rows_total + a.row_offset + b));
-      float tot2 = 0.f;
-      for (int i = 0; i < keep; ++i) tot2 += cexp[i];
-      const float thr = u * tot2;
-      float cs = 0.f;
-      int pick = keep - 1;
-      for (int i = 0; i < keep; ++i) {
-        cs += cexp[i];
-        if (cs > thr) { pick = i; break; }
-      }
-      s_choice = cidx[pick];
+      // inverse-CDF draw (oracle/tokens_oracle.py:sample_filtered convention): first i < keep whose running sum exceeds u * sum(kept)
+      s_keep = keep;
+      s_tot = u_draw * cval[keep - 1];
+      s_choice = keep - 1;
     }
+    __syncthreads();
+    {
+      const int keep = s_keep;
+      const float thr = s_tot;
+      int first = 0x7fffffff;
+      for (int i = tid; i < keep; i += 256)
+        if (cval[i] > thr) { first = i; break; }       // a thread's indices ascend: its first hit is its smallest
+      for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+      if (lane == 0 && first != 0x7fffffff) atomicMin(&s_choice, first);
+    }
+    __syncthreads();
+    if (tid == 0) s_choice = cidx[s_choice];
     __syncthreads();
     choice = s_choice;
   }
@@ -964,8 +1008,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       if (pos == a.end0) ext = a.end0;
       else {
         int lo = 0, hi = lc;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (row[2 * mid] > pos) hi = mid; else lo = mid + 1; }
-        ext = row[2 * (lo < lc ? lo : lc - 1)];
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (pos_at(mid) > pos) hi = mid; else lo = mid + 1; }
+        ext = pos_at(lo < lc ? lo : lc - 1);
       }
       const f32x4* e0 = reinterpret_cast<const f32x4*>(a.E0 + (long long)pos * a.D);
       const f32x4* e1 = reinterpret_cast<const f32x4*>(a.E1 + (long long)val * a.D);
@@ -1021,6 +1065,31 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   if (lane == 0) red[4 + wave] = se;
   __syncthreads();
   if (tid == 0) loss[m] = mx + __logf((red[4] + red[5]) + (red[6] + red[7])) - row[target[m]];
+}
+
+// Infinity-Cache prefetch (no reference counterpart): streams up to four byte ranges - the NEXT layer's packed decode weights - through
+// plain loads and drops the data.  Launched on a side branch of the decode step's hipGraph while the current layer's latency-bound
+// launches run (16-row decode: ~2.5 of 6.3 TB/s in use), so that every GEMM launch of the next layer starts on memory-side cache hits
+// instead of waiting for HBM across a launch boundary.  Scheduling only: touches no state.
+struct PrefetchArgs { const f32x4* p[4]; long long n[4]; float* sink; };
+__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchArgs a) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const long long stride = (long long)gridDim.x * 256, i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) {
+    const f32x4* p = a.p[r];
+    const long long n = a.n[r];
+    long long i = i0;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; i < n; i += stride) acc += p[i];
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345678e-30f && a.sink) a.sink[0] = acc[0];   // never true in practice: keeps the loads alive
 }
 
 __global__ void set_len_kernel(int* len, const int* src, int B, int delta) {
@@ -1196,6 +1265,14 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
   if (pad && attr_err != hipSuccess) return (int)attr_err;
   if (sem) hipLaunchKernelGGL(attn_gate_kernel, dim3(1), dim3(64), 0, st, sem, lanes);
 #define AT(W_, U_) hipLaunchKernelGGL((attn_decode_kernel<W_, U_>), dim3(grid), dim3(64 * W_), pad, st, a)
+  // small grids (<= 2 workgroups per CU: BASELINE config 3's 16 rows x 16 heads): nothing competes for the registers, so the launch is
+  // bound by its own dependent round trips - 8 loads in flight per lane (512 keys per batch with 16 waves) and the values requested
+  // together with the keys.  attn_small: 1 = automatic (default), 0 = off.
+  if (g_tune.attn_small && g_tune.attn_blocks == 0 && nitems <= 512 && !pad) {
+    hipLaunchKernelGGL((attn_decode_kernel<16, 8, true>), dim3(grid), dim3(1024), 0, st, a);
+    SFMI_CHECK_LAUNCH();
+    return SFMI_OK;
+  }
   if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else if (g_tune.attn_unroll == 2) AT(16, 2); else AT(16, 4); }
   else { if (g_tune.attn_unroll == 8) AT(8, 8); else if (g_tune.attn_unroll == 2) AT(8, 2); else AT(8, 4); }
 #undef AT
@@ -1277,6 +1354,21 @@ int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex,
 int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream) {
   if (!logits || !target || !loss || M <= 0 || V <= 0) return SFMI_EINVAL;
   hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, logits, target, loss, V, ld);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// streams the byte ranges (p[i], bytes[i]) (16-byte aligned, multiples of 16; NULL / 0 entries are skipped) through `blocks` workgroups
+// and discards the data: warms the Infinity Cache ahead of the decode GEMMs of the next layer
+int sfmi_prefetch_ranges(const void* p0, long long b0, const void* p1, long long b1, const void* p2, long long b2, const void* p3,
+                         long long b3, int blocks, float* sink, void* stream) {
+  if (blocks <= 0 || blocks > 4096 || ((b0 | b1 | b2 | b3) & 15) || b0 < 0 || b1 < 0 || b2 < 0 || b3 < 0) return SFMI_EINVAL;
+  PrefetchArgs a;
+  const void* ps[4] = {p0, p1, p2, p3};
+  const long long bs[4] = {b0, b1, b2, b3};
+  for (int i = 0; i < 4; ++i) { a.p[i] = reinterpret_cast<const f32x4*>(ps[i]); a.n[i] = ps[i] ? bs[i] / 16 : 0; }
+  a.sink = sink;
+  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

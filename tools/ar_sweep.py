@@ -7,7 +7,8 @@ with HIP events, optionally with one kernel family disabled (timing-only ablatio
 
 A configuration line is `name key=value ...`; keys: the sfmi_tune_set knobs (attn_blocks, attn_unroll, attn_waves,
 attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `lanes=` (gpt.ATTN_LANES: attention turnstile, at most that many
-chains stream their KV cache at a time).  Lines starting with # are skipped.
+chains stream their KV cache at a time), `prefetch=` (gpt.PREFETCH_BLOCKS: Infinity-Cache weight prefetch branch of a single chain),
+`profile=attn,gemm` (in-situ launch timing: prints launches and mean us per family).  Lines starting with # are skipped.
 Condition lengths are uniform in [100, 216] (mean 158 = the bench's synthetic clouds); positions ascending, end-token closed.
 """
 from __future__ import annotations
@@ -101,7 +102,7 @@ class PowerProbe:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default="gpurun_out/r3/ar_sweep.txt")
+    ap.add_argument("--out", default="gpurun_out/r4/ar_sweep.txt")
     ap.add_argument("--rows", type=int, default=320)
     ap.add_argument("--chains", type=int, default=4)
     ap.add_argument("--steps", type=int, default=512)
@@ -120,7 +121,8 @@ def main():
         print(s, flush=True)
         out.write(s + "\n"); out.flush()
     say(f"# ar_sweep: model built in {time.time() - t0:.1f}s; default rows {a.rows} chains {a.chains} steps {a.steps}")
-    defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad", "sdf_blocks", "dgemm_nt2")}
+    defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad", "sdf_blocks", "dgemm_nt2",
+                                                           "dgemm_nw", "dgemm_un", "attn_small")}
     probe = PowerProbe()
     say(f"# power probe: device {probe.bdf}, files {probe.files}")
     bgst = {}        # background SDF-query load (`bgsdf=<shapes per launch>[:<launches>]`): the MFMA-bound decode stage of a previous batch
@@ -159,6 +161,8 @@ def main():
         gpt._ablate = kv.pop("ablate", "")
         gpt.ATTN_LANES = int(kv.pop("lanes", "0"))
         gpt.S_PROJ_M, gpt.S_FC2 = int(kv.pop("sproj", "1")), int(kv.pop("sfc2", "4"))      # in-kernel split-K of proj / fc2 (part of the graph key)
+        gpt.PREFETCH_BLOCKS = int(kv.pop("prefetch", "0"))
+        gpt._profile = kv.pop("profile", "")
         bg = kv.pop("bgsdf", None)
         for k, v in defaults.items():
             L.check(lib.sfmi_tune_set(k.encode(), int(kv.pop(k, v))), f"tune {k}")
@@ -191,6 +195,8 @@ def main():
                 kw = dict(max_steps=a.steps, stop_early=False, seed=rep, after_prefill=started)
                 if rep:
                     probe.start()
+                    if gpt._profile:
+                        gpt.launch_profile(reset=True)
                 if chains > 1:
                     r = gpt.sample_microbatched(tok, Lc, n_micro=chains, **kw)
                 else:
@@ -208,12 +214,15 @@ def main():
                         bginfo = (f"   bg SDF {nshape} shapes/launch: alone {min(t_alone):.2f} ms, {done_bg} of {nl} launches done inside the {ar_ms:.0f} ms loop "
                                   f"= {done_bg * min(t_alone):.0f} ms of decode work hidden ({done_bg * nshape / ar_ms * 1e3:.0f} shapes/s of SDF)")
             sem = gpt._sem.cpu().tolist()
+            if gpt._profile:
+                pr = gpt.launch_profile(reset=True)
+                bginfo += "   in situ: " + ", ".join(f"{k} {n} launches x {us:.2f} us" for k, (n, us) in pr.items() if n)
             say(f"{name:28s} rows {rows} chains {chains} {' '.join(kvs):50s} ms/step " + " ".join(f"{m:.3f}" for m in ms)
                 + f"   rows/ms {rows / min(ms):.1f}" + (f"   turnstile tickets {sem[0]} time-outs {sem[2]}" if gpt.ATTN_LANES else "") + bginfo + pw)
         except Exception as e:   # keep sweeping
             say(f"{name:28s} FAILED: {type(e).__name__}: {e}")
             torch.cuda.synchronize()
-    gpt._ablate = ""
+    gpt._ablate, gpt._profile, gpt.PREFETCH_BLOCKS = "", "", 0
 
 
 if __name__ == "__main__":

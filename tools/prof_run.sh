@@ -1,13 +1,14 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of one command -> text summary under gpurun_out/ (copy into profiles/ to keep it)
-#   tools/prof_run.sh <name> <command...>
+#   [PROF_OUT=dir] tools/prof_run.sh <name> <command...>
 export TMPDIR=/tmp
 R=$PWD
 name=$1; shift
 rm -rf /tmp/prof_$name
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -- "$@" > /tmp/prof_$name.log 2>&1)
 DB=$(find /tmp/prof_$name -name "*.db" | head -1)
-mkdir -p $R/gpurun_out/r3
-{ echo "# rocprofv3 --kernel-trace --stats -- $*"; grep -a '^{"metric"' /tmp/prof_$name.log | cut -c1-400; python $R/tools/prof_summary.py $DB 40; } > $R/gpurun_out/r3/prof_$name.txt
+OUTD=${PROF_OUT:-$R/gpurun_out/r4}
+mkdir -p $OUTD
+{ echo "# rocprofv3 --kernel-trace --stats -- $*"; grep -a '^{"metric"' /tmp/prof_$name.log | cut -c1-400; python $R/tools/prof_summary.py $DB 40; } > $OUTD/prof_$name.txt
 if [ -z "$DB" ]; then echo "no rocpd database produced; log tail:"; tail -n 20 /tmp/prof_$name.log; fi
-tail -n 45 $R/gpurun_out/r3/prof_$name.txt
+tail -n 45 $OUTD/prof_$name.txt
