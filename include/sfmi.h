@@ -140,11 +140,6 @@ int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, con
 int sfmi_decode_gemm_prof_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
                               int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, int* pblk,
                               unsigned long long* prof, void* stream);
-/* Infinity-Cache prefetch of up to four byte ranges (16-byte aligned, multiples of 16 bytes; NULL entries skipped) by `blocks`
- * workgroups that load and drop the data - the next layer's packed weights, on a side branch of the decode step's hipGraph.
- * Scheduling only (no reference counterpart); sink: one writable float, never written in practice. */
-int sfmi_prefetch_ranges(const void* p0, long long b0, const void* p1, long long b1, const void* p2, long long b2, const void* p3,
-                         long long b3, int blocks, float* sink, void* stream);
 /* embedding of the token at t = len[b]-1 into the fragment-packed residual buffer (input of the first decode step) */
 int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex, const float* pos_emb, const float* cond_pos_emb,
                               const int* seq, const int* len, const int* Lc, float* resid, int B, int D, int Lmax, int end0,

@@ -101,7 +101,6 @@ PROTOTYPES = {
     "sfmi_decode_gemm_slab_floats": (sz, [i32, i32, i32]),
     "sfmi_gpt_embed_packed_f32": (i32, [c_ptr] * 9 + [i32] * 4 + [c_ptr]),
     "sfmi_set_len_i32": (i32, [c_ptr, c_ptr, i32, i32, c_ptr]),
-    "sfmi_prefetch_ranges": (i32, [c_ptr, i64, c_ptr, i64, c_ptr, i64, c_ptr, i64, i32, c_ptr, c_ptr]),
     # training step (csrc/train.hip)
     "sfmi_transpose_f32": (i32, [c_ptr, c_ptr, i32, i32, i32, i32, c_ptr]),
     "sfmi_colsum_f32": (i32, [c_ptr, c_ptr, i32, i32, i32, i32, c_ptr]),

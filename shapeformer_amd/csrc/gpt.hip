@@ -432,10 +432,10 @@ struct AttnLds {
   __attribute__((aligned(16))) float yacc[NWV][64];
 };
 
-// EARLYV (small grids: <= 2 workgroups per CU, nothing to overlap with but the launch's own latency): the first batch of VALUES is
-// requested together with the first batch of keys, before any score exists, so a row of <= NWV*4*U cached positions costs ONE memory
-// round trip instead of two.  Which registers a value waits in does not change the arithmetic: bit-identical.
-template <int NWV, int U, bool EARLYV>
+// (Round 4 measured a "small grid" form for 16-32 rows - 8 loads in flight per lane and the first batch of values requested together
+// with the keys, one round trip instead of two - and dropped it: 0.47 against 0.39 ms per step of attention at 16 rows, the extra loads
+// queue in front of the keys the scores wait for.  profiles/r04_b16_experiments.md)
+template <int NWV, int U>
 __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs& a, const int b, const int h) {
   constexpr int KB = NWV * 4 * U;   // keys per batch of loads
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -472,7 +472,6 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
   };
   f32x4 kf0[U], vf0[U];
   load_k(0, kf0);
-  if (EARLYV) load_v(0, vf0);
   if (tid < HD) {
     const float q = a.qkv[pk_off(b, h * HD + tid, 3 * D)];
     const float k = a.qkv[pk_off(b, D + h * HD + tid, 3 * D)];
@@ -504,8 +503,8 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
     load_k(i0, kf);
     score(i0, kf);
   }
-  // same for the values: the first batch is requested before the softmax barrier (EARLYV: it already is in flight)
-  if (!EARLYV) load_v(0, vf0);
+  // same for the values: the first batch is requested before the softmax barrier
+  load_v(0, vf0);
   lmax = wave_max(lmax);
   if (lane == 0) s.red[wave] = lmax;
   __syncthreads();
@@ -545,14 +544,14 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
   }
 }
 
-template <int NWV, int U, bool EARLYV = false>
+template <int NWV, int U>
 __global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : 4) void attn_decode_kernel(AttnArgs a) {   // U <= 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128
   __shared__ AttnLds<NWV> s;
   const int nitems = a.B * a.H;
   prof_begin(a.prof, blockIdx.x);
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int h = __builtin_amdgcn_readfirstlane(it / a.B);   // wave-uniform: keeps the cache bases in scalar registers
-    attn_decode_item<NWV, U, EARLYV>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
+    attn_decode_item<NWV, U>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
     if (it + (int)gridDim.x < nitems) __syncthreads();   // the next item rewrites the hand-off tiles
   }
   if ((a.sem || a.prof) && threadIdx.x == 0) {     // turnstile release: the launch's last workgroup to finish admits the next KV stream
@@ -629,27 +628,55 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
   for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int kend = min(n, q0 + 64);
   float* Pw = Ps[wave];
+  // K / V blocks go global -> registers -> LDS; the loads of block k0 + 64 are issued right after block k0 has been handed to LDS, so
+  // their latency runs under the 128 MFMAs of block k0 (a workgroup walks only 1 - 4 blocks at the bench's condition lengths: an
+  // exposed load per block was most of its time).
+  constexpr int NIT = (64 * KK + 255) / 256;
+  f32x4 kreg[NIT], vreg[NIT];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int r = i / KK, c = i % KK;
+      if (i < 64 * KK) {
+        const int tk = min(k0 + r, n - 1);
+        const float* src = qkv + (base + tk) * 3 * D + h * HD + 4 * c;
+        kreg[it] = *reinterpret_cast<const f32x4*>(src + D);
+        vreg[it] = *reinterpret_cast<const f32x4*>(src + 2 * D);
+      }
+    }
+  };
+  gload(0);
+  const bool wave_active = q0 + 16 * wave < n;     // a wave whose 16 query rows are all padding only helps with the staging
   for (int k0 = 0; k0 < kend; k0 += 64) {
     __syncthreads();
-    for (int i = tid; i < 64 * KK; i += 256) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
       const int r = i / KK, c = i % KK;
-      const int tk = min(k0 + r, n - 1);
-      const float* src = qkv + (base + tk) * 3 * D + h * HD + 4 * c;
-      const f32x4 kv = *reinterpret_cast<const f32x4*>(src + D), vv = *reinterpret_cast<const f32x4*>(src + 2 * D);
-      *reinterpret_cast<f32x4*>(&Ks[r * AP_KS + 4 * c]) = kv;
-      *reinterpret_cast<f32x4*>(&Vs[r * AP_VS + 4 * c]) = vv;
-      if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
-        const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * HD + 4 * c;  // (B,H,Lmax,HD)
-        *reinterpret_cast<f32x4*>(Kc + co) = kv;
-        *reinterpret_cast<f32x4*>(Vc + co) = vv;
+      if (i < 64 * KK) {
+        *reinterpret_cast<f32x4*>(&Ks[r * AP_KS + 4 * c]) = kreg[it];
+        *reinterpret_cast<f32x4*>(&Vs[r * AP_VS + 4 * c]) = vreg[it];
+        if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
+          const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * HD + 4 * c;  // (B,H,Lmax,HD)
+          *reinterpret_cast<f32x4*>(Kc + co) = kreg[it];
+          *reinterpret_cast<f32x4*>(Vc + co) = vreg[it];
+        }
       }
     }
     __syncthreads();
+    if (k0 + 64 < kend) gload(k0 + 64);
+    if (!wave_active) continue;
+    // key tiles this wave needs from the block: all four below the diagonal; on the diagonal block (k0 == q0) only tiles 0 .. wave
+    // (tile t > wave holds keys > every query row of the wave: fully masked, p == 0 exactly, so skipping it changes no bit); never
+    // tiles that start at or beyond the sequence end
+    const int tmax = min(k0 == q0 ? wave : 3, (kend - k0 - 1) >> 4);
     // S = Q K^T
     f32x4 sacc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t > tmax) continue;
       const float* kp = &Ks[(16 * t + lr) * AP_KS + lq];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kk], kp[4 * kk], sacc[t], 0, 0, 0);
@@ -662,6 +689,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
       float mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        if (t > tmax) continue;
         const int key = k0 + 16 * t + lr;
         if (key > qrow || key >= n) sacc[t][j] = -INFINITY;
         mx = fmaxf(mx, sacc[t][j]);
@@ -674,6 +702,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        if (t > tmax) continue;
         float p = __expf(sacc[t][j] - ms);
         ps += p;                       // the softmax denominator is the undropped sum (att = softmax; att = attn_drop(att))
         if (drop_p > 0.f)              // training: element (b, h, query, key) of the (B,H,P,P) attention-probability tensor
@@ -689,14 +718,19 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[dt][j] *= corr[j];
     __builtin_amdgcn_wave_barrier();   // P tile written and read by this wave only; LDS ops of a wave execute in order
-    // O += P V
+    // O += P V over the keys of the tiles in use
     const float* pp = &Pw[lr * AP_PS + lq];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const float pa = pp[4 * kk];
-      const float* vp = &Vs[(4 * kk + lq) * AP_VS + lr];
+    for (int t = 0; t < 4; ++t) {
+      if (t > tmax) continue;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vp[16 * dt], o[dt], 0, 0, 0);
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int kk = 4 * t + k4;
+        const float pa = pp[4 * kk];
+        const float* vp = &Vs[(4 * kk + lq) * AP_VS + lr];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vp[16 * dt], o[dt], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -1067,31 +1101,6 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   if (tid == 0) loss[m] = mx + __logf((red[4] + red[5]) + (red[6] + red[7])) - row[target[m]];
 }
 
-// Infinity-Cache prefetch (no reference counterpart): streams up to four byte ranges - the NEXT layer's packed decode weights - through
-// plain loads and drops the data.  Launched on a side branch of the decode step's hipGraph while the current layer's latency-bound
-// launches run (16-row decode: ~2.5 of 6.3 TB/s in use), so that every GEMM launch of the next layer starts on memory-side cache hits
-// instead of waiting for HBM across a launch boundary.  Scheduling only: touches no state.
-struct PrefetchArgs { const f32x4* p[4]; long long n[4]; float* sink; };
-__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchArgs a) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const long long stride = (long long)gridDim.x * 256, i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-#pragma unroll 1
-  for (int r = 0; r < 4; ++r) {
-    const f32x4* p = a.p[r];
-    const long long n = a.n[r];
-    long long i = i0;
-    for (; i + 7 * stride < n; i += 8 * stride) {
-      f32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    for (; i < n; i += stride) acc += p[i];
-  }
-  if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345678e-30f && a.sink) a.sink[0] = acc[0];   // never true in practice: keeps the loads alive
-}
-
 __global__ void set_len_kernel(int* len, const int* src, int B, int delta) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) len[i] = src[i] + delta;
@@ -1265,14 +1274,6 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
   if (pad && attr_err != hipSuccess) return (int)attr_err;
   if (sem) hipLaunchKernelGGL(attn_gate_kernel, dim3(1), dim3(64), 0, st, sem, lanes);
 #define AT(W_, U_) hipLaunchKernelGGL((attn_decode_kernel<W_, U_>), dim3(grid), dim3(64 * W_), pad, st, a)
-  // small grids (<= 2 workgroups per CU: BASELINE config 3's 16 rows x 16 heads): nothing competes for the registers, so the launch is
-  // bound by its own dependent round trips - 8 loads in flight per lane (512 keys per batch with 16 waves) and the values requested
-  // together with the keys.  attn_small: 1 = automatic (default), 0 = off.
-  if (g_tune.attn_small && g_tune.attn_blocks == 0 && nitems <= 512 && !pad) {
-    hipLaunchKernelGGL((attn_decode_kernel<16, 8, true>), dim3(grid), dim3(1024), 0, st, a);
-    SFMI_CHECK_LAUNCH();
-    return SFMI_OK;
-  }
   if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else if (g_tune.attn_unroll == 2) AT(16, 2); else AT(16, 4); }
   else { if (g_tune.attn_unroll == 8) AT(8, 8); else if (g_tune.attn_unroll == 2) AT(8, 2); else AT(8, 4); }
 #undef AT
@@ -1354,21 +1355,6 @@ int sfmi_gpt_embed_packed_f32(const float* E0, const float* E1, const float* Ex,
 int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream) {
   if (!logits || !target || !loss || M <= 0 || V <= 0) return SFMI_EINVAL;
   hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, logits, target, loss, V, ld);
-  SFMI_CHECK_LAUNCH();
-  return SFMI_OK;
-}
-
-// streams the byte ranges (p[i], bytes[i]) (16-byte aligned, multiples of 16; NULL / 0 entries are skipped) through `blocks` workgroups
-// and discards the data: warms the Infinity Cache ahead of the decode GEMMs of the next layer
-int sfmi_prefetch_ranges(const void* p0, long long b0, const void* p1, long long b1, const void* p2, long long b2, const void* p3,
-                         long long b3, int blocks, float* sink, void* stream) {
-  if (blocks <= 0 || blocks > 4096 || ((b0 | b1 | b2 | b3) & 15) || b0 < 0 || b1 < 0 || b2 < 0 || b3 < 0) return SFMI_EINVAL;
-  PrefetchArgs a;
-  const void* ps[4] = {p0, p1, p2, p3};
-  const long long bs[4] = {b0, b1, b2, b3};
-  for (int i = 0; i < 4; ++i) { a.p[i] = reinterpret_cast<const f32x4*>(ps[i]); a.n[i] = ps[i] ? bs[i] / 16 : 0; }
-  a.sink = sink;
-  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

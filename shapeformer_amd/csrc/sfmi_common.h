@@ -67,7 +67,5 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   dgemm_nw    : k-parts (waves) per decode-GEMM workgroup: 0 = by shape (default), 4 / 8 / 16 where the K-slice allows it
 //   dgemm_un    : cap on the k16-steps of loads in flight per wave: 0 = by shape (8 / 4 / 2 / 2 / 2 / 1 for 1 .. 6 row tiles); can only lower it
 // sfmi_tune_generation() counts successful sfmi_tune_set calls: callers that cache captured hipGraphs key them on it.
-//   attn_small  : 1 (default) = decode-attention launches of <= 512 (row, head) items use the latency-optimised form (16 waves, 8 loads
-//                 in flight, values requested with the keys; bit-identical to the 16-wave form), 0 = never
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, attn_small; };
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un; };
 extern SfmiTune g_sfmi_tune;

@@ -428,12 +428,6 @@ class CondTupleGPT:
     # Two lanes measured best with four chains (6.48 against 6.68 ms per 320-row step ungated, 6.98 with one lane;
     # profiles/r03_ar_overlap.md).
     ATTN_LANES = 2
-    # Infinity-Cache weight prefetch on a side branch of a SINGLE chain's decode graph (csrc/gpt.hip:prefetch_kernel): while layer l's
-    # latency-bound launches run, `PREFETCH_BLOCKS` workgroups stream layer l+1's packed weights (50 MB) so that its GEMM launches
-    # start on memory-side cache hits.  0 = off.  Used only below PREFETCH_MAX_ROWS rows per chain (a 16-row step leaves > half of
-    # the HBM rate idle; at 96 rows x 4 chains the other chains already keep HBM busy).  Scheduling only.
-    PREFETCH_BLOCKS = 0
-    PREFETCH_MAX_ROWS = 32
     MAX_CHAIN_ROWS = 192   # rows per decode chain: row groups of up to 6 row tiles (96 rows) per decode-GEMM workgroup; larger batches = several chains
     SINGLE_CHAIN_ROWS = 96  # `sample` keeps a batch in ONE chain up to here and interleaves chains above (a lone chain cannot overlap anything)
 
@@ -448,30 +442,10 @@ class CondTupleGPT:
             skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
         lanes = int(sp.get("gate_lanes", 0))
         pa, pg = "attn" in self._profile, "gemm" in self._profile      # in-situ launch timing (results untouched)
-        pf = int(self.PREFETCH_BLOCKS) if (B <= self.PREFETCH_MAX_ROWS and not sp.get("chain")) else 0
-        if pf:
-            if getattr(self, "_pf_stream", None) is None:
-                self._pf_stream = torch.cuda.Stream(device=self.dev)
-                self._pf_sink = torch.zeros(4, device=self.dev)
-            main = torch.cuda.current_stream()
-
-            def prefetch(ws):
-                """Fork: the side stream waits for everything enqueued so far on the chain, then streams up to four weight tensors."""
-                self._pf_stream.wait_stream(main)
-                ws = list(ws) + [None] * (4 - len(ws))
-                with torch.cuda.stream(self._pf_stream):
-                    L.check(lib.sfmi_prefetch_ranges(*[v for w in ws for v in (L.ptr(w), w.numel() * 4 if w is not None else 0)], pf,
-                                                     L.ptr(self._pf_sink), L.stream_ptr()), "sfmi_prefetch_ranges")
-            lw = lambda l_: (l_.pqkv, l_.pproj, l_.pfc1, l_.pfc2)
         # in-kernel split-K per GEMM (only the K = 4 n_embd product, and proj at <= 16 rows, use it)
         Sqkv, Sproj, Sfc1, Sfc2, Shead = 1, self.S_PROJ if B <= 16 else self.S_PROJ_M, 1, self.S_FC2, 1
         for li, ly in enumerate(self.layers):
             stage_end = li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage
-            if pf:      # under THIS layer's launches: the next layer's weights (and the head's, when this layer ends a stage)
-                if li + 1 < len(self.layers):
-                    prefetch(lw(self.layers[li + 1]))
-                if stage_end:
-                    prefetch((self.head_f[ly.stage][0],))
             if "gemm" not in skip:
                 self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st, prof=pg)
             if "attn" not in skip:
@@ -484,8 +458,6 @@ class CondTupleGPT:
                 self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st, prof=pg)
                 self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st, prof=pg)
                 self._dgemm(st["h"], ly.pfc2, None, ly.bfc2, r, r, B, D, 4 * D, D, 0, 0, S=Sfc2, st=st, prof=pg)
-            if pf and li + 1 == len(self.layers):
-                prefetch(lw(self.layers[0]))      # the NEXT step's first layer, under this step's last head GEMM + sampler
             if stage_end:
                 s = ly.stage
                 hp, hc1, hc2 = self.head_f[s]
@@ -500,8 +472,6 @@ class CondTupleGPT:
                                                 int(sp["mask_invalid_completion"]), sp["max_steps"], sp["seed"], L.ptr(st.get("seed")), int(s == 1),
                                                 sp.get("row_offset", 0), sp.get("rows_total", B), int(sp.get("step_offset", 0)),
                                                 L.stream_ptr()), "sfmi_gpt_sample_f32")
-        if pf:
-            torch.cuda.current_stream().wait_stream(self._pf_stream)      # join (a captured graph must end on one stream)
 
     # ------------------------------------------------------------------ sample_indices
     def _prepare(self, c_tokens, Lc, max_steps, sp_kw, slot=0, row_offset=0, rows_total=None, return_logits=False,
@@ -571,7 +541,7 @@ class CondTupleGPT:
         graph = None
         if use_graph and steps > 1:
             gkey = (B, tuple(sorted((k, v) for k, v in sp.items() if k not in ("hist", "force", "seed"))), return_logits,
-                    self._ablate, self._profile, self.S_PROJ, self.S_PROJ_M, self.S_FC2, int(self.PREFETCH_BLOCKS), int(self.PREFETCH_MAX_ROWS),
+                    self._ablate, self._profile, self.S_PROJ, self.S_PROJ_M, self.S_FC2,
                     int(L.lib().sfmi_tune_generation()))      # launch-shape knobs are baked into a captured graph: re-capture when one changed
             cached = self._graphs.get(slot)
             if cached is None or cached[0] != gkey or return_logits:

@@ -122,7 +122,7 @@ def main():
         out.write(s + "\n"); out.flush()
     say(f"# ar_sweep: model built in {time.time() - t0:.1f}s; default rows {a.rows} chains {a.chains} steps {a.steps}")
     defaults = {k: lib.sfmi_tune_get(k.encode()) for k in ("attn_blocks", "attn_unroll", "attn_waves", "attn_lds_pad", "sdf_blocks", "dgemm_nt2",
-                                                           "dgemm_nw", "dgemm_un", "attn_small")}
+                                                           "dgemm_nw", "dgemm_un")}
     probe = PowerProbe()
     say(f"# power probe: device {probe.bdf}, files {probe.files}")
     bgst = {}        # background SDF-query load (`bgsdf=<shapes per launch>[:<launches>]`): the MFMA-bound decode stage of a previous batch
@@ -161,7 +161,6 @@ def main():
         gpt._ablate = kv.pop("ablate", "")
         gpt.ATTN_LANES = int(kv.pop("lanes", "0"))
         gpt.S_PROJ_M, gpt.S_FC2 = int(kv.pop("sproj", "1")), int(kv.pop("sfc2", "4"))      # in-kernel split-K of proj / fc2 (part of the graph key)
-        gpt.PREFETCH_BLOCKS = int(kv.pop("prefetch", "0"))
         gpt._profile = kv.pop("profile", "")
         bg = kv.pop("bgsdf", None)
         for k, v in defaults.items():
@@ -222,7 +221,7 @@ def main():
         except Exception as e:   # keep sweeping
             say(f"{name:28s} FAILED: {type(e).__name__}: {e}")
             torch.cuda.synchronize()
-    gpt._ablate, gpt._profile, gpt.PREFETCH_BLOCKS = "", "", 0
+    gpt._ablate, gpt._profile = "", ""
 
 
 if __name__ == "__main__":
