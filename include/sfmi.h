@@ -53,6 +53,12 @@ int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* gr
                                int B, int T, int R, float* tap_stage1, float* tap_stage4c, void* stream);
 int sfmi_encode_points_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out,
                            void* workspace, int B, int T, int R, void* stream);
+/* the same with the FIRST Downsampler convolution fused in (enc.py:66-93 generate_grid_features: scatter_mean -> Downsampler,
+ * updown.py:101-118 first Conv3d(32 -> 64, k2, s2, no bias) (+ReLU)): cloud -> y (B,32,32,32,64) channels-last straight from the
+ * per-cell sums; the dense 64^3 x 32 mean grid is never written or read.  w_down0 = that convolution's weights as packed by
+ * sfmi_conv_pack_weight ([8 taps][64][32]). */
+int sfmi_encode_points_down_f32(const float* cloud, const float* wpack, const float* w_down0, float* y, unsigned char* mask,
+                                int* cell_out, void* workspace, int B, int T, int R, int relu, void* stream);
 
 /* ---- Conv3d / GroupNorm / pooling: updown.py:79-132 (Downsampler, Upsampler), unet3d.py:79-144,195-293,449-474 -- */
 int sfmi_conv_pack_weight(const float* w, int Cout, int Cin, int KS, float* out); /* [host] (Cout,Cin,k,k,k)->[tap][Cout][Cin] */

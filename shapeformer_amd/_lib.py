@@ -59,6 +59,7 @@ PROTOTYPES = {
     "sfmi_enc_pack_weights": (i32, [c_ptr] * 10),
     "sfmi_enc_workspace_bytes": (sz, [i32, i32]),
     "sfmi_encode_points_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
+    "sfmi_encode_points_down_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, i32, c_ptr]),
     "sfmi_encode_points_tap_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr, c_ptr, c_ptr]),
     # conv / groupnorm / pooling
     "sfmi_conv_pack_weight": (i32, [c_ptr, i32, i32, i32, c_ptr]),

@@ -300,6 +300,61 @@ __global__ void enc_grid_mean_kernel(const int* __restrict__ cell, const int* __
   grid[((long long)b * ENC_G * ENC_G * ENC_G + c) * 32 + ch] = (float)(s / (double)ccount[i]);
 }
 
+// E6': the first Downsampler convolution (Conv3d(32 -> 64, k2, s2, no bias) + ReLU, updown.py:101-118) taken DIRECTLY from the
+// per-cell sums - the dense 64^3 x 32 mean grid (33.5 MB per shape: a zero-fill, a scatter of ~3 000 occupied cells, and a full read
+// by the convolution) is never materialised.  A parent voxel of the 32^3 output owns 8 child cells; the counting sort's start /
+// end maps say which of them hold points (1-2 % do), the cell mean is formed exactly as enc_grid_mean_kernel forms it, and an
+// empty child contributes exactly zero, as it does in the dense convolution.  One workgroup per (shape, zo, yo) row of 32 parents,
+// wave w takes parents w, w+4, ...; lane = output channel; taps and input channels are summed in ascending order (fmaf): a fixed
+// order, deterministic - the dense MFMA path sums the same products in another order (differences ~1e-7 relative).
+__global__ __launch_bounds__(256) void enc_down0_sparse_kernel(const int* __restrict__ start, const int* __restrict__ cend,
+                                                               const long long* __restrict__ csum, const int* __restrict__ ccount,
+                                                               const float* __restrict__ w /*[8 taps][64][32]*/, float* __restrict__ y,
+                                                               int T, int relu) {
+  constexpr int G = ENC_G, GO = ENC_G / 2, NC = ENC_G * ENC_G * ENC_G;
+  const int b = blockIdx.z, zo = blockIdx.y, yo = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the four child rows (dz, dy) of this parent row: 64 cells each, lane = child x
+  int st[4], en[4];
+  unsigned long long occ[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long c = (long long)b * NC + ((long long)(2 * zo + (r >> 1)) * G + (2 * yo + (r & 1))) * G + lane;
+    st[r] = start[c]; en[r] = cend[c];
+    occ[r] = __ballot(en[r] != st[r]);
+  }
+  float* yrow = y + ((((long long)b * GO + zo) * GO + yo) * GO) * 64;
+  for (int xo = wave; xo < GO; xo += 4) {
+    float acc = 0.f;
+    const unsigned bits = (unsigned)((occ[0] >> (2 * xo)) & 3) | (unsigned)(((occ[1] >> (2 * xo)) & 3) << 2) |
+                          (unsigned)(((occ[2] >> (2 * xo)) & 3) << 4) | (unsigned)(((occ[3] >> (2 * xo)) & 3) << 6);
+    if (bits) {                                   // wave-uniform: most parents have no occupied child
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          if (!((bits >> (2 * r + dx)) & 1)) continue;
+          const int s0 = __shfl(st[r], 2 * xo + dx, 64);
+          const long long seg = (long long)b * T + s0;             // sorted position of the cell's first point names its sums
+          // cell mean of channel (lane & 31), formed as enc_grid_mean_kernel does
+          const double sm = (double)csum[seg * 32 + (lane & 31)] * (1.0 / 4294967296.0);
+          const float mean = (float)(sm / (double)ccount[seg]);
+          const int tap = ((r >> 1) * 2 + (r & 1)) * 2 + dx;        // (dz, dy, dx), the conv kernel's tap order
+          const f32x4* wp = reinterpret_cast<const f32x4*>(w + ((long long)tap * 64 + lane) * 32);
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) {
+            const f32x4 wv = wp[k4];
+            acc = fmaf(wv[0], __shfl(mean, 4 * k4 + 0, 64), acc);
+            acc = fmaf(wv[1], __shfl(mean, 4 * k4 + 1, 64), acc);
+            acc = fmaf(wv[2], __shfl(mean, 4 * k4 + 2, 64), acc);
+            acc = fmaf(wv[3], __shfl(mean, 4 * k4 + 3, 64), acc);
+          }
+        }
+    }
+    yrow[(long long)xo * 64 + lane] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
 extern "C" {
 
 size_t sfmi_enc_pack_floats(void) { return ENC_PACK_FLOATS; }
@@ -345,19 +400,33 @@ size_t sfmi_enc_workspace_bytes(int B, int T) {
   return bt * 12 + 2 * (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + 1024;
 }
 
-int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace,
-                               int B, int T, int R, float* tap_stage1, float* tap_stage4c, void* stream_);
+static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace, int B, int T,
+                        int R, float* tap_stage1, float* tap_stage4c, const float* down_w, float* down_y, int down_relu, void* stream_);
 // replaces LocalPoolPointnet.forward up to scatter_mean (enc.py:115-140 minus the Downsampler):
 // cloud (B,T,3) -> dense channels-last mean grid (B,64,64,64,32) + latent occupancy mask (B,R,R,R) u8.
 int sfmi_encode_points_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask,
                            int* cell_out /*optional (B,T)*/, void* workspace, int B, int T, int R, void* stream_) {
-  return sfmi_encode_points_tap_f32(cloud, wpack, grid_cl, mask, cell_out, workspace, B, T, R, nullptr, nullptr, stream_);
+  if (!grid_cl) return SFMI_EINVAL;
+  return enc_pipeline(cloud, wpack, grid_cl, mask, cell_out, workspace, B, T, R, nullptr, nullptr, nullptr, nullptr, 0, stream_);
+}
+// the same encoder with the FIRST Downsampler convolution fused in (enc.py:115-140 + the first Conv3d(32 -> 64, k2, s2, no bias)
+// (+ ReLU) of updown.py:101-118): cloud -> y (B,32,32,32,64) channels-last, taken from the per-cell sums without materialising the
+// dense 64^3 x 32 mean grid.  w_down0: the convolution's weights as [8 taps (dz,dy,dx)][64][32] (the layout sfmi_conv3d_cl_f32 takes).
+int sfmi_encode_points_down_f32(const float* cloud, const float* wpack, const float* w_down0, float* y, unsigned char* mask,
+                                int* cell_out /*optional (B,T)*/, void* workspace, int B, int T, int R, int relu, void* stream_) {
+  if (!w_down0 || !y) return SFMI_EINVAL;
+  return enc_pipeline(cloud, wpack, nullptr, mask, cell_out, workspace, B, T, R, nullptr, nullptr, w_down0, y, relu, stream_);
 }
 // the same pipeline with per-point taps for stage-wise parity tests (caller's point order): tap_stage1 (B,T,32) = output of
 // blocks[1] (after the first local max pool), tap_stage4c (B,T,64) = [output of blocks[4] | c = fc_c(net)] (enc.py:124-133)
 int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace,
                                int B, int T, int R, float* tap_stage1, float* tap_stage4c, void* stream_) {
-  if (!cloud || !wpack || !grid_cl || !mask || !workspace || B <= 0 || T <= 0 || R <= 0) return SFMI_EINVAL;
+  if (!grid_cl) return SFMI_EINVAL;
+  return enc_pipeline(cloud, wpack, grid_cl, mask, cell_out, workspace, B, T, R, tap_stage1, tap_stage4c, nullptr, nullptr, 0, stream_);
+}
+static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace, int B, int T,
+                        int R, float* tap_stage1, float* tap_stage4c, const float* down_w, float* down_y, int down_relu, void* stream_) {
+  if (!cloud || !wpack || (!grid_cl && !down_y) || !mask || !workspace || B <= 0 || T <= 0 || R <= 0) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
   const size_t bt = (size_t)B * T, nc = (size_t)B * ENC_G * ENC_G * ENC_G;
   char* w = (char*)workspace;
@@ -373,7 +442,7 @@ int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* gr
   hipMemsetAsync(start, 0, nc * 4, st);
   hipMemsetAsync(mask, 0, (size_t)B * R * R * R, st);
   hipMemsetAsync(csum, 0, bt * 256 + bt * 4, st);
-  hipMemsetAsync(grid_cl, 0, nc * 32 * 4, st);
+  if (grid_cl) hipMemsetAsync(grid_cl, 0, nc * 32 * 4, st);
   int nb = (int)((bt + 255) / 256);
   // group the points of every shape by cell: histogram -> exclusive scan -> scatter (2 integer atomics per point)
   hipLaunchKernelGGL(enc_cells_kernel, dim3(nb), dim3(256), 0, st, cloud, cell, start, mask, B, T, R);
@@ -400,8 +469,12 @@ int sfmi_encode_points_tap_f32(const float* cloud, const float* wpack, float* gr
   hipLaunchKernelGGL(enc_block_kernel<4>, dim3(grid), dim3(256), lds4, st, cloud, scell, start, order, net[1], sm[1], tap_stage4c,
                      nullptr, csum, ccount, wpack, B, T);
   long long nthr = (long long)bt * 32;
-  hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, scell, start, csum,
-                     ccount, grid_cl, B, T);
+  if (grid_cl)
+    hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, scell, start, csum,
+                       ccount, grid_cl, B, T);
+  if (down_y)     // `cursor` has been advanced to each cell's END by the scatter: cursor != start <=> the cell holds points
+    hipLaunchKernelGGL(enc_down0_sparse_kernel, dim3(ENC_G / 2, ENC_G / 2, B), dim3(256), 0, st, start, cursor, csum, ccount, down_w, down_y,
+                       T, down_relu);
   if (cell_out) hipMemcpyAsync(cell_out, cell, bt * 4, hipMemcpyDeviceToDevice, st);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;

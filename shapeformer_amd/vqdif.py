@@ -54,6 +54,7 @@ class _Conv:
 
 class VQDIF:
     """Inference-side VQDIF (res16: d=128, 2 down/up steps; res32: d=64, 1 step)."""
+    FUSE_DOWN0 = True     # False: the dense-grid route (mean grid + sfmi_conv3d_cl_f32), kept as the cross-check of the fused first conv
 
     G = 64
     GROUPS = 8
@@ -162,13 +163,26 @@ class VQDIF:
         R = self.res
         lib = L.lib()
         ws = self._buf("enc_ws", (lib.sfmi_enc_workspace_bytes(B, T),), torch.uint8)
-        grid = self._buf("enc_grid", (B, self.G, self.G, self.G, 32))
         mask = self._buf("enc_mask", (B, R, R, R), torch.uint8)
         self.last_cell = self._buf("enc_cell", (B, T), torch.int32)
-        L.check(lib.sfmi_encode_points_f32(L.ptr(cloud), L.ptr(self.enc_w), L.ptr(grid), L.ptr(mask), L.ptr(self.last_cell),
-                                           L.ptr(ws), B, T, R, L.stream_ptr()), "sfmi_encode_points_f32")
-        x, sc, sh = grid, None, None
+        d0 = self.down[0]
+        first = 0
+        if self.FUSE_DOWN0 and d0.ks == 2 and d0.stride == 2 and d0.cin == 32 and d0.cout == 64 and self.G == 64:
+            # the first Downsampler convolution straight from the per-cell sums (csrc/encoder.hip:enc_down0_sparse_kernel): the
+            # dense 64^3 x 32 mean grid (33.5 MB per shape) is neither zero-filled, scattered into, nor read back
+            x = self._buf("down0", (B, self.G // 2, self.G // 2, self.G // 2, 64))
+            L.check(lib.sfmi_encode_points_down_f32(L.ptr(cloud), L.ptr(self.enc_w), L.ptr(d0.w), L.ptr(x), L.ptr(mask),
+                                                    L.ptr(self.last_cell), L.ptr(ws), B, T, R, 1, L.stream_ptr()), "sfmi_encode_points_down_f32")
+            sc, sh = self._gn(x, d0.gamma, d0.beta, "down0")
+            first = 1
+        else:
+            grid = self._buf("enc_grid", (B, self.G, self.G, self.G, 32))
+            L.check(lib.sfmi_encode_points_f32(L.ptr(cloud), L.ptr(self.enc_w), L.ptr(grid), L.ptr(mask), L.ptr(self.last_cell),
+                                               L.ptr(ws), B, T, R, L.stream_ptr()), "sfmi_encode_points_f32")
+            x, sc, sh = grid, None, None
         for i, cv in enumerate(self.down):  # 'crg': conv -> ReLU -> GN (GN folded into the next consumer)
+            if i < first:
+                continue
             x = self._conv(x, cv, f"down{i}", sc, sh, relu=True)
             sc, sh = self._gn(x, cv.gamma, cv.beta, f"down{i}")
         latent = self._affine(x, sc, sh, "latent")

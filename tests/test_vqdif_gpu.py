@@ -168,3 +168,39 @@ def test_per_point_encoder_stages_vs_reference_fixture(vq):
     grid2, mask2 = torch.empty_like(grid), torch.empty_like(mask)
     L.check(lib.sfmi_encode_points_f32(L.ptr(cloud), L.ptr(vq.enc_w), L.ptr(grid2), L.ptr(mask2), None, L.ptr(ws), B, T, 16, L.stream_ptr()), "encode")
     assert torch.equal(grid, grid2) and torch.equal(mask, mask2)
+
+
+@pytest.mark.parametrize("res", [16, 32])
+def test_fused_first_downsampler_conv_equals_the_dense_grid_route(dev, res):
+    """enc.py:66-93: the product path takes the first Downsampler convolution (k2 s2, 32 -> 64, no bias, + ReLU) straight from the
+    per-cell sums (csrc/encoder.hip:enc_down0_sparse_kernel, no dense 64^3 x 32 mean grid).  It must give what the dense route
+    gives - mean grid, zero-filled, through sfmi_conv3d_cl_f32 (the route the reference-fixture tests above pinned in rounds 1-3):
+    identical occupancy mask and cell ids, the first conv's output and the latent to fp32 summation-order tolerance, identical
+    code indices (near-ties excepted), on the reference's demo clouds and on a 16 384-point synthetic batch."""
+    from shapeformer_amd import synthetic, weights as W
+    from shapeformer_amd.vqdif import VQDIF
+    vq = VQDIF(W.make_state_dict(W.vqdif_spec(res)), res=res, device=dev)
+    z = np.load(os.path.join(G, "vqdif16_small.npz"))
+    for cloud in (torch.from_numpy(z["cloud"]), torch.from_numpy(synthetic.make_batch(77, 3, n_partial=16384)["Xct"])):
+        assert vq.FUSE_DOWN0
+        lat_f, mask_f = vq.encode_cl(cloud)
+        lat_f, mask_f, cell_f, d0_f = lat_f.clone(), mask_f.clone(), vq.last_cell.clone(), vq._buf("down0", (cloud.shape[0], 32, 32, 32, 64)).clone()
+        idx_f = vq.quantize_cl(lat_f).clone()
+        try:
+            vq.FUSE_DOWN0 = False
+            lat_d, mask_d = vq.encode_cl(cloud)
+            d0_d = vq._buf("down0", (cloud.shape[0], 32, 32, 32, 64))
+            idx_d = vq.quantize_cl(lat_d)
+        finally:
+            vq.FUSE_DOWN0 = True
+        assert torch.equal(mask_f, mask_d) and torch.equal(cell_f, vq.last_cell)
+        s0 = float(d0_d.abs().max())
+        e0 = float((d0_f - d0_d).abs().max())
+        assert e0 <= 2e-6 * s0 + 1e-7, (e0, s0)
+        assert torch.equal(d0_f == 0, d0_d == 0)                  # the same voxels are empty (ReLU zeros included)
+        scale = float(lat_d.abs().max())
+        e = float((lat_f - lat_d).abs().max())
+        assert e <= 2e-5 * scale + 1e-5, (e, scale)
+        nbad = int((idx_f != idx_d).sum())
+        assert nbad <= 2, nbad
+        print(f"res{res}: fused vs dense first conv {e0:.2e} (scale {s0:.2f}), latent {e:.2e} (scale {scale:.1f}), index mismatches {nbad}")
