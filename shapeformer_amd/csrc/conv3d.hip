@@ -30,14 +30,25 @@ struct ConvArgs {
   int sp_on, spz, spy, spx, padz, pady, padx;
 };
 
-template <int CO_TILES, int WM, int WN, bool UPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES == 1 ? 3 : 2))) void conv3d_igemm_kernel(ConvArgs a) {
+// XR ("x reuse", stride-1 convolutions whose M tile is made of whole x-rows of the output; narrow output-channel tiles): the taps of
+// one (dz, dy) pair read the SAME input voxels shifted by one in x, so a chunk stages the tile's input rows ONCE - each x-row
+// framed by its zero-padding columns - and multiplies them KS times at LDS row offsets 0 .. KS-1 against KS weight tiles.  One third
+// (one half for the 2^3 sub-pixel convolutions) of the global loads, LDS writes and barriers per MFMA of the plain form, which
+// re-stages the activation tile for every tap; with 32 or 64 output channels per workgroup that staging is what bounds the kernel.
+template <int CO_TILES, int WM, int WN, bool UPS, bool XR = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES == 1 && !XR ? 3 : 2))) void conv3d_igemm_kernel(ConvArgs a) {
   constexpr int N_T = 32 * CO_TILES * WM;
   constexpr int M_T = 64 * WN;
   constexpr int W_ROWS = (N_T * 4 + 255) / 256;  // weight float4 rows per thread
+  constexpr int XT = XR ? 3 : 1;                 // weight tiles per chunk (taps along x; KS <= 3)
+  static_assert(!(XR && UPS), "x reuse needs the direct addressing");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* act_lds = lds;                              // [2][M_T][LDS_STRIDE]
-  float* wgt_lds = lds + 2 * M_T * LDS_STRIDE;       // [2][N_T][LDS_STRIDE]
+  // XR: an x-row of Wo voxels occupies Wo + KS - 1 LDS rows: padL zero columns, the Wo real ones, padR zero columns
+  const int xr_rw = XR ? a.Wo + a.KS - 1 : 0;
+  const int xr_padl = XR ? (a.sp_on ? a.padx : a.pad) : 0;
+  const int AROWS = XR ? (M_T / a.Wo) * xr_rw : M_T;   // activation rows per LDS buffer
+  float* act_lds = lds;                              // [2][AROWS][LDS_STRIDE]
+  float* wgt_lds = lds + 2 * AROWS * LDS_STRIDE;     // [2][XT][N_T][LDS_STRIDE]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, pl = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
     vx[i] = xw * a.stride - (a.sp_on ? a.padx : a.pad);
   }
   const int cpt = a.Cin / KC;                 // chunks per tap
-  const int nchunks = a.KS * a.KS * a.KS * cpt;
+  const int nchunks = (XR ? a.KS * a.KS : a.KS * a.KS * a.KS) * cpt;   // XR: one chunk serves the KS taps along x
 
   // Per-chunk work kept off the vector unit (with one 32-column tile per wave the MFMAs of a chunk take ~1000 cycles, and
   // the old per-chunk tap decode + bounds tests + 64-bit address chains of 4 voxels took about as long): per voxel ONE base
@@ -100,10 +111,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
   for (int i = 0; i < W_ROWS; ++i) wbase[i] = (long long)(n0 + srow + 64 * i) * a.Cin + seg * 4;
   int t_dz = 0, t_dy = 0, t_dx = 0, t_cc = 0, t_tap = 0;   // wave-uniform walk over (tap, channel chunk)
 
+  // LDS row of the voxel this thread stages / of the voxels this lane multiplies (XR: inside its framed x-row)
+  int srow_l[WN], mrow_l[2];
+#pragma unroll
+  for (int i = 0; i < WN; ++i) {
+    const int v = srow + 64 * i;
+    srow_l[i] = XR ? (v / a.Wo) * xr_rw + xr_padl + v % a.Wo : v;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int v = wn * 64 + j * 32 + pl;
+    mrow_l[j] = XR ? (v / a.Wo) * xr_rw + v % a.Wo : v;      // tap dx reads row mrow_l + dx
+  }
+  if (XR) {   // the frame columns of both buffers are zero for the whole launch (nothing else writes them)
+    const int nxr = M_T / a.Wo, fr = a.KS - 1;
+    for (int idx = tid; idx < 2 * nxr * fr * (LDS_STRIDE / 4); idx += 256) {
+      const int q4 = idx % (LDS_STRIDE / 4), r = idx / (LDS_STRIDE / 4);
+      const int f = r % fr, xrow = (r / fr) % nxr, S = r / (fr * nxr);
+      const int lrow = xrow * xr_rw + (f < xr_padl ? f : a.Wo + f);
+      *reinterpret_cast<f32x4*>(act_lds + (S * AROWS + lrow) * LDS_STRIDE + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
   // two register sets: the global loads of chunk c+2 are issued while chunk c is multiplied (one set gave the loads only the
   // ~1000 MFMA cycles of a single chunk to land).  The GroupNorm affine and the zero padding are applied when a set is
   // written to LDS (x*scale+shift needs the loaded value: done at load time it would stall on the load it was meant to hide).
-  f32x4 ra[2][WN], rw[2][W_ROWS], rs[2], rt[2];
+  f32x4 ra[2][WN], rw[2][XT * W_ROWS], rs[2], rt[2];
   int rok[2];
   auto load_chunk = [&](const int S) {
     const int c0 = t_cc * KC + seg * 4;
@@ -113,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
     if (UPS || !one_b) {   // general arithmetic (address-folded up-sampling, tiles that straddle shapes): affine applied here
 #pragma unroll
       for (int i = 0; i < WN; ++i) {
-        const int iz = vz[i] + t_dz, iy = vy[i] + t_dy, ix = vx[i] + t_dx;
+        const int iz = vz[i] + t_dz, iy = vy[i] + t_dy, ix = vx[i] + (XR ? xr_padl : t_dx);   // XR: the voxel's own column
         const bool ok = vok[i] && iz >= 0 && iz < Dv && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
@@ -129,27 +162,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
         rok[S] |= 1 << i;
       }
     } else {
-      const long long toff = (((long long)t_dz * a.Hi + t_dy) * a.Wi + t_dx) * a.Cin + t_cc * KC;
+      const long long toff = (((long long)t_dz * a.Hi + t_dy) * a.Wi + (XR ? xr_padl : t_dx)) * a.Cin + t_cc * KC;
       if (a.in_scale) {
         rs[S] = *reinterpret_cast<const f32x4*>(a.in_scale + (long long)vb[0] * a.Cin + c0);
         rt[S] = *reinterpret_cast<const f32x4*>(a.in_shift + (long long)vb[0] * a.Cin + c0);
       }
 #pragma unroll
       for (int i = 0; i < WN; ++i) {
-        const bool ok = ((vmask[i] >> t_dz) & (vmask[i] >> (3 + t_dy)) & (vmask[i] >> (6 + t_dx)) & 1) != 0;
+        const bool ok = XR ? (((vmask[i] >> t_dz) & (vmask[i] >> (3 + t_dy)) & 1) != 0 && vok[i])     // the own column is always inside
+                           : (((vmask[i] >> t_dz) & (vmask[i] >> (3 + t_dy)) & (vmask[i] >> (6 + t_dx)) & 1) != 0);
         ra[S][i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? vbase[i] + toff : (long long)(seg * 4)));   // unconditional load
         rok[S] |= (ok ? 1 : 0) << i;
       }
     }
     const long long woff = (long long)t_tap * a.Cout * a.Cin + t_cc * KC;
 #pragma unroll
-    for (int i = 0; i < W_ROWS; ++i) {
-      const int row = srow + 64 * i;
-      if (row < N_T) rw[S][i] = *reinterpret_cast<const f32x4*>(a.wT + wbase[i] + woff);
-    }
+    for (int d = 0; d < XT; ++d)
+#pragma unroll
+      for (int i = 0; i < W_ROWS; ++i) {
+        const int row = srow + 64 * i;
+        if (row < N_T && d < a.KS) rw[S][d * W_ROWS + i] = *reinterpret_cast<const f32x4*>(a.wT + wbase[i] + woff + (long long)d * a.Cout * a.Cin);
+      }
     if (++t_cc == cpt) {
-      t_cc = 0; ++t_tap;
-      if (++t_dx == a.KS) { t_dx = 0; if (++t_dy == a.KS) { t_dy = 0; ++t_dz; } }
+      t_cc = 0;
+      if (XR) { t_tap += a.KS; if (++t_dy == a.KS) { t_dy = 0; ++t_dz; } }
+      else { ++t_tap; if (++t_dx == a.KS) { t_dx = 0; if (++t_dy == a.KS) { t_dy = 0; ++t_dz; } } }
     }
   };
   auto store_chunk = [&](const int S) {   // register set S -> LDS buffer S
@@ -158,13 +195,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
       f32x4 v = ra[S][i];
       if (a.in_scale) v = v * rs[S] + rt[S];
       if (!((rok[S] >> i) & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(act_lds + ((S * M_T) + srow + 64 * i) * LDS_STRIDE + seg * 4) = v;
+      *reinterpret_cast<f32x4*>(act_lds + ((S * AROWS) + srow_l[i]) * LDS_STRIDE + seg * 4) = v;
     }
 #pragma unroll
-    for (int i = 0; i < W_ROWS; ++i) {
-      const int row = srow + 64 * i;
-      if (row < N_T) *reinterpret_cast<f32x4*>(wgt_lds + ((S * N_T) + row) * LDS_STRIDE + seg * 4) = rw[S][i];
-    }
+    for (int d = 0; d < XT; ++d)
+#pragma unroll
+      for (int i = 0; i < W_ROWS; ++i) {
+        const int row = srow + 64 * i;
+        if (row < N_T && d < a.KS) *reinterpret_cast<f32x4*>(wgt_lds + (((S * XT + d) * N_T) + row) * LDS_STRIDE + seg * 4) = rw[S][d * W_ROWS + i];
+      }
   };
 
   f32x16 acc[CO_TILES][2];
@@ -176,21 +215,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
       for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
 
   auto multiply = [&](const int S) {
-    const float* ab = act_lds + (S * M_T + wn * 64 + pl) * LDS_STRIDE + 4 * hi;
-    const float* wb = wgt_lds + (S * N_T + wm * CO_TILES * 32 + pl) * LDS_STRIDE + 4 * hi;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      f32x4 bf[2], af[CO_TILES];
+    for (int d = 0; d < XT; ++d) {
+      if (d >= (XR ? a.KS : 1)) break;
+      const float* ab = act_lds + (S * AROWS + d) * LDS_STRIDE + 4 * hi;
+      const float* wb = wgt_lds + ((S * XT + d) * N_T + wm * CO_TILES * 32 + pl) * LDS_STRIDE + 4 * hi;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(ab + j * 32 * LDS_STRIDE + sub * 8);
+      for (int sub = 0; sub < 2; ++sub) {
+        f32x4 bf[2], af[CO_TILES];
 #pragma unroll
-      for (int i = 0; i < CO_TILES; ++i) af[i] = *reinterpret_cast<const f32x4*>(wb + i * 32 * LDS_STRIDE + sub * 8);
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(ab + mrow_l[j] * LDS_STRIDE + sub * 8);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int i = 0; i < CO_TILES; ++i) af[i] = *reinterpret_cast<const f32x4*>(wb + i * 32 * LDS_STRIDE + sub * 8);
 #pragma unroll
-        for (int i = 0; i < CO_TILES; ++i)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = MFMA(af[i][q], bf[j][q], acc[i][j]);
+          for (int i = 0; i < CO_TILES; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = MFMA(af[i][q], bf[j][q], acc[i][j]);
+      }
     }
   };
   load_chunk(0);
@@ -354,21 +397,42 @@ static int conv_dispatch(const ConvArgs& a, void* stream) {
   const int Cout = a.Cout;
   const long long M = (long long)a.B * a.Do * a.Ho * a.Wo;
   hipStream_t st = (hipStream_t)stream;
+  // x reuse (see the kernel): stride-1 k2 / k3 convolutions with same-size output whose 256-voxel tile is whole x-rows, for the
+  // 32- and 64-channel output tiles (the Upsampler's four layers; the 128-channel tiles amortise the staging over 4x the MFMAs and
+  // would lose their second resident workgroup to the three weight tiles)
+  const bool xr = g_sfmi_tune.conv_xreuse && a.stride == 1 && !a.up && (a.KS == 2 || a.KS == 3) && a.Wo == a.Wi && a.Ho == a.Hi &&
+                  a.Do == a.Di && 256 % a.Wo == 0 && (a.sp_on || 2 * a.pad == a.KS - 1) && Cout % 128 != 0;
+  auto lds_bytes = [&](int M_T, int N_T, bool x) {
+    const int arows = x ? (M_T / a.Wo) * (a.Wo + a.KS - 1) : M_T;
+    return (size_t)(2 * arows + 2 * (x ? 3 : 1) * N_T) * LDS_STRIDE * 4;
+  };
   if (Cout % 128 == 0) {
     constexpr int M_T = 128, N_T = 128;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, true>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
-    else hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, false>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, true>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
+    else hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, false>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
   } else if (Cout % 64 == 0) {
     constexpr int M_T = 256, N_T = 64;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, true>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
-    else hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, false>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    if (xr) {
+      static const hipError_t attr = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<2, 1, 4, false, true>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (attr != hipSuccess || lds_bytes(M_T, N_T, true) > 96 * 1024) return SFMI_ELDS;
+      hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, false, true>), grid, dim3(256), lds_bytes(M_T, N_T, true), st, a);
+    }
+    else if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, true>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
+    else hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, false>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
   } else {
     constexpr int M_T = 256, N_T = 32;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, true>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
-    else hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, false>), grid, dim3(256), 2 * (M_T + N_T) * LDS_STRIDE * 4, st, a);
+    if (xr) {
+      static const hipError_t attr = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<1, 1, 4, false, true>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (attr != hipSuccess || lds_bytes(M_T, N_T, true) > 96 * 1024) return SFMI_ELDS;
+      hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, false, true>), grid, dim3(256), lds_bytes(M_T, N_T, true), st, a);
+    }
+    else if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, true>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
+    else hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, false>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
   }
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;

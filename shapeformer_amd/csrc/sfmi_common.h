@@ -67,5 +67,8 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   dgemm_nw    : k-parts (waves) per decode-GEMM workgroup: 0 = by shape (default), 4 / 8 / 16 where the K-slice allows it
 //   dgemm_un    : cap on the k16-steps of loads in flight per wave: 0 = by shape (8 / 4 / 2 / 2 / 2 / 1 for 1 .. 6 row tiles); can only lower it
 // sfmi_tune_generation() counts successful sfmi_tune_set calls: callers that cache captured hipGraphs key them on it.
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un; };
+//   conv_xreuse : 1 (default) = stride-1 k2 / k3 convolutions with 32 / 64 output channels per tile stage each input row once per
+//                 (dz, dy) and reuse it for the taps along x; 0 = re-stage per tap (round 1-3 form).  NOT bit-identical to each other
+//                 (the taps are summed in another order: fp32 rounding only)
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse; };
 extern SfmiTune g_sfmi_tune;

@@ -197,10 +197,69 @@ def test_fused_first_downsampler_conv_equals_the_dense_grid_route(dev, res):
         s0 = float(d0_d.abs().max())
         e0 = float((d0_f - d0_d).abs().max())
         assert e0 <= 2e-6 * s0 + 1e-7, (e0, s0)
-        assert torch.equal(d0_f == 0, d0_d == 0)                  # the same voxels are empty (ReLU zeros included)
+        assert bool((d0_f[(d0_d == 0).all(-1)] == 0).all())       # parents without points are exactly zero in both routes
         scale = float(lat_d.abs().max())
         e = float((lat_f - lat_d).abs().max())
         assert e <= 2e-5 * scale + 1e-5, (e, scale)
         nbad = int((idx_f != idx_d).sum())
         assert nbad <= 2, nbad
         print(f"res{res}: fused vs dense first conv {e0:.2e} (scale {s0:.2f}), latent {e:.2e} (scale {scale:.1f}), index mismatches {nbad}")
+
+
+def test_conv_x_reuse_form_and_subpixel_upsampling_conv_vs_torch(dev):
+    """The Upsampler's convolutions (updown.py:119-132) on the `x reuse` form of csrc/conv3d.hip (one staging of the input rows per
+    (dz, dy), the taps along x read it at LDS row offsets; 32 / 64 output channels per tile) against torch CPU fp32:
+    direct k3 p1 convolutions whose 256-voxel tile is whole x-rows (Wo = 4 .. 64: tiles inside one shape AND tiles that straddle
+    shapes, with the fused per-(shape, channel) input affine, bias, ReLU), and conv3(nearest_x2(x)) as 8 parity-wise 2^3
+    convolutions with per-axis leading pads (sfmi_conv3d_up2_cl_f32).  The same launches with conv_xreuse = 0 (the round 1-3 form)
+    must agree with them to summation-order rounding."""
+    import torch.nn.functional as F
+    from shapeformer_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    assert lib.sfmi_tune_get(b"conv_xreuse") == 1
+
+    def run(fn):
+        outs = []
+        for knob in (1, 0):
+            L.check(lib.sfmi_tune_set(b"conv_xreuse", knob), "tune")
+            try:
+                outs.append(fn().clone())
+            finally:
+                L.check(lib.sfmi_tune_set(b"conv_xreuse", 1), "tune")
+        return outs
+    for (Cin, Cout, D, B) in [(32, 32, 16, 2), (64, 64, 8, 3), (32, 64, 4, 5), (16, 32, 64, 1), (64, 32, 32, 1)]:
+        x = torch.randn(B, Cin, D, D, D, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5
+        bias = torch.randn(Cout, generator=g)
+        sc, sh = torch.rand(B, Cin, generator=g) + 0.5, torch.randn(B, Cin, generator=g)
+        xin = x * sc[:, :, None, None, None] + sh[:, :, None, None, None]
+        ref = F.relu(F.conv3d(xin, w, bias, stride=1, padding=1))
+        wp = np.empty(w.numel(), np.float32)
+        L.check(lib.sfmi_conv_pack_weight(w.numpy().ctypes.data, Cout, Cin, 3, wp.ctypes.data), "pack")
+        xd = x.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+        y = torch.empty(B, D, D, D, Cout, device=dev)
+        wd, bd, scd, shd = torch.from_numpy(wp).to(dev), bias.to(dev), sc.to(dev), sh.to(dev)
+
+        def direct():
+            L.check(lib.sfmi_conv3d_cl_f32(L.ptr(xd), L.ptr(wd), L.ptr(scd), L.ptr(shd), L.ptr(bd), L.ptr(y), B, D, D, D, Cin, Cout, 3, 1, 1, 0, 1,
+                                           L.stream_ptr()), "conv")
+            return y
+        yx, y0 = run(direct)
+        torch.testing.assert_close(yx.cpu().permute(0, 4, 1, 2, 3), ref, atol=2e-4, rtol=1e-4)
+        torch.testing.assert_close(yx, y0, atol=2e-5, rtol=1e-5)
+        # the up-sampling convolution of the same tensors: conv3(nearest_x2(affine(x))) by the sub-pixel decomposition
+        if D <= 16:
+            refu = F.relu(F.conv3d(F.interpolate(xin, scale_factor=2, mode="nearest"), w, bias, stride=1, padding=1))
+            ws = np.empty(64 * Cout * Cin, np.float32)
+            L.check(lib.sfmi_conv_pack_weight_subpixel(np.ascontiguousarray(w.numpy()).ctypes.data, Cout, Cin, ws.ctypes.data), "pack_subpixel")
+            wsd = torch.from_numpy(ws).to(dev)
+            yu = torch.empty(B, 2 * D, 2 * D, 2 * D, Cout, device=dev)
+
+            def up2():
+                L.check(lib.sfmi_conv3d_up2_cl_f32(L.ptr(xd), L.ptr(wsd), L.ptr(scd), L.ptr(shd), L.ptr(bd), L.ptr(yu), B, D, D, D, Cin, Cout, 1,
+                                                   L.stream_ptr()), "conv_up2")
+                return yu
+            ux, u0 = run(up2)
+            torch.testing.assert_close(ux.cpu().permute(0, 4, 1, 2, 3), refu, atol=3e-4, rtol=1e-4)
+            torch.testing.assert_close(ux, u0, atol=2e-5, rtol=1e-5)
