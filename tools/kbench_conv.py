@@ -9,7 +9,10 @@ from shapeformer_amd.vqdif import VQDIF
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--xreuse", type=int, default=1, help="conv_xreuse knob (csrc/conv3d.hip): 1 = stage once per (dz,dy), 0 = the round 1-3 form")
 a = ap.parse_args()
+from shapeformer_amd import _lib as L
+L.check(L.lib().sfmi_tune_set(b"conv_xreuse", a.xreuse), "tune")
 dev = torch.device("cuda:0")
 vq = VQDIF(res=16, device=dev)
 code = vq.get_code_cl(torch.randint(0, vq.K, (a.batch, 16, 16, 16), device=dev)).clone()
@@ -46,4 +49,4 @@ for k, v in rec.items():
     tot += ms
     fl = v[-1][2]
     print(f"{k:60s} {ms:8.3f} ms" + (f"  {fl / ms / 1e9:7.1f} TFLOP/s  ({fl / 1e9 / a.batch:6.2f} GF/shape)" if fl else ""))
-print(f"total {tot:.2f} ms for {a.batch} shapes")
+print(f"total {tot:.2f} ms for {a.batch} shapes (conv_xreuse={a.xreuse})")
