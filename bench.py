@@ -691,6 +691,20 @@ def main():
                     step(a.warmup + a.steps + 1, timings=t2)
                     split[fam] = t2["ar_loop"] / a.ar_steps
                 gpt._ablate = ""
+                # the attention turnstile (a device-side FIFO gate in front of every attention launch) has to keep earning its place:
+                # the same loop with the gate off, in the same run on the same box
+                if gpt.ATTN_LANES > 0 and (a.micro or default_chains(B)) > gpt.ATTN_LANES:
+                    lanes_on = gpt.ATTN_LANES
+                    ab = {}
+                    for nm, ln in (("off", 0), (f"lanes{lanes_on}", lanes_on)):
+                        gpt.ATTN_LANES = ln
+                        step(a.warmup + a.steps + 2)           # re-captures the chains' graphs with / without the gate
+                        t3 = {}
+                        step(a.warmup + a.steps + 3, timings=t3)
+                        ab[nm] = round(t3["ar_loop"] / a.ar_steps, 3)
+                    gpt.ATTN_LANES = lanes_on
+                    ab["timeouts"] = int(gpt._sem.cpu().tolist()[2])
+                    line["turnstile"]["ab_ms_per_step"] = ab
                 flops_step = 2.0 * B * (w_one / 4.0)
                 line["ar_loop"]["attention_only_ms_per_step"] = round(split["gemm"], 3)
                 line["ar_loop"]["attention_only_KV_TBps"] = round(kv_bytes / split["gemm"] / 1e9, 3)

@@ -240,10 +240,17 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
         for (int t = 0; t < 16; ++t) { const int u = __shfl_up(key[t], 1 << k, 32); if (same[k]) key[t] = max(key[t], u); }
       if (valid && run_last) {
         int* sm = segmax_out + seg * 32 + 4 * hi;
+        if (pl < 31 && seg >= tile * 32) {
+          // the run starts AND ends inside this tile: no other wave ever touches its segment, the pooled maxima are final -
+          // four 16-byte stores instead of sixteen atomics on one cache line (most runs: a cell holds ~5 points)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<int4*>(sm + 8 * g) = int4{key[4 * g], key[4 * g + 1], key[4 * g + 2], key[4 * g + 3]};
+        } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) atomicMax(sm + 8 * g + j, key[4 * g + j]);
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicMax(sm + 8 * g + j, key[4 * g + j]);
+        }
       }
     } else {
       // c = fc_c(net) (enc.py:133) -> fixed-point accumulate for the per-cell mean (enc.py:70-74)
@@ -275,11 +282,19 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
       }
       if (valid && run_last) {
         long long* sp = csum + seg * 32 + 4 * hi;
+        if (pl < 31 && seg >= tile * 32) {      // run wholly inside the tile (see the max pool above): plain stores into the zeroed sums
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(sp + 8 * g + j), (unsigned long long)q[4 * g + j]);
-        if (hi == 0) atomicAdd(ccount + seg, n);
+            for (int j = 0; j < 4; j += 2) *reinterpret_cast<longlong2*>(sp + 8 * g + j) = longlong2{q[4 * g + j], q[4 * g + j + 1]};
+          if (hi == 0) ccount[seg] = n;
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(sp + 8 * g + j), (unsigned long long)q[4 * g + j]);
+          if (hi == 0) atomicAdd(ccount + seg, n);
+        }
       }
     }
   }
@@ -329,27 +344,37 @@ __global__ __launch_bounds__(256) void enc_down0_sparse_kernel(const int* __rest
     const unsigned bits = (unsigned)((occ[0] >> (2 * xo)) & 3) | (unsigned)(((occ[1] >> (2 * xo)) & 3) << 2) |
                           (unsigned)(((occ[2] >> (2 * xo)) & 3) << 4) | (unsigned)(((occ[3] >> (2 * xo)) & 3) << 6);
     if (bits) {                                   // wave-uniform: most parents have no occupied child
+      // the sums of ALL occupied children are requested first (independent loads: one round trip), then multiplied
+      float mean[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          if (!((bits >> (2 * r + dx)) & 1)) continue;
+      for (int c = 0; c < 8; ++c) {
+        const int r = c >> 1, dx = c & 1;
+        mean[c] = 0.f;
+        if ((bits >> c) & 1) {
           const int s0 = __shfl(st[r], 2 * xo + dx, 64);
           const long long seg = (long long)b * T + s0;             // sorted position of the cell's first point names its sums
           // cell mean of channel (lane & 31), formed as enc_grid_mean_kernel does
           const double sm = (double)csum[seg * 32 + (lane & 31)] * (1.0 / 4294967296.0);
-          const float mean = (float)(sm / (double)ccount[seg]);
-          const int tap = ((r >> 1) * 2 + (r & 1)) * 2 + dx;        // (dz, dy, dx), the conv kernel's tap order
-          const f32x4* wp = reinterpret_cast<const f32x4*>(w + ((long long)tap * 64 + lane) * 32);
-#pragma unroll
-          for (int k4 = 0; k4 < 8; ++k4) {
-            const f32x4 wv = wp[k4];
-            acc = fmaf(wv[0], __shfl(mean, 4 * k4 + 0, 64), acc);
-            acc = fmaf(wv[1], __shfl(mean, 4 * k4 + 1, 64), acc);
-            acc = fmaf(wv[2], __shfl(mean, 4 * k4 + 2, 64), acc);
-            acc = fmaf(wv[3], __shfl(mean, 4 * k4 + 3, 64), acc);
-          }
+          mean[c] = (float)(sm / (double)ccount[seg]);
         }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (!((bits >> c) & 1)) continue;
+        const int r = c >> 1, dx = c & 1;
+        const int tap = ((r >> 1) * 2 + (r & 1)) * 2 + dx;        // (dz, dy, dx), the conv kernel's tap order
+        const f32x4* wp = reinterpret_cast<const f32x4*>(w + ((long long)tap * 64 + lane) * 32);
+        f32x4 wv[8];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) wv[k4] = wp[k4];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+          acc = fmaf(wv[k4][0], __shfl(mean[c], 4 * k4 + 0, 64), acc);
+          acc = fmaf(wv[k4][1], __shfl(mean[c], 4 * k4 + 1, 64), acc);
+          acc = fmaf(wv[k4][2], __shfl(mean[c], 4 * k4 + 2, 64), acc);
+          acc = fmaf(wv[k4][3], __shfl(mean[c], 4 * k4 + 3, 64), acc);
+        }
+      }
     }
     yrow[(long long)xo * 64 + lane] = relu ? fmaxf(acc, 0.f) : acc;
   }

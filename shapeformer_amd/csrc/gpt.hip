@@ -490,7 +490,7 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
       const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
       if (i == t && cok) kf[u] = *reinterpret_cast<const f32x4*>(s.kn + 4 * c4);     // the new token's key comes from LDS
       float d = (qf[0] * kf[u][0] + qf[1] * kf[u][1]) + (qf[2] * kf[u][2] + qf[3] * kf[u][3]);
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+      d = row16_sum(d);      // over the 16 lanes that share the key (DPP: no LDS round trips)
       if (i <= t) {
         if (c4 == 0) s.sc[i] = d;
         lmax = fmaxf(lmax, d);
@@ -694,8 +694,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
         if (key > qrow || key >= n) sacc[t][j] = -INFINITY;
         mx = fmaxf(mx, sacc[t][j]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+      mx = row16_max(mx);
       const float mnew = fmaxf(mrun[j], mx);
       const float ms = mnew == -INFINITY ? 0.f : mnew;        // fully masked so far: keep everything at zero
       corr[j] = __expf(mrun[j] - ms);
@@ -709,7 +708,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
           p *= sfmi_dropout_mul(drop_seed, (unsigned)(((b * gridDim.y + h) * P + qrow) * P + k0 + 16 * t + lr), drop_p, 1.0f / (1.0f - drop_p));
         Pw[(4 * lq + j) * AP_PS + 16 * t + lr] = p;
       }
-      ps += __shfl_xor(ps, 1, 64); ps += __shfl_xor(ps, 2, 64); ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64);
+      ps = row16_sum(ps);
       lrun[j] = lrun[j] * corr[j] + ps;
       mrun[j] = mnew;
     }

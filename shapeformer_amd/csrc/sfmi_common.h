@@ -30,6 +30,29 @@ __device__ __forceinline__ float sfmi_normalize(float p) {
   return u;
 }
 
+// Sum / max over each aligned group of 16 lanes (a DPP "row"), result in every lane of the group: the xor-1 / 2 / 4 / 8 butterfly with
+// the exchanges done by DPP operand modifiers (quad_perm, row_half_mirror, row_mirror) inside the adds instead of four ds_bpermute
+// round trips through the LDS crossbar.  Bit-identical to the __shfl_xor butterfly: after the quad steps all four lanes of a quad hold
+// the same value, so "the lane 7-i / 15-i away" and "the lane i^4 / i^8 away" deliver the same addend, and a + b == b + a.
+__device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
+  // ctrl_sel: 0 quad_perm[1,0,3,2], 1 quad_perm[2,3,0,1], 2 row_half_mirror, 3 row_mirror (compile-time constants below)
+  int r;
+  const int x = __float_as_int(v);
+  if (ctrl_sel == 0) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);
+  else if (ctrl_sel == 1) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);
+  else if (ctrl_sel == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false);
+  else r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false);
+  return __int_as_float(r);
+}
+__device__ __forceinline__ float row16_sum(float d) {
+  d += dpp_f(d, 0); d += dpp_f(d, 1); d += dpp_f(d, 2); d += dpp_f(d, 3);
+  return d;
+}
+__device__ __forceinline__ float row16_max(float d) {
+  d = fmaxf(d, dpp_f(d, 0)); d = fmaxf(d, dpp_f(d, 1)); d = fmaxf(d, dpp_f(d, 2)); d = fmaxf(d, dpp_f(d, 3));
+  return d;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
