@@ -24,7 +24,7 @@ int sfmi_tune_set(const char* name, int value) {
   else if (n == "attn_waves" && (value == 8 || value == 16)) t.attn_waves = value;
   else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) t.attn_lds_pad = value;
   else if (n == "sdf_blocks" && value >= 1 && value <= 512) t.sdf_blocks = value;
-  else if (n == "dgemm_nt2" && ((value >= 0 && value <= 2) || value == 4)) t.dgemm_nt2 = value;
+  else if (n == "dgemm_nt2" && value >= 0 && value <= 2) t.dgemm_nt2 = value;
   else if (n == "dgemm_nw" && (value == 0 || value == 4 || value == 8 || value == 16)) t.dgemm_nw = value;
   else if (n == "dgemm_un" && value >= 0 && value <= 8) t.dgemm_un = value;
   else if (n == "conv_xreuse" && (value == 0 || value == 1)) t.conv_xreuse = value;

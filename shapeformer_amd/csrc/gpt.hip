@@ -207,17 +207,13 @@ struct DgProduct {
   static __device__ __forceinline__ int xidx(int i) { return i; }
   static __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
-template <int MT, int NW, int UN, int NT = 1, class P = DgProduct, int CH = 2>
-__global__ __launch_bounds__(64 * NW, NT == 4 ? 4 : 1) void dgemm_kernel(DGemmArgs a) {   // NT = 4: two resident workgroups (<= 128 VGPRs)
+template <int MT, int NW, int UN, int NT = 1, class P = DgProduct>
+__global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   // NT n-tiles per wave (NT = 2: an activation fragment feeds two weight tiles - 5 operand loads per 24 MFMAs instead of 7 for the
   // same 6 accumulator tiles - and the 96-row launch becomes two row groups of MT = 3, whose batch of two k16-steps fits 128 VGPRs,
   // which the 6-row-tile instance does not).  VT = MT * NT "virtual tiles" (row tile j, column tile nn) per wave.
-  // CH accumulator chains per tile (2: even / odd k4-steps, hides the dependent-MFMA latency of a wave with few tiles; 1: a wave with
-  // >= 6 tiles has enough independent accumulators, and the registers go to more tiles).  PT tiles go through the cross-wave
-  // reduction buffer per epilogue phase (more than 8 tiles: two phases, so that the buffer stays at 48 KB).
   constexpr int VT = MT * NT;
-  constexpr int PT = VT <= 8 ? VT : (VT + 1) / 2;
-  __shared__ __attribute__((aligned(16))) float red[NW][PT][4][64];
+  __shared__ __attribute__((aligned(16))) float red[NW][VT][4][64];
   __shared__ float st1[NW][MT][16], st2[NW][MT][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, ml = lane & 15;
   const int sp = blockIdx.y, S = gridDim.y;
@@ -243,15 +239,13 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? 4 : 1) void dgemm_kernel(DGemmAr
 #pragma unroll
   for (int j = 0; j < MT; ++j) xr[j] = reinterpret_cast<const f32x4*>(a.x) + ((long long)(t0 + j) * (a.K / 16) + k0 / 16) * 64;
   const unsigned lo = (unsigned)lane;
-  f32x4 acc[MT][NT][CH];
+  f32x4 acc[MT][NT][2];
   float s1[MT], s2[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     s1[j] = 0.f; s2[j] = 0.f;
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn)
-#pragma unroll
-      for (int c = 0; c < CH; ++c) acc[j][nn][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nn = 0; nn < NT; ++nn) { acc[j][nn][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][nn][1] = acc[j][nn][0]; }
   }
   // epilogue operands are fetched NOW (wave v owns virtual tile v) so that no dependent global round trip is left
   // after the weight stream: the memory system is saturated by then and a late load costs ~1.5 us.
@@ -260,8 +254,7 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? 4 : 1) void dgemm_kernel(DGemmAr
   const int n_ep = ent * 16 + 4 * q;
   const long long off_ep = a.out_packed ? (((long long)(t0 + ej) * (a.N >> 4) + ent) * 64 + lane) * 4
                                         : (long long)min((t0 + ej) * 16 + ml, a.M - 1) * a.ldo + n_ep;
-  constexpr bool PRE = NT < 4;   // the four-tile form has no registers to spare for the prefetched epilogue operands
-  if (PRE && wave < VT && ent < ntiles && n_ep < a.N) {
+  if (wave < VT && ent < ntiles && n_ep < a.N) {
     if (a.ln) pc1 = *reinterpret_cast<const f32x4*>(a.c1 + n_ep);
     if (a.c2) pc2 = *reinterpret_cast<const f32x4*>(a.c2 + n_ep);
     if (a.resid) pres = *reinterpret_cast<const f32x4*>(a.resid + off_ep);
@@ -282,8 +275,8 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? 4 : 1) void dgemm_kernel(DGemmAr
 #pragma unroll
       for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)   // CH = 2: two independent accumulator chains hide the 40-cycle dependent latency
-          acc[j][nn][e & (CH - 1)] = P::mfma(wv[nn][e], xv[e], acc[j][nn][e & (CH - 1)]);
+        for (int e = 0; e < 4; ++e)   // two independent accumulator chains hide the 40-cycle dependent latency
+          acc[j][nn][e & 1] = P::mfma(wv[nn][e], xv[e], acc[j][nn][e & 1]);
     }
   };
   // batches of UN k16-steps: UN*NT weight + UN*MT activation loads in flight, all pinned ahead of the MFMAs
@@ -307,43 +300,35 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? 4 : 1) void dgemm_kernel(DGemmAr
   if (P::kSkipEpilogue) {   // ablation policies only: main loop alone (one store per lane keeps the accumulators alive)
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < MT; ++j) t = t + acc[j][0][0] + acc[j][0][CH - 1];
+    for (int j = 0; j < MT; ++j) t = t + acc[j][0][0] + acc[j][0][1];
     if (t[0] == 1.2345f) a.out[tid] = t[1] + s1[0] + s2[0] + pc1[0] + pc2[0] + pres[0];
     return;
   }
-  if (a.ln) {
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
+  for (int j = 0; j < MT; ++j) {
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+      const f32x4 t = acc[j][nn][0] + acc[j][nn][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][j * NT + nn][r][lane] = t[r];
+    }
+    if (a.ln) {
       float t1 = s1[j], t2 = s2[j];
       t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
       t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
       if (q == 0) { st1[wave][j][ml] = t1; st2[wave][j][ml] = t2; }
     }
   }
-  // epilogue, PT tiles per phase: every wave hands its partial tiles to LDS, then wave w finishes the tiles p0 + w, p0 + w + NW, ...
-#pragma unroll
-  for (int p0 = 0; p0 < VT; p0 += PT) {
-  if (p0) __syncthreads();               // the previous phase's readers are done with the buffer
-#pragma unroll
-  for (int j = 0; j < MT; ++j)
-#pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
-      const int vq = j * NT + nn;
-      if (vq < p0 || vq >= p0 + PT) continue;
-      f32x4 t = acc[j][nn][0];
-      if (CH == 2) t = t + acc[j][nn][CH - 1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][vq - p0][r][lane] = t[r];
-    }
   __syncthreads();
-  for (int v = p0 + wave; v < VT && v < p0 + PT; v += NW) {
+  // epilogue: wave w finishes the virtual tiles v = w, w+NW, ...
+  for (int v = wave; v < VT; v += NW) {
     const int j = v / NT, nt = nt0 + v % NT;
-    if (nt >= ntiles) continue;          // masked tiles of a tile count that NT does not divide (wave-uniform)
+    if (nt >= ntiles) continue;          // masked second tile of an odd tile count (wave-uniform)
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] += red[w][v - p0][e][lane];
+      for (int e = 0; e < 4; ++e) r[e] += red[w][v][e][lane];
     float t1 = 0.f, t2 = 0.f;
     if (a.ln) {
 #pragma unroll
@@ -389,7 +374,7 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? 4 : 1) void dgemm_kernel(DGemmAr
       // the operands fetched ahead belong to this wave's FIRST virtual tile; later ones (VT > NW only) are fetched here
       f32x4 qc1 = pc1, qc2 = pc2, qres = pres;
       const long long off = a.out_packed ? (((long long)(t0 + j) * (a.N >> 4) + nt) * 64 + lane) * 4 : (long long)m * a.ldo + n;
-      if (!PRE || v != wave) {
+      if (v != wave) {
         qc1 = a.ln ? *reinterpret_cast<const f32x4*>(a.c1 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         qc2 = a.c2 ? *reinterpret_cast<const f32x4*>(a.c2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         qres = a.resid ? *reinterpret_cast<const f32x4*>(a.resid + off) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -409,7 +394,6 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? 4 : 1) void dgemm_kernel(DGemmAr
       *reinterpret_cast<f32x4*>(a.out + off) = r;
     }
   }
-  }   // epilogue phases
   if (a.prof && tid == 0 &&
       __hip_atomic_fetch_add(a.pblk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y * gridDim.z) - 1) {
     __hip_atomic_store(a.pblk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1144,16 +1128,6 @@ static int decode_gemm_launch(const float* x, const float* Wp16, const float* c1
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
   a.out_packed = out_packed; a.slab = slab; a.cnt = cnt; a.pblk = pblk; a.prof = prof;
   hipStream_t st = (hipStream_t)stream;
-  if (g_tune.dgemm_nt2 == 4 && tiles % 3 == 0 && NWv == 8 && (kslice / 8 / 16) % 2 == 0) {
-    // EXPERIMENT (round 4): four n-tiles per wave on ONE accumulator chain per tile - 7 operand loads per 48 MFMAs (10 in the two-tile
-    // form) with the same 48 accumulator registers; 12 tiles per wave go through the reduction buffer in two phases.  Not bit-identical
-    // to the two-chain forms (k4-steps are summed in one chain instead of two).
-    const int g2 = tiles / 3;
-    dim3 grid4(((N + 15) / 16 + 3) / 4, S, g2);
-    hipLaunchKernelGGL((dgemm_kernel<3, 8, 2, 4, P, 1>), grid4, dim3(512), 0, st, a);
-    SFMI_CHECK_LAUNCH();
-    return SFMI_OK;
-  }
   if ((g_tune.dgemm_nt2 == 2 || (g_tune.dgemm_nt2 == 1 && tiles % 3 == 0)) && NWv == 8 && (kslice / 8 / 16) % 2 == 0 && tiles >= 3) {
     // two n-tiles per wave, row groups of <= 3 row tiles, batches of two k16-steps: 5 operand loads per 24 MFMAs (7 in the one-tile
     // form) with the same 6 accumulator tiles per wave; same per-element arithmetic (k ascending, two chains): bit-identical.
