@@ -168,3 +168,17 @@ def test_bench_rccl_path_with_one_rank(dev):
     line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1 and line[0]["n_gpus"] == 1 and line[0]["unit"] == "tokens/s" and np.isfinite(line[0]["loss_last"])
     assert line[0]["allreduce_wait_ms"] is not None, "the RCCL bucket path did not run"
+    # north_star's gradient path on RCCL: in-place reduce_scatter_tensor / all_gather_into_tensor per bucket (one-rank group: the
+    # collectives, their stream ordering and the sharded AdamW + unflatten launches are the real ones)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--mode", "train",
+                        "--steps", "2", "--warmup", "1", "--train-lc", "24", "--train-lz", "40", "--grad-sync", "rs_ag"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    l2 = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(l2) == 1 and l2[0]["config"]["grad_sync_mode"] == "rs_ag" and l2[0]["param_allgather_wait_ms"] is not None
+    # same data, same seeds, one rank: the sharded update (shard = everything) must reproduce the ring mode's loss trajectory
+    assert abs(l2[0]["loss_last"] - line[0]["loss_last"]) < 1e-6 and abs(l2[0]["loss_first"] - line[0]["loss_first"]) < 1e-6
