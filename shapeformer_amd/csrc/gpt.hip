@@ -598,6 +598,12 @@ __global__ __launch_bounds__(64) void attn_gate_kernel(int* sem, int lanes) {
 //   O (16 x 64) += P V     : P goes through a per-wave LDS tile to become an A operand; 4 d tiles x 16 k-steps
 // LDS row strides 68 (K, P: 16 rows x 4 k-columns per operand read hit 64 distinct banks) and 80 (V: 4 rows x 16 columns).
 // ------------------------------------------------------------------------------------------------
+// Operand-order LDS rows (round 4): inside a row the elements are PERMUTED so that what one lane feeds to consecutive MFMAs is
+// contiguous and comes in with ds_read_b128 instead of four ds_read_b32 (144 -> 36 LDS read instructions per 64-key block and wave):
+//   K row (one key):   dim d   at (d % 4) * KK + d / 4       (lane lq reads its KK k-steps 4 kk + lq in a row)
+//   V row (one key):   dim d   at (d % 16) * DT + d / 16     (lane lr reads its DT output tiles 16 dt + lr in a row)
+//   P row (one query): key k   at (k % 4) * 16 + k / 4       (lane lq reads its 16 k-steps 4 kk + lq in a row)
+// The MFMA operands and their order are those of the linear layout: results are bit-identical.
 constexpr int AP_PS = 68;   // P tile row stride (16 rows x 64 keys)
 template <int HD>           // head dim 16 / 32 / 64
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
@@ -655,8 +661,11 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
       const int i = tid + it * 256;
       const int r = i / KK, c = i % KK;
       if (i < 64 * KK) {
-        *reinterpret_cast<f32x4*>(&Ks[r * AP_KS + 4 * c]) = kreg[it];
-        *reinterpret_cast<f32x4*>(&Vs[r * AP_VS + 4 * c]) = vreg[it];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {       // dims 4c .. 4c+3 of key row r, scattered into operand order
+          Ks[r * AP_KS + e * KK + c] = kreg[it][e];
+          Vs[r * AP_VS + ((4 * c + e) & 15) * DT + (c >> 2)] = vreg[it][e];
+        }
         if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
           const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * HD + 4 * c;  // (B,H,Lmax,HD)
           *reinterpret_cast<f32x4*>(Kc + co) = kreg[it];
@@ -677,9 +686,13 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     for (int t = 0; t < 4; ++t) {
       sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t > tmax) continue;
-      const float* kp = &Ks[(16 * t + lr) * AP_KS + lq];
+      const f32x4* kp = reinterpret_cast<const f32x4*>(&Ks[(16 * t + lr) * AP_KS + lq * KK]);
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kk], kp[4 * kk], sacc[t], 0, 0, 0);
+      for (int k4 = 0; k4 < KK / 4; ++k4) {
+        const f32x4 kv = kp[k4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[4 * k4 + e], kv[e], sacc[t], 0, 0, 0);
+      }
     }
     // causal / length mask, online softmax per row (row of register j: q0 + 16 wave + 4 lq + j)
     float corr[4];
@@ -706,7 +719,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
         ps += p;                       // the softmax denominator is the undropped sum (att = softmax; att = attn_drop(att))
         if (drop_p > 0.f)              // training: element (b, h, query, key) of the (B,H,P,P) attention-probability tensor
           p *= sfmi_dropout_mul(drop_seed, (unsigned)(((b * gridDim.y + h) * P + qrow) * P + k0 + 16 * t + lr), drop_p, 1.0f / (1.0f - drop_p));
-        Pw[(4 * lq + j) * AP_PS + 16 * t + lr] = p;
+        Pw[(4 * lq + j) * AP_PS + (lr & 3) * 16 + 4 * t + (lr >> 2)] = p;     // key 16 t + lr in operand order
       }
       ps = row16_sum(ps);
       lrun[j] = lrun[j] * corr[j] + ps;
@@ -718,17 +731,23 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
       for (int j = 0; j < 4; ++j) o[dt][j] *= corr[j];
     __builtin_amdgcn_wave_barrier();   // P tile written and read by this wave only; LDS ops of a wave execute in order
     // O += P V over the keys of the tiles in use
-    const float* pp = &Pw[lr * AP_PS + lq];
+    const f32x4* pp = reinterpret_cast<const f32x4*>(&Pw[lr * AP_PS + lq * 16]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (t > tmax) continue;
+      const f32x4 pa = pp[t];               // P[query lr][keys 4 (4t + k4) + lq], k4 = 0..3
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
         const int kk = 4 * t + k4;
-        const float pa = pp[4 * kk];
-        const float* vp = &Vs[(4 * kk + lq) * AP_VS + lr];
+        const float* vp = &Vs[(4 * kk + lq) * AP_VS + lr * DT];
+        float vv[DT];
+        if (DT == 4) { const f32x4 v4 = *reinterpret_cast<const f32x4*>(vp); vv[0] = v4[0]; vv[1] = v4[1]; vv[DT > 2 ? 2 : 0] = v4[2]; vv[DT > 3 ? 3 : 0] = v4[3]; }
+        else {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vp[16 * dt], o[dt], 0, 0, 0);
+          for (int dt = 0; dt < DT; ++dt) vv[dt] = vp[dt];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k4], vv[dt], o[dt], 0, 0, 0);
       }
     }
   }
