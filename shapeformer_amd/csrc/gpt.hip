@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64) void attn_gate_kernel(int* sem, int lanes) {
 //   S (16 x 64)  = Q K^T   : 4 key tiles x 16 k-steps of v_mfma_f32_16x16x4_f32, Q fragments live in 16 registers
 //   online softmax on the C/D layout (row 4(l>>4)+j lives in register j of lanes with the same l>>4: 16-lane reductions)
 //   O (16 x 64) += P V     : P goes through a per-wave LDS tile to become an A operand; 4 d tiles x 16 k-steps
-// LDS row strides 68 (K, P: 16 rows x 4 k-columns per operand read hit 64 distinct banks) and 80 (V: 4 rows x 16 columns).
+// LDS row strides HD + 4 (K, V) and 68 (P), rows in operand order (below).
 // ------------------------------------------------------------------------------------------------
 // Operand-order LDS rows (round 4): inside a row the elements are PERMUTED so that what one lane feeds to consecutive MFMAs is
 // contiguous and comes in with ds_read_b128 instead of four ds_read_b32 (144 -> 36 LDS read instructions per 64-key block and wave):
@@ -610,7 +610,9 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
                                                                 float* __restrict__ Vc, const int* __restrict__ nval,
                                                                 float* __restrict__ y, int P, int D, int Lmax, float scale,
                                                                 const int* __restrict__ rowoff, float drop_p, unsigned drop_seed) {
-  constexpr int AP_KS = HD + 4, AP_VS = HD + 16, KK = HD / 4, DT = HD / 16;
+  // row strides HD + 4: 16-byte aligned rows whose ds_read_b128 of 16 consecutive rows hit distinct banks; 51 KB of LDS per workgroup
+  // at HD = 64 -> three resident workgroups per CU (a workgroup walks only 1-4 key blocks: its prologue latency needs company)
+  constexpr int AP_KS = HD + 4, AP_VS = HD + 4, KK = HD / 4, DT = HD / 16;
   __shared__ __attribute__((aligned(16))) float Ks[64 * AP_KS], Vs[64 * AP_VS], Ps[4][16 * AP_PS];
   const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = min(P, max(nval[b], 0));
