@@ -25,11 +25,7 @@
 namespace {
 
 constexpr int SG_BM = 128, SG_BN = 128, SG_KC = 32;
-#ifndef SG_GM_OVERRIDE
 constexpr int SG_GM = 8;                // M-tiles per panel of the block order
-#else
-constexpr int SG_GM = SG_GM_OVERRIDE;
-#endif
 constexpr int SG_KS = SG_KC + 4;      // row stride of a K-contiguous LDS tile
 constexpr int SG_RS = SG_BM + 4;      // row stride of a row-contiguous LDS tile ([k][rows])
 constexpr int SG_TILE = 128 * 36;     // floats per operand tile in either orientation (32 * 132 = 4224 <= 4608)
@@ -74,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(SgemmArgs a) {
   f32x4 ra[2][4], rb[2][4];      // two prefetch sets: the loads of chunk c+2 are issued while chunk c computes
   // Per-thread source pointers are fixed for the whole K loop (rows are clamped: their results are masked in the epilogue); a
   // chunk that lies fully inside K - every chunk but possibly the last - loads with no per-element condition (wave-uniform
-  // branch), the tail chunk zero-fills k >= K.  (Per-load guards cost ~10 % of the kernel: tools/ubench/sgemm_abl.hip.)
+  // branch), the tail chunk zero-fills k >= K.  (Per-load guards cost ~10 % of the kernel: round-2 ablation, profiles/r02_decode_step_experiments.md section 3.)
   const float* pa[4];
   const float* pb[4];
   int ka[4], kb[4];      // k offset of the element inside a chunk
@@ -164,26 +160,14 @@ __global__ __launch_bounds__(256, 2) void sgemm_mfma_kernel(SgemmArgs a) {
   load_chunk(ra[0], rb[0], c_lo * SG_KC);
   if (nchunks > 1) load_chunk(ra[1], rb[1], (c_lo + 1) * SG_KC);
   for (int c = 0; c < nchunks; c += 2) {
-#ifndef SG_ABL_NOSTORE     // ablation hooks of tools/ubench/sgemm_abl.hip
     store_chunk(ra[0], rb[0], 0);
-#endif
-#ifndef SG_ABL_NOBARRIER
     __syncthreads();
-#endif
-#ifndef SG_ABL_NOLOAD
     if (c + 2 < nchunks) load_chunk(ra[0], rb[0], (c_lo + c + 2) * SG_KC);
-#endif
     compute(0);
     if (c + 1 < nchunks) {
-#ifndef SG_ABL_NOSTORE
       store_chunk(ra[1], rb[1], 1);
-#endif
-#ifndef SG_ABL_NOBARRIER
       __syncthreads();
-#endif
-#ifndef SG_ABL_NOLOAD
       if (c + 3 < nchunks) load_chunk(ra[1], rb[1], (c_lo + c + 3) * SG_KC);
-#endif
       compute(1);
     }
   }
