@@ -337,6 +337,41 @@ def test_more_rows_than_the_chains_hold_run_as_rounds(dev):
         assert torch.equal(h["samples"][r], seq[r, int(Lc[r]):int(Lc[r]) + steps].long())
 
 
+def test_rounds_that_stop_early_are_padded_like_a_single_run(dev):
+    """Early exit (shapeformer.py:110-115: the loop stops once EVERY row has drawn an end token) with more rows than one round of
+    chains holds: the rounds stop independently, a single run would have kept stepping the rows that ended first - which can only
+    draw (end, end) pairs with log-probability 0 from then on.  The merged result of three rounds must equal the single run's:
+    same step count, same tokens (the end-token padding included), same lengths and log-probs."""
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    kw = dict(n_embd=128, n_layers=(2, 1), block_size=400)
+    g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=400, device=dev)
+    rs = np.random.RandomState(18)
+    B = 80
+    Lc = rs.randint(6, 20, B).astype(np.int32)
+    tok = np.full((B, 32, 2), 4096, np.int32)
+    for b in range(B):
+        tok[b, :Lc[b] - 1, 0] = np.sort(rs.choice(2048, Lc[b] - 1, replace=False)); tok[b, :Lc[b] - 1, 1] = rs.randint(0, 4096, Lc[b] - 1)
+    ct, lt = torch.from_numpy(tok), torch.from_numpy(Lc)
+    kws = dict(n_micro=4, max_steps=240, stop_early=True, check_every=8, seed=12, mask_invalid_completion=False)
+    one = g.sample_microbatched(ct, lt, **kws)                       # 4 chains of 20 rows: one round
+    want = {k: v.clone() for k, v in one["state"].items()}
+    assert one["steps"] < 240, "the rows must end by themselves for this test to mean anything"
+    old = g.MAX_CHAIN_ROWS
+    try:
+        g.MAX_CHAIN_ROWS = 8                                         # 4 chains x 8 rows = 32 rows per round -> three rounds
+        many = g.sample_microbatched(ct, lt, **kws)
+    finally:
+        g.MAX_CHAIN_ROWS = old
+    assert many["steps"] == one["steps"]
+    for k in ("len", "Lc", "seq", "logp"):
+        assert torch.equal(many["state"][k], want[k]), k
+    ln, seq = want["len"].cpu().numpy(), want["seq"].cpu().numpy()
+    assert all(tuple(seq[b, ln[b] - 1]) == (4096, 4096) for b in range(B))      # every row ends on the end-token pair
+    stops = sorted({int(np.argmax((seq[b, Lc[b]:ln[b], 0] == 4096))) for b in range(B)})
+    assert len(stops) > 3, "rows should end at different steps"
+
+
 def test_large_batches_keep_the_single_chain_features(dev):
     """More than 96 rows in one `sample` call run as interleaved chains; the features of the single-chain path must survive the
     split: shared-prefix KV (every chain prefills the common condition once) and a non-empty z prefix, both bit-identical to the
