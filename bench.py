@@ -753,6 +753,7 @@ def main():
                 line["roofline"]["all_launches_together"] = {
                     "achieved": round(att["achieved"] * inflight, 1), "unit": "GB/s", "frac": round(att["achieved"] * inflight / HBM, 4),
                     "note": "per-launch rate x launches in flight = this kernel's algorithmic bytes over the wall time of the AR loop (GEMM launches of the other chains run in the same interval)"}
+            line["roofline"]["summary"] = None       # filled below once the isolated and traced figures are known
             ta = kernel_trace_avg("attn_decode_kernel" if dom_is_attn else "dgemm_kernel")
             if ta:
                 alg = attn_bytes if dom_is_attn else gemm_flop
@@ -775,6 +776,14 @@ def main():
                 # the GEMM phase is higher than one launch's own rate
                 line["roofline"]["dgemm_all_chains_in_flight"] = {"achieved": line["ar_loop"]["gemm_only_TFLOPs"], "unit": "TFLOP/s",
                                                                   "frac": round(line["ar_loop"]["gemm_only_TFLOPs"] / 157.3, 4)}
+            rf = line["roofline"]
+            rf["summary"] = (f"{rf['kernel'].split(' ')[0]}: {rf['frac']:.2f} of peak per launch IN SITU ({rf['avg_us']:.0f} us, "
+                             f"{rf.get('mean_launches_in_flight', 1)} launches in flight share the chip"
+                             + (f": {rf['all_launches_together']['frac']:.2f} together" if rf.get("all_launches_together") else "") + "); "
+                             f"{rf.get('frac_isolated', float('nan')):.2f} for one chain alone"
+                             + (f"; {rf['kernel_trace']['frac']:.2f} in the committed rocprofv3 trace ({rf['kernel_trace']['avg_us']:.1f} us: the "
+                                "profiler serialises the chains, and the kernel's own clock agrees with it in that profiled run)"
+                                if rf.get("kernel_trace") else "") + " - DESIGN.md section 5.2")
             line["kernels"] = ks
         if world == 1 and not a.no_subrecords:
             # BASELINE configs 2-5 in the same driver run (a few seconds each), so that their numbers are not builder-only
