@@ -183,9 +183,10 @@ class GradBuckets:
         self.pending, self.done = [], set()
         return order
 
-    def all_gather_params(self):
-        """mode rs_ag, after the sharded optimizer step wrote the updated parameters of this rank's slices into the flat buffer:
-        all-gather every reduce-scattered bucket in place (all launched, then all waited for)."""
+    def all_gather_flat(self, flat, profile=False):
+        """In-place all-gather of every reduce-scattered bucket of `flat` - any buffer laid out like the gradient buffer (the
+        updated parameters written over the consumed gradients; the AdamW moments when a checkpoint is written): rank r's slice
+        of each bucket goes to every rank.  All collectives are launched, then waited for."""
         if not self.active or self.mode != "rs_ag":
             return
         works = []
@@ -193,15 +194,19 @@ class GradBuckets:
             if self.sharded(name):
                 slo, shi = self.shard(name)
                 if self._staged():
-                    works.append(_StagedWork(self.dist, "ag", self.flat, (lo, hi), (slo, shi), None))
+                    works.append(_StagedWork(self.dist, "ag", flat, (lo, hi), (slo, shi), None))
                 else:
-                    works.append(self.dist.all_gather_into_tensor(self.flat[lo:hi], self.flat[slo:shi], async_op=True))
-        ev = self._bracket()
+                    works.append(self.dist.all_gather_into_tensor(flat[lo:hi], flat[slo:shi], async_op=True))
+        ev = self._bracket() if profile else None
         for w in works:
             w.wait()
         if ev is not None:
             ev[1].record()
             self._gather_events = getattr(self, "_gather_events", []) + [ev]
+
+    def all_gather_params(self):
+        """mode rs_ag, after the sharded optimizer step wrote the updated parameters of this rank's slices into the flat buffer."""
+        self.all_gather_flat(self.flat, profile=True)
 
     def wait_ms(self, reset=True):
         """Mean time per finish() the compute stream spent waiting for gradient collectives since the last reset (ms); None

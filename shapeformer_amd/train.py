@@ -383,7 +383,14 @@ class GPTTrainer:
 
     def optimizer_state(self):
         """Resume state: AdamW moments (flat, in parameter-table order) and the step count."""
-        return dict(step=self.step_count, exp_avg=self.flat_m.detach().cpu(), exp_avg_sq=self.flat_v.detach().cpu(),
+        m, v = self.flat_m, self.flat_v
+        if self.buckets.active and self.buckets.mode == "rs_ag":
+            # optimizer sharding: a rank holds the moments of its own slices only - gather them (a collective: every rank must call
+            # this) so that the checkpoint is complete and can be resumed in either synchronisation mode, on any world size
+            m, v = m.clone(), v.clone()
+            self.buckets.all_gather_flat(m)
+            self.buckets.all_gather_flat(v)
+        return dict(step=self.step_count, exp_avg=m.detach().cpu(), exp_avg_sq=v.detach().cpu(),
                     names=[n for n, _, _ in self.params])
 
     def load_optimizer_state(self, st):

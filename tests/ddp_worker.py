@@ -54,6 +54,7 @@ def main():
     tr2.training_step(c, z)
     out["gpt_w_rsag"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr2.params])
     out["gpt_m_rsag"] = tr2.flat_m.detach().cpu().numpy().copy()     # moments exist only on the rank's shard
+    out["gpt_m_rsag_state"] = tr2.optimizer_state()["exp_avg"].numpy().copy()     # ... and are gathered when a checkpoint is written
     out["gpt_m_ring"] = tr.flat_m.detach().cpu().numpy().copy()
     # ---- VQDIF autoencoder: item r of a 2-item batch; gradients averaged, EMA statistics summed over ranks ------
     T = np.load(os.path.join(G, "vqdif_train.npz"))

@@ -85,6 +85,8 @@ def test_gpt_trainer_reduce_scatter_all_gather_equals_ring(ranks):
     own0, own1 = m0 != 0, m1 != 0
     assert not np.any(own0 & own1) and np.array_equal(np.where(own0, m0, m1), np.where(own0 | own1, mr, 0))
     assert np.count_nonzero(own0 | own1) > 0.5 * np.count_nonzero(mr)
+    # optimizer_state() (what a checkpoint stores) gathers the shards: complete on every rank, equal to the ring mode's moments
+    assert np.array_equal(r0["gpt_m_rsag_state"], r1["gpt_m_rsag_state"]) and np.array_equal(r0["gpt_m_rsag_state"], mr)
 
 
 def test_vqdif_trainer_two_ranks_gradient_mean_and_shared_ema_codebook(dev, ranks):
