@@ -176,16 +176,18 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
     Be = X.shape[0]
     lib = L_.lib()
     ws = torch.empty(lib.sfmi_enc_workspace_bytes(Be, T), device=dev, dtype=torch.uint8)
-    g64 = torch.empty(Be, 64, 64, 64, 32, device=dev)
+    y0 = torch.empty(Be, 32, 32, 32, 64, device=dev)
     msk = torch.empty(Be, 16, 16, 16, device=dev, dtype=torch.uint8)
     cell = torch.empty(Be, T, device=dev, dtype=torch.int32)
-    ms = ev_time(lambda: L_.check(lib.sfmi_encode_points_f32(L_.ptr(X), L_.ptr(vq.enc_w), L_.ptr(g64), L_.ptr(msk), L_.ptr(cell), L_.ptr(ws), Be, T, 16,
-                                                             L_.stream_ptr()), "enc"), 5)
-    # algorithmic HBM bytes: 4 pool passes x (T*32*4 read + T*32*4 write + T*4 cell ids) + the mean pass
-    # (T*32*4 read) + the 64^3 x 32 grid written once
-    enc_bytes = Be * (4 * (2 * T * 32 * 4 + T * 4) + T * 32 * 4 + 64 ** 3 * 32 * 4)
-    add("enc_block_kernel<0..4> + enc_cells + enc_grid_mean (sfmi_encode_points_f32)", ms, "hbm", enc_bytes, 1e9, HBM, "GB/s",
-        f"{Be} shapes x {T} points: local-pool scatter_max x4 + scatter_mean, {enc_bytes / Be / 1e6:.1f} MB algorithmic per shape")
+    d0 = vq.down[0]
+    ms = ev_time(lambda: L_.check(lib.sfmi_encode_points_down_f32(L_.ptr(X), L_.ptr(vq.enc_w), L_.ptr(d0.w), L_.ptr(y0), L_.ptr(msk), L_.ptr(cell),
+                                                                  L_.ptr(ws), Be, T, 16, 1, L_.stream_ptr()), "enc"), 5)
+    # algorithmic HBM bytes: 4 pool passes x (T*32*4 read + T*32*4 write + T*4 cell ids) + the mean pass (T*32*4 read)
+    # + the 32^3 x 64 output of the fused first Downsampler convolution written once (the product route has no dense 64^3 x 32 grid)
+    enc_bytes = Be * (4 * (2 * T * 32 * 4 + T * 4) + T * 32 * 4 + 32 ** 3 * 64 * 4)
+    add("enc_block_kernel<0..4> + cell sort + enc_down0_sparse (sfmi_encode_points_down_f32)", ms, "hbm", enc_bytes, 1e9, HBM, "GB/s",
+        f"{Be} shapes x {T} points: local-pool scatter_max x4 + scatter_mean + first Downsampler conv, {enc_bytes / Be / 1e6:.1f} MB algorithmic per shape")
+    del y0
     lat = torch.randn(Be, 16, 16, 16, 128, device=dev)
     ms = ev_time(lambda: vq.quantize_cl(lat), 10)
     add("vq_argmin_kernel", ms, "mfma", 2.0 * Be * 4096 * 4096 * 128, 1e12, F32, "TFLOP/s", f"{Be} x 4096 cells x 4096 codes x d128 (f32 MFMA + running argmin)")
@@ -195,7 +197,7 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
     conv_flop = Be * (31.2e9 + 34.6e9)
     add("conv3d_igemm_kernel (UNet3D + Upsampler, 16 layers + GroupNorm statistics)", ms, "mfma", conv_flop, 1e12, F32, "TFLOP/s",
         f"{Be} shapes, res16 -> 64^3 x 32 grid; FLOPs as executed (sub-pixel up-sampling: 8/27 of the dense count)")
-    del lat, code, g64
+    del lat, code
     # sampler (latency-bound): one tuple element for Bk rows
     lg = torch.randn(B, gpt.Vpad, device=dev) * 3
     st["Lc"].fill_(int(round(lc_mean)))

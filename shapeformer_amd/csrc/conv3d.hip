@@ -315,28 +315,37 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
   }
 }
 
-// GroupNorm(groups, eps) coefficients: scale[b,c] = gamma[c]*rstd[b,g], shift[b,c] = beta[c]-mean*scale
-__global__ void gn_coeffs_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
-                                 int V, int C, int S, int groups, float eps) {
-  const int b = blockIdx.x, g = threadIdx.x;
-  if (g >= groups) return;
+// GroupNorm(groups, eps) coefficients: scale[b,c] = gamma[c]*rstd[b,g], shift[b,c] = beta[c]-mean*scale.
+// One workgroup per shape, one WAVEFRONT per group (groups beyond the 4 waves are taken in turns): the cpg x S f64 partials of a group
+// are summed lane-parallel in a fixed pattern (lane l takes items l, l + 64, ...; then a shuffle tree): deterministic, and 64 x
+// shorter than the one-thread-per-group loop it replaces (46 us per call, 20 calls per decoded batch).
+__global__ __launch_bounds__(256) void gn_coeffs_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                                        int V, int C, int S, int groups, float eps) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cpg = C / groups;
-  double s = 0, q = 0;
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c)
-    for (int sp = 0; sp < S; ++sp) {
+  for (int g = wave; g < groups; g += 4) {
+    double s = 0, q = 0;
+    for (int it = lane; it < cpg * S; it += 64) {
+      const int c = g * cpg + it / S, sp = it % S;
       const double* p = partial + (((long long)b * S + sp) * C + c) * 2;
       s += p[0]; q += p[1];
     }
-  const double n = (double)V * cpg;
-  const double mean = s / n;
-  double var = q / n - mean * mean;
-  if (var < 0) var = 0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-    const float sc = gamma[c] * rstd;
-    scale[b * C + c] = sc;
-    shift[b * C + c] = beta[c] - (float)mean * sc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    const double n = (double)V * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+      const float sc = gamma[c] * rstd;
+      scale[b * C + c] = sc;
+      shift[b * C + c] = beta[c] - (float)mean * sc;
+    }
   }
 }
 
@@ -541,7 +550,7 @@ int sfmi_groupnorm_coeffs_f32(const float* x, const float* gamma, const float* b
   hipStream_t st = (hipStream_t)stream;
   const int S = sfmi_gn_splits(V);
   hipLaunchKernelGGL(chan_stats_kernel, dim3(S, B), dim3(256), 0, st, x, partial, V, C, S);
-  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(64), 0, st, partial, gamma, beta, scale, shift, V, C, S, groups, eps);
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(256), 0, st, partial, gamma, beta, scale, shift, V, C, S, groups, eps);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

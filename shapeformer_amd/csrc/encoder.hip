@@ -59,29 +59,50 @@ __global__ void enc_cells_kernel(const float* __restrict__ cloud,  // (B,T,3) in
 }
 
 // E0b: exclusive scan of one shape's 64^3 cell counts -> start[cell] (sorted position of the cell's first point), and a copy
-// `cursor` that the scatter advances.  One 1024-thread workgroup per shape, 256 cells per thread.
-__global__ __launch_bounds__(1024) void enc_scan_kernel(int* __restrict__ start /*in: counts*/, int* __restrict__ cursor) {
+// `cursor` that the scatter advances.  Two coalesced launches over 4096-cell chunks (64 per shape): chunk sums, then every chunk
+// scans itself on top of the sum of the chunks before it (a 64-entry prefix formed by one wave) - 64 x B workgroups instead of B
+// (round 3's one-workgroup-per-shape scan with 256 consecutive cells per THREAD was uncoalesced and took 150-250 us).
+constexpr int ENC_CH = 4096, ENC_NCH = ENC_G * ENC_G * ENC_G / ENC_CH;     // 64 chunks per shape
+__global__ __launch_bounds__(1024) void enc_scan_sums_kernel(const int* __restrict__ cnt, int* __restrict__ chunk_sum) {
   __shared__ int wsum[16];
-  constexpr int NC = ENC_G * ENC_G * ENC_G, PER = NC / 1024;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int* sp = start + (long long)b * NC + tid * PER;
-  int* cp = cursor + (long long)b * NC + tid * PER;
-  int tot = 0;
-  for (int i = 0; i < PER; i += 4) { const int4 v = *reinterpret_cast<const int4*>(sp + i); tot += (v.x + v.y) + (v.z + v.w); }
+  const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int4 v = *reinterpret_cast<const int4*>(cnt + ((long long)b * ENC_NCH + ch) * ENC_CH + 4 * tid);
+  int t = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  if (lane == 0) wsum[wave] = t;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) tot += wsum[w];
+    chunk_sum[b * ENC_NCH + ch] = tot;
+  }
+}
+__global__ __launch_bounds__(1024) void enc_scan_apply_kernel(int* __restrict__ start /*in: counts*/, int* __restrict__ cursor,
+                                                              const int* __restrict__ chunk_sum) {
+  __shared__ int wsum[16];
+  __shared__ int s_base;
+  const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long off = ((long long)b * ENC_NCH + ch) * ENC_CH + 4 * tid;
+  const int4 v = *reinterpret_cast<const int4*>(start + off);
+  if (wave == 0) {          // cells of the chunks before this one
+    int c = lane < ch ? chunk_sum[b * ENC_NCH + lane] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) s_base = c;
+  }
+  const int tot = (v.x + v.y) + (v.z + v.w);
   int incl = tot;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  int base = incl - tot;
+  int base = s_base + incl - tot;
   for (int w = 0; w < wave; ++w) base += wsum[w];
-  for (int i = 0; i < PER; i += 4) {
-    int4 v = *reinterpret_cast<const int4*>(sp + i);
-    int4 o;
-    o.x = base; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z; base = o.w + v.w;
-    *reinterpret_cast<int4*>(sp + i) = o;
-    *reinterpret_cast<int4*>(cp + i) = o;
-  }
+  int4 o;
+  o.x = base; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+  *reinterpret_cast<int4*>(start + off) = o;
+  *reinterpret_cast<int4*>(cursor + off) = o;
 }
 
 // E0c: scatter the points into cell order: order[b][pos] = t, scell[b][pos] = cell (any order INSIDE a cell: max and the
@@ -327,56 +348,67 @@ __global__ __launch_bounds__(256) void enc_down0_sparse_kernel(const int* __rest
                                                                const float* __restrict__ w /*[8 taps][64][32]*/, float* __restrict__ y,
                                                                int T, int relu) {
   constexpr int G = ENC_G, GO = ENC_G / 2, NC = ENC_G * ENC_G * ENC_G;
-  const int b = blockIdx.z, zo = blockIdx.y, yo = blockIdx.x;
+  // one workgroup per (shape, zo) PLANE of 32 x 32 parents; wave w walks the rows yo = w, w + 4, ... with the next row's cell maps
+  // in flight: 2 048 workgroups for 64 shapes, all resident at once (the first version - one workgroup per row - spent 32 dispatch
+  // rounds on workgroups whose only work was one dependent load and 2 KB of zeros)
+  const int b = blockIdx.y, zo = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the four child rows (dz, dy) of this parent row: 64 cells each, lane = child x
-  int st[4], en[4];
-  unsigned long long occ[4];
+  int st[4], en[4], stn[4], enn[4];
+  auto load_row = [&](int yo, int (&s_)[4], int (&e_)[4]) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long c = (long long)b * NC + ((long long)(2 * zo + (r >> 1)) * G + (2 * yo + (r & 1))) * G + lane;
-    st[r] = start[c]; en[r] = cend[c];
-    occ[r] = __ballot(en[r] != st[r]);
-  }
-  float* yrow = y + ((((long long)b * GO + zo) * GO + yo) * GO) * 64;
-  for (int xo = wave; xo < GO; xo += 4) {
-    float acc = 0.f;
-    const unsigned bits = (unsigned)((occ[0] >> (2 * xo)) & 3) | (unsigned)(((occ[1] >> (2 * xo)) & 3) << 2) |
-                          (unsigned)(((occ[2] >> (2 * xo)) & 3) << 4) | (unsigned)(((occ[3] >> (2 * xo)) & 3) << 6);
-    if (bits) {                                   // wave-uniform: most parents have no occupied child
-      // the sums of ALL occupied children are requested first (independent loads: one round trip), then multiplied
-      float mean[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int r = c >> 1, dx = c & 1;
-        mean[c] = 0.f;
-        if ((bits >> c) & 1) {
-          const int s0 = __shfl(st[r], 2 * xo + dx, 64);
-          const long long seg = (long long)b * T + s0;             // sorted position of the cell's first point names its sums
-          // cell mean of channel (lane & 31), formed as enc_grid_mean_kernel does
-          const double sm = (double)csum[seg * 32 + (lane & 31)] * (1.0 / 4294967296.0);
-          mean[c] = (float)(sm / (double)ccount[seg]);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        if (!((bits >> c) & 1)) continue;
-        const int r = c >> 1, dx = c & 1;
-        const int tap = ((r >> 1) * 2 + (r & 1)) * 2 + dx;        // (dz, dy, dx), the conv kernel's tap order
-        const f32x4* wp = reinterpret_cast<const f32x4*>(w + ((long long)tap * 64 + lane) * 32);
-        f32x4 wv[8];
-#pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) wv[k4] = wp[k4];
-#pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-          acc = fmaf(wv[k4][0], __shfl(mean[c], 4 * k4 + 0, 64), acc);
-          acc = fmaf(wv[k4][1], __shfl(mean[c], 4 * k4 + 1, 64), acc);
-          acc = fmaf(wv[k4][2], __shfl(mean[c], 4 * k4 + 2, 64), acc);
-          acc = fmaf(wv[k4][3], __shfl(mean[c], 4 * k4 + 3, 64), acc);
-        }
-      }
+    for (int r = 0; r < 4; ++r) {      // the four child rows (dz, dy) of parent row yo: 64 cells each, lane = child x
+      const long long c = (long long)b * NC + ((long long)(2 * zo + (r >> 1)) * G + (2 * yo + (r & 1))) * G + lane;
+      s_[r] = start[c]; e_[r] = cend[c];
     }
-    yrow[(long long)xo * 64 + lane] = relu ? fmaxf(acc, 0.f) : acc;
+  };
+  load_row(wave, st, en);
+  for (int yo = wave; yo < GO; yo += 4) {
+    if (yo + 4 < GO) load_row(yo + 4, stn, enn);
+    unsigned long long occ[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) occ[r] = __ballot(en[r] != st[r]);
+    float* yrow = y + ((((long long)b * GO + zo) * GO + yo) * GO) * 64;
+    for (int xo = 0; xo < GO; ++xo) {
+      float acc = 0.f;
+      const unsigned bits = (unsigned)((occ[0] >> (2 * xo)) & 3) | (unsigned)(((occ[1] >> (2 * xo)) & 3) << 2) |
+                            (unsigned)(((occ[2] >> (2 * xo)) & 3) << 4) | (unsigned)(((occ[3] >> (2 * xo)) & 3) << 6);
+      if (bits) {                                   // wave-uniform: most parents have no occupied child
+        // the sums of ALL occupied children are requested first (independent loads: one round trip), then multiplied
+        float mean[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int r = c >> 1, dx = c & 1;
+          mean[c] = 0.f;
+          if ((bits >> c) & 1) {
+            const int s0 = __shfl(st[r], 2 * xo + dx, 64);
+            const long long seg = (long long)b * T + s0;             // sorted position of the cell's first point names its sums
+            // cell mean of channel (lane & 31), formed as enc_grid_mean_kernel does
+            const double sm = (double)csum[seg * 32 + (lane & 31)] * (1.0 / 4294967296.0);
+            mean[c] = (float)(sm / (double)ccount[seg]);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (!((bits >> c) & 1)) continue;
+          const int r = c >> 1, dx = c & 1;
+          const int tap = ((r >> 1) * 2 + (r & 1)) * 2 + dx;        // (dz, dy, dx), the conv kernel's tap order
+          const f32x4* wp = reinterpret_cast<const f32x4*>(w + ((long long)tap * 64 + lane) * 32);
+          f32x4 wv[8];
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) wv[k4] = wp[k4];
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) {
+            acc = fmaf(wv[k4][0], __shfl(mean[c], 4 * k4 + 0, 64), acc);
+            acc = fmaf(wv[k4][1], __shfl(mean[c], 4 * k4 + 1, 64), acc);
+            acc = fmaf(wv[k4][2], __shfl(mean[c], 4 * k4 + 2, 64), acc);
+            acc = fmaf(wv[k4][3], __shfl(mean[c], 4 * k4 + 3, 64), acc);
+          }
+        }
+      }
+      yrow[(long long)xo * 64 + lane] = relu ? fmaxf(acc, 0.f) : acc;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[r] = stn[r]; en[r] = enn[r]; }
   }
 }
 
@@ -421,8 +453,8 @@ int sfmi_enc_pack_weights(const float* fc_pos_w /*64x3*/, const float* fc_pos_b 
 
 size_t sfmi_enc_workspace_bytes(int B, int T) {
   size_t bt = (size_t)B * T;
-  // cell + order + sorted cell (3 x 4) + start map + cursor map + 2 net buffers + 2 segmax buffers + csum + ccount
-  return bt * 12 + 2 * (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + 1024;
+  // cell + order + sorted cell (3 x 4) + start map + cursor map + 2 net buffers + 2 segmax buffers + csum + ccount + scan chunk sums
+  return bt * 12 + 2 * (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + (size_t)B * 64 * 4 + 1024;
 }
 
 static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace, int B, int T,
@@ -463,7 +495,8 @@ static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, 
   float* net[2]; net[0] = (float*)w; w += bt * 128; net[1] = (float*)w; w += bt * 128;
   int* sm[2]; sm[0] = (int*)w; w += bt * 128; sm[1] = (int*)w; w += bt * 128;
   long long* csum = (long long*)w; w += bt * 256;
-  int* ccount = (int*)w;
+  int* ccount = (int*)w; w += bt * 4;
+  int* chunk_sum = (int*)w;      // (B, 64) chunk totals of the cell-count scan
   hipMemsetAsync(start, 0, nc * 4, st);
   hipMemsetAsync(mask, 0, (size_t)B * R * R * R, st);
   hipMemsetAsync(csum, 0, bt * 256 + bt * 4, st);
@@ -471,7 +504,8 @@ static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, 
   int nb = (int)((bt + 255) / 256);
   // group the points of every shape by cell: histogram -> exclusive scan -> scatter (2 integer atomics per point)
   hipLaunchKernelGGL(enc_cells_kernel, dim3(nb), dim3(256), 0, st, cloud, cell, start, mask, B, T, R);
-  hipLaunchKernelGGL(enc_scan_kernel, dim3(B), dim3(1024), 0, st, start, cursor);
+  hipLaunchKernelGGL(enc_scan_sums_kernel, dim3(ENC_NCH, B), dim3(1024), 0, st, start, chunk_sum);
+  hipLaunchKernelGGL(enc_scan_apply_kernel, dim3(ENC_NCH, B), dim3(1024), 0, st, start, cursor, chunk_sum);
   hipLaunchKernelGGL(enc_scatter_kernel, dim3(nb), dim3(256), 0, st, cell, cursor, order, scell, B, T);
   const long long tiles = (long long)(bt + 31) / 32;
   int grid = (int)((tiles + 3) / 4);
@@ -498,7 +532,7 @@ static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, 
     hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, scell, start, csum,
                        ccount, grid_cl, B, T);
   if (down_y)     // `cursor` has been advanced to each cell's END by the scatter: cursor != start <=> the cell holds points
-    hipLaunchKernelGGL(enc_down0_sparse_kernel, dim3(ENC_G / 2, ENC_G / 2, B), dim3(256), 0, st, start, cursor, csum, ccount, down_w, down_y,
+    hipLaunchKernelGGL(enc_down0_sparse_kernel, dim3(ENC_G / 2, B), dim3(256), 0, st, start, cursor, csum, ccount, down_w, down_y,
                        T, down_relu);
   if (cell_out) hipMemcpyAsync(cell_out, cell, bt * 4, hipMemcpyDeviceToDevice, st);
   SFMI_CHECK_LAUNCH();
