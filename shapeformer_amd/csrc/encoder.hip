@@ -343,9 +343,9 @@ __global__ void enc_grid_mean_kernel(const int* __restrict__ cell, const int* __
 // empty child contributes exactly zero, as it does in the dense convolution.  One workgroup per (shape, zo, yo) row of 32 parents,
 // wave w takes parents w, w+4, ...; lane = output channel; taps and input channels are summed in ascending order (fmaf): a fixed
 // order, deterministic - the dense MFMA path sums the same products in another order (differences ~1e-7 relative).
-__global__ __launch_bounds__(256) void enc_down0_sparse_kernel(const int* __restrict__ start, const int* __restrict__ cend,
+__global__ __launch_bounds__(256, 4) void enc_down0_sparse_kernel(const int* __restrict__ start, const int* __restrict__ cend,
                                                                const long long* __restrict__ csum, const int* __restrict__ ccount,
-                                                               const float* __restrict__ w /*[8 taps][64][32]*/, float* __restrict__ y,
+                                                               const float* __restrict__ wt /*[8 taps][32 cin][64 cout]*/, float* __restrict__ y,
                                                                int T, int relu) {
   constexpr int G = ENC_G, GO = ENC_G / 2, NC = ENC_G * ENC_G * ENC_G;
   // one workgroup per (shape, zo) PLANE of 32 x 32 parents; wave w walks the rows yo = w, w + 4, ... with the next row's cell maps
@@ -373,36 +373,41 @@ __global__ __launch_bounds__(256) void enc_down0_sparse_kernel(const int* __rest
       const unsigned bits = (unsigned)((occ[0] >> (2 * xo)) & 3) | (unsigned)(((occ[1] >> (2 * xo)) & 3) << 2) |
                             (unsigned)(((occ[2] >> (2 * xo)) & 3) << 4) | (unsigned)(((occ[3] >> (2 * xo)) & 3) << 6);
       if (bits) {                                   // wave-uniform: most parents have no occupied child
-        // the sums of ALL occupied children are requested first (independent loads: one round trip), then multiplied
-        float mean[8];
+        // the sums of all 8 child slots are requested UNCONDITIONALLY (an empty slot reads the shape's first segment and is zeroed
+        // afterwards): sixteen independent loads in one round trip - with the loads inside per-child branches every child cost two
+        // dependent round trips of its own (26 us per occupied parent, 0.42 ms per 64 shapes)
+        long long cs[8];
+        int cc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const int r = c >> 1, dx = c & 1;
-          mean[c] = 0.f;
-          if ((bits >> c) & 1) {
-            const int s0 = __shfl(st[r], 2 * xo + dx, 64);
-            const long long seg = (long long)b * T + s0;             // sorted position of the cell's first point names its sums
-            // cell mean of channel (lane & 31), formed as enc_grid_mean_kernel does
-            const double sm = (double)csum[seg * 32 + (lane & 31)] * (1.0 / 4294967296.0);
-            mean[c] = (float)(sm / (double)ccount[seg]);
-          }
+          const int s0 = __shfl(st[r], 2 * xo + dx, 64);
+          const long long seg = (long long)b * T + (((bits >> c) & 1) ? s0 : 0);      // sorted position of the cell's first point names its sums
+          cs[c] = csum[seg * 32 + (lane & 31)];
+          cc[c] = ccount[seg];
+        }
+        float mean[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {     // cell mean of channel (lane & 31), formed as enc_grid_mean_kernel does
+          const double sm = (double)cs[c] * (1.0 / 4294967296.0);
+          mean[c] = ((bits >> c) & 1) ? (float)(sm / (double)cc[c]) : 0.f;
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           if (!((bits >> c) & 1)) continue;
           const int r = c >> 1, dx = c & 1;
           const int tap = ((r >> 1) * 2 + (r & 1)) * 2 + dx;        // (dz, dy, dx), the conv kernel's tap order
-          const f32x4* wp = reinterpret_cast<const f32x4*>(w + ((long long)tap * 64 + lane) * 32);
-          f32x4 wv[8];
+          // weights transposed to [tap][cin][cout]: one coalesced 256-byte load per input channel, all 32 in flight together.
+          // The offset is laundered through an empty asm: the weights do not depend on the parent, and hoisting all 8 x 32 of
+          // them out of the parent loop (what the optimiser does otherwise) costs 256 registers and the kernel's occupancy
+          int woff = tap * 32 * 64;
+          asm volatile("" : "+s"(woff));
+          const float* wp = wt + woff + lane;
+          float wv[32];
 #pragma unroll
-          for (int k4 = 0; k4 < 8; ++k4) wv[k4] = wp[k4];
+          for (int k = 0; k < 32; ++k) wv[k] = wp[k * 64];
 #pragma unroll
-          for (int k4 = 0; k4 < 8; ++k4) {
-            acc = fmaf(wv[k4][0], __shfl(mean[c], 4 * k4 + 0, 64), acc);
-            acc = fmaf(wv[k4][1], __shfl(mean[c], 4 * k4 + 1, 64), acc);
-            acc = fmaf(wv[k4][2], __shfl(mean[c], 4 * k4 + 2, 64), acc);
-            acc = fmaf(wv[k4][3], __shfl(mean[c], 4 * k4 + 3, 64), acc);
-          }
+          for (int k = 0; k < 32; ++k) acc = fmaf(wv[k], __shfl(mean[c], k, 64), acc);
         }
       }
       yrow[(long long)xo * 64 + lane] = relu ? fmaxf(acc, 0.f) : acc;
@@ -410,6 +415,14 @@ __global__ __launch_bounds__(256) void enc_down0_sparse_kernel(const int* __rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) { st[r] = stn[r]; en[r] = enn[r]; }
   }
+}
+
+// [8 taps][64 cout][32 cin] (sfmi_conv_pack_weight layout) -> [8][32][64] for enc_down0_sparse_kernel
+__global__ void enc_down0_wt_kernel(const float* __restrict__ w, float* __restrict__ wt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over 8 * 64 * 32
+  if (i >= 8 * 64 * 32) return;
+  const int ci = i & 31, co = (i >> 5) & 63, tap = i >> 11;
+  wt[(tap * 32 + ci) * 64 + co] = w[i];
 }
 
 extern "C" {
@@ -454,7 +467,7 @@ int sfmi_enc_pack_weights(const float* fc_pos_w /*64x3*/, const float* fc_pos_b 
 size_t sfmi_enc_workspace_bytes(int B, int T) {
   size_t bt = (size_t)B * T;
   // cell + order + sorted cell (3 x 4) + start map + cursor map + 2 net buffers + 2 segmax buffers + csum + ccount + scan chunk sums
-  return bt * 12 + 2 * (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + (size_t)B * 64 * 4 + 1024;
+  return bt * 12 + 2 * (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + (size_t)B * 64 * 4 + 65536 + 1024;
 }
 
 static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace, int B, int T,
@@ -496,7 +509,9 @@ static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, 
   int* sm[2]; sm[0] = (int*)w; w += bt * 128; sm[1] = (int*)w; w += bt * 128;
   long long* csum = (long long*)w; w += bt * 256;
   int* ccount = (int*)w; w += bt * 4;
-  int* chunk_sum = (int*)w;      // (B, 64) chunk totals of the cell-count scan
+  int* chunk_sum = (int*)w; w += (size_t)B * 64 * 4;     // (B, 64) chunk totals of the cell-count scan
+  w = (char*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+  float* down_wt = (float*)w;    // [8][32][64] transposed copy of the first Downsampler convolution's weights (64 KB)
   hipMemsetAsync(start, 0, nc * 4, st);
   hipMemsetAsync(mask, 0, (size_t)B * R * R * R, st);
   hipMemsetAsync(csum, 0, bt * 256 + bt * 4, st);
@@ -531,9 +546,11 @@ static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, 
   if (grid_cl)
     hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, scell, start, csum,
                        ccount, grid_cl, B, T);
-  if (down_y)     // `cursor` has been advanced to each cell's END by the scatter: cursor != start <=> the cell holds points
-    hipLaunchKernelGGL(enc_down0_sparse_kernel, dim3(ENC_G / 2, B), dim3(256), 0, st, start, cursor, csum, ccount, down_w, down_y,
+  if (down_y) {   // `cursor` has been advanced to each cell's END by the scatter: cursor != start <=> the cell holds points
+    hipLaunchKernelGGL(enc_down0_wt_kernel, dim3(64), dim3(256), 0, st, down_w, down_wt);
+    hipLaunchKernelGGL(enc_down0_sparse_kernel, dim3(ENC_G / 2, B), dim3(256), 0, st, start, cursor, csum, ccount, down_wt, down_y,
                        T, down_relu);
+  }
   if (cell_out) hipMemcpyAsync(cell_out, cell, bt * 4, hipMemcpyDeviceToDevice, st);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
