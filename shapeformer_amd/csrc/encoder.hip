@@ -353,11 +353,6 @@ __global__ __launch_bounds__(256, 4) void enc_down0_sparse_kernel(const int* __r
   // rounds on workgroups whose only work was one dependent load and 2 KB of zeros)
   const int b = blockIdx.y, zo = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the convolution's weights ([8 taps][32 cin][64 cout], 64 KB) live in LDS for the whole plane: an occupied child then costs 32
-  // conflict-free ds_read_b32 instead of a global round trip of its own
-  __shared__ __attribute__((aligned(16))) float wl[8 * 32 * 64];
-  for (int i = threadIdx.x; i < 8 * 32 * 64 / 4; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(wt)[i];
-  __syncthreads();
   int st[4], en[4], stn[4], enn[4];
   auto load_row = [&](int yo, int (&s_)[4], int (&e_)[4]) {
 #pragma unroll
@@ -402,11 +397,12 @@ __global__ __launch_bounds__(256, 4) void enc_down0_sparse_kernel(const int* __r
           if (!((bits >> c) & 1)) continue;
           const int r = c >> 1, dx = c & 1;
           const int tap = ((r >> 1) * 2 + (r & 1)) * 2 + dx;        // (dz, dy, dx), the conv kernel's tap order
+          // weights transposed to [tap][cin][cout]: one coalesced 256-byte load per input channel, all 32 in flight together.
           // The offset is laundered through an empty asm: the weights do not depend on the parent, and hoisting all 8 x 32 of
           // them out of the parent loop (what the optimiser does otherwise) costs 256 registers and the kernel's occupancy
           int woff = tap * 32 * 64;
           asm volatile("" : "+s"(woff));
-          const float* wp = wl + woff + lane;
+          const float* wp = wt + woff + lane;
           float wv[32];
 #pragma unroll
           for (int k = 0; k < 32; ++k) wv[k] = wp[k * 64];
