@@ -396,10 +396,14 @@ class ShapeFormerModel:
         c, z, _, _ = self.representer.get_indices(Xct, Xbd, stage=stage)
         return c, z
 
-    def make_trainer(self, optim_opt=None, dist=None):
+    def make_trainer(self, optim_opt=None, dist=None, grad_sync="ring"):
+        """AdamW trainer of the transformer (shapeformer.py:198-206).  dist: torch.distributed for data-parallel training
+        (trainer.py:22,93); grad_sync "ring" = per-block all-reduce, "rs_ag" = reduce-scatter / sharded AdamW / all-gather (the weights
+        are the same bit for bit; with "rs_ag" `save_checkpoint` gathers the sharded moments, i.e. EVERY rank must call it - only
+        the ranks that should own a file need a distinct path)."""
         from .train import GPTTrainer
         lr = (optim_opt or getattr(self, "optim_opt", None) or {}).get("lr", 1e-5)
-        self.trainer = GPTTrainer(self.transformer, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, dist=dist)
+        self.trainer = GPTTrainer(self.transformer, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, dist=dist, grad_sync=grad_sync)
         return self.trainer
 
     def training_step(self, batch, batch_idx=0):
@@ -419,11 +423,14 @@ class ShapeFormerModel:
     def save_checkpoint(self, path, hyper_parameters=None, epoch=0):
         """Lightning-layout file: `state_dict` (reference key names), `hyper_parameters` (the ctor kwargs, so that
         `load_from_checkpoint` of either code base can rebuild the module), `epoch`, `global_step`.  The AdamW moments of the
-        flat-buffer trainer are NOT a torch.optim state dict; they live under the private key `sfmi_optimizer_state`."""
+        flat-buffer trainer are NOT a torch.optim state dict; they live under the private key `sfmi_optimizer_state`.
+        path=None: take part in the collectives of a sharded optimizer state (grad_sync "rs_ag") without writing a file."""
         ck = dict(state_dict=self.state_dict(), hyper_parameters=dict(hyper_parameters or self.hparams), epoch=epoch,
                   global_step=getattr(getattr(self, "trainer", None), "step_count", 0))
         if hasattr(self, "trainer"):
-            ck["sfmi_optimizer_state"] = self.trainer.optimizer_state()
+            ck["sfmi_optimizer_state"] = self.trainer.optimizer_state()     # rs_ag: an all-gather of the moments (all ranks)
+        if path is None:
+            return None
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save(ck, path)
         return path
