@@ -223,7 +223,7 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
 
 
 def pmc_traffic(kernel, B):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic_B64.json: FETCH_SIZE
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r0N_pmc_traffic_B<rows>.json, newest round first: FETCH_SIZE
     doubled per the gfx950 correction + WRITE_SIZE); only valid for the configuration it was collected on."""
     f = None
     for r in ("r04", "r03", "r02", "r01"):                               # newest collection for this launch shape (tools/pmc_run.sh)
@@ -714,7 +714,7 @@ def main():
                 line["ar_loop"]["gemm_only_TFLOPs"] = round(flops_step / split["attn"] / 1e9, 1)
                 line["ar_loop"]["split_note"] = ("all chains interleaved, one kernel family disabled at a time (each still runs the head GEMMs + samplers): "
                                                  "the KV stream alone runs at the achievable HBM rate; the two families time-share the chip "
-                                                 "(sum ~ real), profiles/r02_decode_step_experiments.md")
+                                                 "(sum ~ real: the loop is bound by energy at the socket's power cap, profiles/r04_gemm_experiments.md)")
             nm = a.micro or default_chains(B)
             Bk = -(-B // nm)     # rows per decode launch (micro-batch)
         if not a.no_roofline:
