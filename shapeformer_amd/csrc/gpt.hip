@@ -605,44 +605,40 @@ __global__ __launch_bounds__(64) void attn_gate_kernel(int* sem, int lanes) {
 //   P row (one query): key k   at (k % 4) * 16 + k / 4       (lane lq reads its 16 k-steps 4 kk + lq in a row)
 // The MFMA operands and their order are those of the linear layout: results are bit-identical.
 constexpr int AP_PS = 68;   // P tile row stride (16 rows x 64 keys)
-template <int HD, int QT>   // head dim 16 / 32 / 64; QT query tiles (16 rows each) per wave: a workgroup covers 64 * QT queries
+template <int HD>           // head dim 16 / 32 / 64
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
                                                                 float* __restrict__ Vc, const int* __restrict__ nval,
                                                                 float* __restrict__ y, int P, int D, int Lmax, float scale,
                                                                 const int* __restrict__ rowoff, float drop_p, unsigned drop_seed) {
   // row strides HD + 4: 16-byte aligned rows whose ds_read_b128 of 16 consecutive rows hit distinct banks; 51 KB of LDS per workgroup
-  // at HD = 64.  QT > 1 (round 4): every staged 64-key block serves QT query tiles per wave - 1 / QT of the global loads, LDS
-  // writes and barriers per MFMA, and QT x the MFMA work per workgroup prologue (a workgroup of the one-tile form walks only 1-4 key
-  // blocks at the bench's condition lengths and spends most of its life in its prologue).  Wave w owns the tiles w, w + 4, ... of
-  // the workgroup's query range (interleaved: the causal work per wave stays balanced).  Each query row sees the same key blocks
-  // and key tiles in the same order whatever QT is: all QT give bit-identical results.
-  constexpr int AP_KS = HD + 4, AP_VS = HD + 4, KK = HD / 4, DT = HD / 16, QB = 64 * QT;
+  // at HD = 64 -> three resident workgroups per CU (a workgroup walks only 1-4 key blocks: its prologue latency needs company)
+  constexpr int AP_KS = HD + 4, AP_VS = HD + 4, KK = HD / 4, DT = HD / 16;
   __shared__ __attribute__((aligned(16))) float Ks[64 * AP_KS], Vs[64 * AP_VS], Ps[4][16 * AP_PS];
-  const int b = blockIdx.x, h = blockIdx.y, qg = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = min(P, max(nval[b], 0));
   const long long base = rowoff ? rowoff[b] : (long long)b * P;
-  const int q0g = qg * QB;
-  if (q0g >= n) return;
+  const int q0 = qb * 64;
+  if (q0 >= n) return;
   const int lr = lane & 15, lq = lane >> 4;
   // Q fragments (A operand: row lr, k = 4 kk + lq), pre-scaled
-  float qf[QT][KK];
-  float mrun[QT][4], lrun[QT][4];
-  f32x4 o[QT][DT];
-#pragma unroll
-  for (int i = 0; i < QT; ++i) {
-    const int tq = min(q0g + 16 * (wave + 4 * i) + lr, n - 1);
+  float qf[KK];
+  {
+    const int tq = min(q0 + 16 * wave + lr, n - 1);
     const float* qp = qkv + (base + tq) * 3 * D + h * HD + lq;
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) qf[i][kk] = qp[4 * kk] * scale;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { mrun[i][j] = -INFINITY; lrun[i][j] = 0.f; }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = qp[4 * kk] * scale;
   }
-  const int kend = min(n, q0g + QB);
+  float mrun[4], lrun[4];
+  f32x4 o[DT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kend = min(n, q0 + 64);
   float* Pw = Ps[wave];
   // K / V blocks go global -> registers -> LDS; the loads of block k0 + 64 are issued right after block k0 has been handed to LDS, so
-  // their latency runs under the MFMAs of block k0.
+  // their latency runs under the 128 MFMAs of block k0 (a workgroup walks only 1 - 4 blocks at the bench's condition lengths: an
+  // exposed load per block was most of its time).
   constexpr int NIT = (64 * KK + 255) / 256;
   f32x4 kreg[NIT], vreg[NIT];
   auto gload = [&](int k0) {
@@ -659,6 +655,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     }
   };
   gload(0);
+  const bool wave_active = q0 + 16 * wave < n;     // a wave whose 16 query rows are all padding only helps with the staging
   for (int k0 = 0; k0 < kend; k0 += 64) {
     __syncthreads();
 #pragma unroll
@@ -671,7 +668,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
           Ks[r * AP_KS + e * KK + c] = kreg[it][e];
           Vs[r * AP_VS + ((4 * c + e) & 15) * DT + (c >> 2)] = vreg[it][e];
         }
-        if (k0 >= q0g && k0 + r < n) {  // the workgroup whose queries these keys are owns these cache rows
+        if (k0 == q0 && k0 + r < n) {  // this block owns these cache rows
           const long long co = (((long long)b * gridDim.y + h) * Lmax + k0 + r) * HD + 4 * c;  // (B,H,Lmax,HD)
           *reinterpret_cast<f32x4*>(Kc + co) = kreg[it];
           *reinterpret_cast<f32x4*>(Vc + co) = vreg[it];
@@ -680,97 +677,91 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     }
     __syncthreads();
     if (k0 + 64 < kend) gload(k0 + 64);
+    if (!wave_active) continue;
+    // key tiles this wave needs from the block: all four below the diagonal; on the diagonal block (k0 == q0) only tiles 0 .. wave
+    // (tile t > wave holds keys > every query row of the wave: fully masked, p == 0 exactly, so skipping it changes no bit); never
+    // tiles that start at or beyond the sequence end
+    const int tmax = min(k0 == q0 ? wave : 3, (kend - k0 - 1) >> 4);
+    // S = Q K^T
+    f32x4 sacc[4];
 #pragma unroll
-    for (int i = 0; i < QT; ++i) {
-      const int qbase = q0g + 16 * (wave + 4 * i);      // first query row of this tile (wave-uniform)
-      if (qbase >= n || k0 > qbase + 15) continue;      // a tile of pure padding rows / a block wholly above the tile's diagonal
-      // key tiles the tile needs from the block: up to its diagonal (a key tile beyond it holds keys > every query row of the tile:
-      // fully masked, p == 0 exactly, so skipping it changes no bit), never tiles that start at or beyond the sequence end
-      const int tmax = min(min(3, (qbase + 15 - k0) >> 4), (n - 1 - k0) >> 4);
-      // S = Q K^T
-      f32x4 sacc[4];
+    for (int t = 0; t < 4; ++t) {
+      sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t > tmax) continue;
+      const f32x4* kp = reinterpret_cast<const f32x4*>(&Ks[(16 * t + lr) * AP_KS + lq * KK]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t > tmax) continue;
-        const f32x4* kp = reinterpret_cast<const f32x4*>(&Ks[(16 * t + lr) * AP_KS + lq * KK]);
+      for (int k4 = 0; k4 < KK / 4; ++k4) {
+        const f32x4 kv = kp[k4];
 #pragma unroll
-        for (int k4 = 0; k4 < KK / 4; ++k4) {
-          const f32x4 kv = kp[k4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[i][4 * k4 + e], kv[e], sacc[t], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[4 * k4 + e], kv[e], sacc[t], 0, 0, 0);
       }
-      // causal / length mask, online softmax per row (row of register j: qbase + 4 lq + j)
-      float corr[4];
+    }
+    // causal / length mask, online softmax per row (row of register j: q0 + 16 wave + 4 lq + j)
+    float corr[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int qrow = qbase + 4 * lq + j;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (t > tmax) continue;
-          const int key = k0 + 16 * t + lr;
-          if (key > qrow || key >= n) sacc[t][j] = -INFINITY;
-          mx = fmaxf(mx, sacc[t][j]);
-        }
-        mx = row16_max(mx);
-        const float mnew = fmaxf(mrun[i][j], mx);
-        const float ms = mnew == -INFINITY ? 0.f : mnew;        // fully masked so far: keep everything at zero
-        corr[j] = __expf(mrun[i][j] - ms);
-        float ps = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (t > tmax) continue;
-          float p = __expf(sacc[t][j] - ms);
-          ps += p;                       // the softmax denominator is the undropped sum (att = softmax; att = attn_drop(att))
-          if (drop_p > 0.f)              // training: element (b, h, query, key) of the (B,H,P,P) attention-probability tensor
-            p *= sfmi_dropout_mul(drop_seed, (unsigned)(((b * gridDim.y + h) * P + qrow) * P + k0 + 16 * t + lr), drop_p, 1.0f / (1.0f - drop_p));
-          Pw[(4 * lq + j) * AP_PS + (lr & 3) * 16 + 4 * t + (lr >> 2)] = p;     // key 16 t + lr in operand order
-        }
-        ps = row16_sum(ps);
-        lrun[i][j] = lrun[i][j] * corr[j] + ps;
-        mrun[i][j] = mnew;
-      }
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[i][dt][j] *= corr[j];
-      __builtin_amdgcn_wave_barrier();   // P tile written and read by this wave only; LDS ops of a wave execute in order
-      // O += P V over the keys of the tiles in use
-      const f32x4* pp = reinterpret_cast<const f32x4*>(&Pw[lr * AP_PS + lq * 16]);
+    for (int j = 0; j < 4; ++j) {
+      const int qrow = q0 + 16 * wave + 4 * lq + j;
+      float mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (t > tmax) continue;
-        const f32x4 pa = pp[t];               // P[query lr][keys 4 (4t + k4) + lq], k4 = 0..3
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const int kk = 4 * t + k4;
-          const float* vp = &Vs[(4 * kk + lq) * AP_VS + lr * DT];
-          float vv[DT];
-          if (DT == 4) { const f32x4 v4 = *reinterpret_cast<const f32x4*>(vp); vv[0] = v4[0]; vv[1] = v4[1]; vv[DT > 2 ? 2 : 0] = v4[2]; vv[DT > 3 ? 3 : 0] = v4[3]; }
-          else {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vv[dt] = vp[dt];
-          }
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k4], vv[dt], o[i][dt], 0, 0, 0);
-        }
+        const int key = k0 + 16 * t + lr;
+        if (key > qrow || key >= n) sacc[t][j] = -INFINITY;
+        mx = fmaxf(mx, sacc[t][j]);
       }
-      __builtin_amdgcn_wave_barrier();   // the next tile of this wave rewrites the P tile
+      mx = row16_max(mx);
+      const float mnew = fmaxf(mrun[j], mx);
+      const float ms = mnew == -INFINITY ? 0.f : mnew;        // fully masked so far: keep everything at zero
+      corr[j] = __expf(mrun[j] - ms);
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t > tmax) continue;
+        float p = __expf(sacc[t][j] - ms);
+        ps += p;                       // the softmax denominator is the undropped sum (att = softmax; att = attn_drop(att))
+        if (drop_p > 0.f)              // training: element (b, h, query, key) of the (B,H,P,P) attention-probability tensor
+          p *= sfmi_dropout_mul(drop_seed, (unsigned)(((b * gridDim.y + h) * P + qrow) * P + k0 + 16 * t + lr), drop_p, 1.0f / (1.0f - drop_p));
+        Pw[(4 * lq + j) * AP_PS + (lr & 3) * 16 + 4 * t + (lr >> 2)] = p;     // key 16 t + lr in operand order
+      }
+      ps = row16_sum(ps);
+      lrun[j] = lrun[j] * corr[j] + ps;
+      mrun[j] = mnew;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] *= corr[j];
+    __builtin_amdgcn_wave_barrier();   // P tile written and read by this wave only; LDS ops of a wave execute in order
+    // O += P V over the keys of the tiles in use
+    const f32x4* pp = reinterpret_cast<const f32x4*>(&Pw[lr * AP_PS + lq * 16]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t > tmax) continue;
+      const f32x4 pa = pp[t];               // P[query lr][keys 4 (4t + k4) + lq], k4 = 0..3
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int kk = 4 * t + k4;
+        const float* vp = &Vs[(4 * kk + lq) * AP_VS + lr * DT];
+        float vv[DT];
+        if (DT == 4) { const f32x4 v4 = *reinterpret_cast<const f32x4*>(vp); vv[0] = v4[0]; vv[1] = v4[1]; vv[DT > 2 ? 2 : 0] = v4[2]; vv[DT > 3 ? 3 : 0] = v4[3]; }
+        else {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) vv[dt] = vp[dt];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k4], vv[dt], o[dt], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < QT; ++i)
+  for (int j = 0; j < 4; ++j) {
+    const int tq = q0 + 16 * wave + 4 * lq + j;
+    if (tq >= n) continue;
+    const float inv = 1.0f / lrun[j];
+    float* yp = y + (base + tq) * D + h * HD + lr;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int tq = q0g + 16 * (wave + 4 * i) + 4 * lq + j;
-      if (tq >= n) continue;
-      const float inv = 1.0f / lrun[i][j];
-      float* yp = y + (base + tq) * D + h * HD + lr;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) yp[16 * dt] = o[i][dt][j] * inv;
-    }
+    for (int dt = 0; dt < DT; ++dt) yp[16 * dt] = o[dt][j] * inv;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1320,16 +1311,12 @@ int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int*
                               int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, void* stream) {
   const int HD = H > 0 ? D / H : 0;
   if (!qkv || !Kc || !Vc || !nval || !y || H <= 0 || D % H || (HD != 16 && HD != 32 && HD != 64) || P <= 0 || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
+  const dim3 grid(B, H, (P + 63) / 64);
   const float scale = 1.0f / sqrtf((float)HD);
   hipStream_t st = (hipStream_t)stream;
-  // query tiles per wave (knob attn_prefill_qt, default 2): 128 queries per workgroup; 1 = the round 1-3 shape
-  const int qt = HD == 64 ? g_tune.attn_prefill_qt : 1;
-#define AP(HD_, QT_) hipLaunchKernelGGL((attn_prefill_mfma_kernel<HD_, QT_>), dim3(B, H, (P + 64 * QT_ - 1) / (64 * QT_)), dim3(256), 0, st, qkv, Kc, Vc, \
-                                        nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed)
-  if (HD == 64) { if (qt == 3) AP(64, 3); else if (qt == 2) AP(64, 2); else AP(64, 1); }
-  else if (HD == 32) AP(32, 1);
-  else AP(16, 1);
-#undef AP
+  if (HD == 64) hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
+  else if (HD == 32) hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
+  else hipLaunchKernelGGL(attn_prefill_mfma_kernel<16>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

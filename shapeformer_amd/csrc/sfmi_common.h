@@ -93,6 +93,5 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   conv_xreuse : 1 (default) = stride-1 k2 / k3 convolutions with 32 / 64 output channels per tile stage each input row once per
 //                 (dz, dy) and reuse it for the taps along x; 0 = re-stage per tap (round 1-3 form).  NOT bit-identical to each other
 //                 (the taps are summed in another order: fp32 rounding only)
-//   attn_prefill_qt : query tiles per wave of the prefill attention at head dim 64 (1, 2 or 3; bit-identical to each other)
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse, attn_prefill_qt; };
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse; };
 extern SfmiTune g_sfmi_tune;

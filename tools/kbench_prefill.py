@@ -14,14 +14,6 @@ for B, P in ((64, 160), (96, 160), (96, 300), (16, 400), (8, 811)):
     Kc, Vc = torch.empty(B, Lmax, D, device=dev), torch.empty(B, Lmax, D, device=dev)
     f = lambda: L.check(lib.sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(Kc), L.ptr(Vc), L.ptr(nv), L.ptr(y), B, P, D, H, Lmax, None, 0.0, 0,
                                                       L.stream_ptr()), "attn_prefill")
+    ms = ev_time(f, 20)
     fl = B * H * (P * (P + 1) / 2) * 4 * 64
-    ref = None
-    for qt in (1, 2, 3):        # query tiles per wave (knob attn_prefill_qt): bit-identical results, different workgroup shapes
-        L.check(lib.sfmi_tune_set(b"attn_prefill_qt", qt), "tune")
-        ms = ev_time(f, 20)
-        torch.cuda.synchronize()
-        same = "" if ref is None else ("  == qt 1" if torch.equal(ref, y) and torch.equal(Kref, Kc) else "  DIFFERS from qt 1")
-        if ref is None:
-            ref, Kref = y.clone(), Kc.clone()
-        print(f"B={B:3d} P={P:3d} qt={qt}: {ms * 1e3:8.1f} us  useful {fl / ms / 1e9:6.1f} TFLOP/s = {fl / ms / 1e9 / 157.3:.3f} of f32 MFMA{same}")
-L.check(lib.sfmi_tune_set(b"attn_prefill_qt", 2), "tune")
+    print(f"B={B:3d} P={P:3d}: {ms * 1e3:8.1f} us  useful {fl / ms / 1e9:6.1f} TFLOP/s = {fl / ms / 1e9 / 157.3:.3f} of f32 MFMA")
