@@ -130,7 +130,19 @@ int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int*
 int sfmi_sgemm_mfma_splits(int M, int N, int K);
 int sfmi_sgemm_mfma_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                         int ldc, int accumulate, const float* bias, int act, const float* resid, float* ws, long long ws_floats,
-                        void* stream);
+                        float drop_p, unsigned drop_seed, void* stream); /* drop_p > 0: nn.Dropout on the product (mingpt.py:90,105), counter-hash mask */
+/* the same product, work-balanced ("stream-K", csrc/sgemm_sk.hip), for the SMALL GEMMs of the training step at the YAML's batch
+ * size (M = B*L ~ 500 rows: 32-128 output tiles for 512 workgroup slots): K-chunks of tiles are dealt out evenly to 512 workgroups,
+ * tiles cut between workgroups are finished in the same launch (write-through slabs + tickets, slices added in k order:
+ * deterministic).  act: 0 none, 1 ReLU, 2 GELU(erf) (C2 != NULL also receives the pre-activation), 3 multiply by GELU'(aux[m][n]).
+ * slab (>= sfmi_sgemm_sk_slab_floats() floats) / cnt (>= sfmi_sgemm_sk_cnt_ints(M, N) ints, zeroed ONCE): caller-owned scratch,
+ * one pair per stream that runs these launches concurrently.  Replaces nn.Linear and its autograd, mingpt.py:46-111 */
+int sfmi_sgemm_sk_tile(int M, int N, int K);          /* [host] 2 = 128 x 128 workgroup tiles, 1 = 64 x 64 */
+long long sfmi_sgemm_sk_slab_floats(void);            /* [host] */
+long long sfmi_sgemm_sk_cnt_ints(int M, int N);       /* [host] */
+int sfmi_sgemm_sk_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, float* C2,
+                      int ldc, int accumulate, const float* bias, int act, const float* aux, const float* resid, float drop_p,
+                      unsigned drop_seed, float* slab, long long slab_floats, int* cnt, long long cnt_ints, void* stream);
 int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long long M, int V, int ld, void* stream); /* shapeformer.py:132-140 */
 /* decode step (M = B <= 192 rows per launch: workgroups of up to 6 row tiles, more rows = row groups in grid.z; larger batches run as
  * several chains; packed x/out/resid hold sfmi_decode_gemm_padded_rows(M) rows) */

@@ -90,6 +90,11 @@ PROTOTYPES = {
     "sfmi_gpt_embed_f32": (i32, [c_ptr] * 15 + [i32] * 5 + [c_ptr, i32, c_ptr]),
     "sfmi_gpt_rowprep_f32": (i32, [c_ptr] * 12 + [i32] * 5 + [c_ptr, i32, c_ptr]),
     "sfmi_sgemm_mfma_splits": (i32, [i32, i32, i32]),
+    "sfmi_sgemm_sk_tile": (i32, [i32, i32, i32]),
+    "sfmi_sgemm_sk_slab_floats": (i64, []),
+    "sfmi_sgemm_sk_cnt_ints": (i64, [i32, i32]),
+    "sfmi_sgemm_sk_f32": (i32, [i32] * 5 + [c_ptr, i32, c_ptr, i32, c_ptr, c_ptr, i32, i32, c_ptr, i32, c_ptr, c_ptr, f32, C.c_uint, c_ptr, i64, c_ptr, i64,
+                                c_ptr]),
     "sfmi_sgemm_mfma_f32": (i32, [i32] * 5 + [c_ptr, i32, c_ptr, i32, c_ptr, i32, i32, c_ptr, i32, c_ptr, c_ptr, i64, f32, C.c_uint, c_ptr]),
     "sfmi_ce_rows_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr]),
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr, c_ptr]),

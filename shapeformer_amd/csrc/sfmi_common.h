@@ -93,5 +93,8 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   conv_xreuse : 1 (default) = stride-1 k2 / k3 convolutions with 32 / 64 output channels per tile stage each input row once per
 //                 (dz, dy) and reuse it for the taps along x; 0 = re-stage per tap (round 1-3 form).  NOT bit-identical to each other
 //                 (the taps are summed in another order: fp32 rounding only)
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse; };
+//   sk_grid     : workgroups of the work-balanced training GEMM (csrc/sgemm_sk.hip): 512 (default: two per CU) / 256 / 768 / 1024.  NOT
+//                 bit-identical to each other (a tile's K range is cut at other places: fp32 rounding only)
+//   sk_tile     : its workgroup tile: 0 = by output size (default), 1 = 64 x 64, 2 = 128 x 128 (same remark)
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse, sk_grid, sk_tile; };
 extern SfmiTune g_sfmi_tune;

@@ -115,6 +115,9 @@ class GradBuckets:
             self.avg = dist.get_backend() == "nccl"     # RCCL averages in the collective; gloo has no AVG
         self.profile_waits = bool(profile_waits)
         self._wait_events = []                           # (before, after) HIP-event pairs around the waits (profile_waits only)
+        self._gather_events = []                         # the same around the waits for parameter all-gathers (mode rs_ag)
+        self._gather_steps = 0                           # optimizer steps those events belong to
+        self._param_works = {}                           # bucket name -> pending all-gather of its updated parameters
 
     def _staged(self):
         """gloo has no device path for reduce_scatter_tensor / all_gather_into_tensor: device buffers go through the host
@@ -183,30 +186,62 @@ class GradBuckets:
         self.pending, self.done = [], set()
         return order
 
+    def _all_gather_bucket(self, flat, name):
+        lo, hi = self.ranges[name]
+        slo, shi = self.shard(name)
+        if self._staged():
+            return _StagedWork(self.dist, "ag", flat, (lo, hi), (slo, shi), None)
+        return self.dist.all_gather_into_tensor(flat[lo:hi], flat[slo:shi], async_op=True)
+
     def all_gather_flat(self, flat, profile=False):
-        """In-place all-gather of every reduce-scattered bucket of `flat` - any buffer laid out like the gradient buffer (the
-        updated parameters written over the consumed gradients; the AdamW moments when a checkpoint is written): rank r's slice
-        of each bucket goes to every rank.  All collectives are launched, then waited for."""
+        """In-place all-gather of every reduce-scattered bucket of `flat` - any buffer laid out like the gradient buffer (e.g. the
+        AdamW moments when a checkpoint is written): rank r's slice of each bucket goes to every rank.  All collectives are
+        launched, then waited for (blocking form; the parameters of a training step use launch_param_gathers / wait_params)."""
         if not self.active or self.mode != "rs_ag":
             return
-        works = []
-        for name, (lo, hi) in self.ranges.items():
-            if self.sharded(name):
-                slo, shi = self.shard(name)
-                if self._staged():
-                    works.append(_StagedWork(self.dist, "ag", flat, (lo, hi), (slo, shi), None))
-                else:
-                    works.append(self.dist.all_gather_into_tensor(flat[lo:hi], flat[slo:shi], async_op=True))
+        works = [self._all_gather_bucket(flat, name) for name in self.ranges if self.sharded(name)]
         ev = self._bracket() if profile else None
         for w in works:
             w.wait()
         if ev is not None:
             ev[1].record()
-            self._gather_events = getattr(self, "_gather_events", []) + [ev]
+            self._gather_events.append(ev)
+            self._gather_steps += 1
 
     def all_gather_params(self):
-        """mode rs_ag, after the sharded optimizer step wrote the updated parameters of this rank's slices into the flat buffer."""
+        """mode rs_ag, blocking form: all buckets gathered before the call returns to the compute stream."""
         self.all_gather_flat(self.flat, profile=True)
+
+    def launch_param_gathers(self, order=None):
+        """mode rs_ag, after the sharded optimizer step wrote the updated parameters of this rank's slices into the flat buffer:
+        launch one all-gather per bucket in the order the NEXT forward reads the parameters (`order`: bucket names; default = the
+        bucket order) and return without waiting.  RCCL runs them back to back on its own stream; `wait_params(name)` makes the
+        compute stream wait for ONE bucket right before the first kernel that reads it, so the gather of bucket k rides under the
+        forward kernels of the buckets before it.  -> the names of the buckets whose parameters are now in flight."""
+        if not self.active or self.mode != "rs_ag":
+            return []
+        assert not self._param_works, "launch_param_gathers: the previous step's gathers were never consumed (wait_params / drain_params)"
+        for name in (order or list(self.ranges)):
+            if self.sharded(name):
+                self._param_works[name] = self._all_gather_bucket(self.flat, name)
+        self._gather_steps += 1
+        return list(self._param_works)
+
+    def wait_params(self, name):
+        """Wait (stream-ordered for RCCL) for the parameter all-gather of bucket `name`; True when there was one pending - the
+        caller then copies the bucket's gathered values out of the flat buffer.  The stall is what `gather_ms()` reports."""
+        work = self._param_works.pop(name, None)
+        if work is None:
+            return False
+        ev = self._bracket()
+        work.wait()
+        if ev is not None:
+            ev[1].record()
+            self._gather_events.append(ev)
+        return True
+
+    def params_in_flight(self):
+        return list(self._param_works)
 
     def wait_ms(self, reset=True):
         """Mean time per finish() the compute stream spent waiting for gradient collectives since the last reset (ms); None
@@ -220,12 +255,13 @@ class GradBuckets:
         return ms
 
     def gather_ms(self, reset=True):
-        """The same for the parameter all-gathers of mode rs_ag."""
-        evs = getattr(self, "_gather_events", [])
+        """The same for the parameter all-gathers of mode rs_ag: mean EXPOSED wait per optimizer step (the sum of the per-bucket
+        stalls of a step when the gathers are overlapped with the next forward)."""
+        evs = self._gather_events
         if not evs:
             return None
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        ms = sum(a.elapsed_time(b) for a, b in evs) / max(self._gather_steps, 1)
         if reset:
-            self._gather_events = []
+            self._gather_events, self._gather_steps = [], 0
         return ms

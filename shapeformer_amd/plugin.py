@@ -24,6 +24,7 @@ import torch
 import yaml
 
 from . import weights as W
+from .vqdif import LocalDecoder, LocalPoolPointnet, Quantizer
 
 
 # --------------------------------------------------------------------------- config loading
@@ -82,20 +83,24 @@ class VQDIFModel:
     def __init__(self, Xct_as_Xbd=False, encoder_opt=None, decoder_opt=None, quantizer_opt=None, vq_beta=1.0,
                  optim_opt=None, ckpt_path=None, opt=None, state_dict=None, device=None):
         from .vqdif import VQDIF
-        ek, dk, qk = encoder_opt["kwargs"], decoder_opt["kwargs"], quantizer_opt["kwargs"]
-        assert encoder_opt["class"].endswith("enc.LocalPoolPointnet") and decoder_opt["class"].endswith("dec.LocalDecoder")
-        assert quantizer_opt["class"].endswith("quantizer.Quantizer")
-        assert ek["hidden_dim"] == 32 and ek["c_dim"] == 32 and ek["grid_resolution"] == 64 and ek["plane_type"] == "grid"
-        steps = ek["downsampler_kwargs"]["downsample_steps"]
-        assert dk["upsampler_kwargs"]["upsampler_steps"] == steps and dk["hidden_size"] == 32 and dk["c_dim"] == 32
-        res = 64 >> steps
-        assert res in (16, 32) and qk["n_embd"] == 32 << steps, "shipped configs: res16 (d=128) / res32 (d=64)"
+        dev = device or _device()
         if state_dict is None and ckpt_path and os.path.exists(ckpt_path):
             state_dict = load_pl_state_dict(ckpt_path)
+        # the three sub-modules are what the YAML names (vqdif.py:28-32: sysutil.instantiate_from_opt of encoder_opt /
+        # decoder_opt / quantizer_opt); hyper-parameters the kernels are not built for raise a ValueError naming the limit
+        mods = {}
+        for key, o, prefix in (("encoder", encoder_opt, "encoder."), ("quantizer", quantizer_opt, "quantizer."), ("decoder", decoder_opt, "decoder.")):
+            if o is None or o.get("class") is None:
+                raise ValueError(f"VQDIF: {key}_opt with a `class` entry is required (the path always encodes, quantizes and decodes)")
+            kw = dict(o.get("kwargs") or {}, device=dev)
+            if state_dict is not None:
+                kw["state_dict"] = {k: v for k, v in state_dict.items() if k.startswith(prefix)}
+            mods[key] = load_object(o["class"])(**kw)
         self.hparams = dict(encoder_opt=encoder_opt, decoder_opt=decoder_opt, quantizer_opt=quantizer_opt, vq_beta=vq_beta,
                             optim_opt=optim_opt)
         self.Xct_as_Xbd = Xct_as_Xbd
-        self.core = VQDIF(state_dict, res=res, device=device or _device(), vocab_size=qk["vocab_size"])
+        self.core = VQDIF(device=dev, **mods)
+        self.encoder, self.quantizer, self.decoder = self.core.encoder, self.core.quantizer, self.core.decoder
 
     def __getattr__(self, name):  # encode / quantize_cloud / decode / decode_index / forward ...
         return getattr(self.core, name)
@@ -491,6 +496,9 @@ def _cb(name):
 
 
 REGISTRY = {
+    "shapeformer.models.vqdif.enc.LocalPoolPointnet": LocalPoolPointnet,
+    "shapeformer.models.vqdif.quantizer.Quantizer": Quantizer,
+    "shapeformer.models.vqdif.dec.LocalDecoder": LocalDecoder,
     "shapeformer.models.vqdif.vqdif.VisSparseRecon3D": _cb("VisSparseRecon3D"),
     "shapeformer.models.shapeformer.shapeformer.VisShapeFormer": _cb("VisShapeFormer"),
     "shapeformer.models.vqdif.vqdif.VQDIF": VQDIFModel,

@@ -52,75 +52,64 @@ class _Conv:
         self.w_up = torch.from_numpy(out).to(dev)
 
 
-class VQDIF:
-    """Inference-side VQDIF (res16: d=128, 2 down/up steps; res32: d=64, 1 step)."""
-    FUSE_DOWN0 = True     # False: the dense-grid route (mean grid + sfmi_conv3d_cl_f32), kept as the cross-check of the fused first conv
+class _Workspace:
+    """Named device buffers, reused from call to call (no allocation on the steady-state path)."""
 
-    G = 64
+    def __init__(self, dev):
+        self.dev, self.bufs = dev, {}
+
+    def buf(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, device=self.dev, dtype=dtype)
+            self.bufs[key] = t
+        return t
+
+
+def _dev_of(device):
+    dev = torch.device(device if device is not None else "cuda:0")
+    if dev.type != "cuda":
+        raise L.SfmiError("the VQDIF modules need a HIP device (no CPU fallback)")
+    return dev
+
+
+def _twice(p, dev):
+    """[-.5,.5]^3 module coordinates -> the [-1,1]^3 the kernels take (they halve again: vqdif.py:36,71).  p + p on the device:
+    exact in f32."""
+    p = torch.as_tensor(p).to(dev, torch.float32).contiguous()
+    out = torch.empty_like(p)
+    L.check(L.lib().sfmi_add_f32(L.ptr(p), L.ptr(p), L.ptr(out), p.numel(), L.stream_ptr()), "sfmi_add_f32")
+    return out
+
+
+def _np_sd(sd):
+    return {k: np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in sd.items()}
+
+
+def _limit(cond, what):
+    """Hyper-parameters outside what the HIP kernels are built for: say which, and what the limit is."""
+    if not cond:
+        raise ValueError(f"shapeformer_amd: unsupported hyper-parameter: {what}")
+
+
+def _sub_sd(state_dict, prefix, res):
+    """Sub-module weights: `state_dict` with or without the `prefix` ("encoder." ...); None -> the hash-generated
+    weights of the full VQDIF of that latent resolution (the same values VQDIF(res=...) builds)."""
+    if state_dict is None:
+        state_dict = W.make_state_dict(W.vqdif_spec(res))
+    if any(k.startswith(prefix) for k in state_dict):
+        return {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+    return dict(state_dict)
+
+
+class _GridOps:
+    """Convolution / GroupNorm helpers shared by the encoder's Downsampler and the decoder's UNet3D + Upsampler."""
     GROUPS = 8
     EPS = 1e-5
 
-    def __init__(self, state_dict=None, res=16, device="cuda:0", vocab_size=4096):
-        self.dev = torch.device(device)
-        if self.dev.type != "cuda":
-            raise L.SfmiError("VQDIF needs a HIP device (no CPU fallback)")
-        L.lib()
-        self.res = res
-        self.steps = 2 if res == 16 else 1
-        self.d = 32 * 2 ** self.steps
-        self.K = vocab_size
-        sd = state_dict if state_dict is not None else W.make_state_dict(W.vqdif_spec(res))
-        self.load_state_dict(sd)
-        self._ws = {}
-
-    # ------------------------------------------------------------------ weights
-    def state_dict_np(self):
-        """The (numpy, reference-layout) state dict the packed device weights were built from."""
-        return self._sd
-
-    def load_state_dict(self, sd):
-        dev = self.dev
-        lib = L.lib()
-        self._sd = {k: np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in sd.items()}
-        cat = lambda fmt, n=5: np.ascontiguousarray(np.stack([_np(sd, fmt.format(i)) for i in range(n)]))
-        enc = np.empty(lib.sfmi_enc_pack_floats(), np.float32)
-        a = [_np(sd, "encoder.fc_pos.weight"), _np(sd, "encoder.fc_pos.bias"), cat("encoder.blocks.{}.fc_0.weight"),
-             cat("encoder.blocks.{}.fc_0.bias"), cat("encoder.blocks.{}.fc_1.weight"), cat("encoder.blocks.{}.fc_1.bias"),
-             cat("encoder.blocks.{}.shortcut.weight"), _np(sd, "encoder.fc_c.weight"), _np(sd, "encoder.fc_c.bias"), enc]
-        L.check(lib.sfmi_enc_pack_weights(*[x.ctypes.data for x in a]), "sfmi_enc_pack_weights")
-        self.enc_w = torch.from_numpy(enc).to(dev)
-        self.down = []
-        for s in range(self.steps):
-            self.down.append(_Conv(sd, f"encoder.downsampler.blocks.{2 * s}.", dev, 2, 2, 0))
-            self.down.append(_Conv(sd, f"encoder.downsampler.blocks.{2 * s + 1}.", dev, 1, 1, 0))
-        cb = _np(sd, "quantizer.embedding.weight")
-        assert cb.shape == (self.K, self.d), cb.shape
-        pk = np.empty(lib.sfmi_vq_pack_floats(self.K, self.d), np.float32)
-        L.check(lib.sfmi_vq_pack_codebook(cb.ctypes.data, self.K, self.d, pk.ctypes.data), "sfmi_vq_pack_codebook")
-        self.codebook = torch.from_numpy(cb).to(dev)
-        self.codebook_packed = torch.from_numpy(pk).to(dev)
-        u = "decoder.unet3d."
-        self.unet = {}
-        for name in ("encoders.0", "encoders.1", "encoders.2", "decoders.0", "decoders.1"):
-            for sc in ("SingleConv1", "SingleConv2"):
-                self.unet[f"{name}.{sc}"] = _Conv(sd, f"{u}{name}.basic_module.{sc}.", dev, 3, 1, 1)
-        self.unet_final = _Conv(sd, u + "final_conv.", dev, 1, 1, 0)
-        self.up = []
-        for s in range(self.steps):
-            self.up.append(_Conv(sd, f"decoder.upsampler.blocks.{3 * s + 1}.", dev, 3, 1, 1))
-            self.up[-1].pack_subpixel(dev)
-            self.up.append(_Conv(sd, f"decoder.upsampler.blocks.{3 * s + 2}.", dev, 3, 1, 1))
-        from .ops import sdf_pack_weights
-        self.sdf_w = torch.from_numpy(sdf_pack_weights(sd)).to(dev)
-
-    # ------------------------------------------------------------------ primitives
     def _buf(self, name, shape, dtype=torch.float32):
-        key = (name, tuple(shape), dtype)
-        t = self._ws.get(key)
-        if t is None:
-            t = torch.empty(shape, device=self.dev, dtype=dtype)
-            self._ws[key] = t
-        return t
+        return self.ws.buf(name, shape, dtype)
 
     def _conv(self, x, cv, name, scale=None, shift=None, up=0, relu=True, bias=None):
         B, Di, Hi, Wi, Cin = x.shape
@@ -155,9 +144,54 @@ class VQDIF:
         L.check(L.lib().sfmi_affine_cl_f32(L.ptr(x), L.ptr(sc), L.ptr(sh), L.ptr(y), B, V, C, L.stream_ptr()), "sfmi_affine_cl_f32")
         return y
 
-    # ------------------------------------------------------------------ encoder (a1-a8)
+
+class LocalPoolPointnet(_GridOps):
+    """`shapeformer.models.vqdif.enc.LocalPoolPointnet` (enc.py:11-140): ctor kwargs, state-dict keys (`fc_pos.*`,
+    `blocks.{0-4}.*`, `fc_c.*`, `downsampler.blocks.*`) and call contract `encoder(p) -> (fea (B,k*C,R,R,R), mask (B,R,R,R) bool)`
+    with p = Xbd / 2 in [-.5,.5]^3 (vqdif.py:35-37).  One C-ABI call runs the point MLP, the four local max-pools, the
+    per-cell mean and the first Downsampler convolution (csrc/encoder.hip); the remaining Downsampler convolutions and the
+    GroupNorms are csrc/conv3d.hip.  Built for the shipped hyper-parameters; anything else raises ValueError naming the limit."""
+    FUSE_DOWN0 = True     # False: the dense-grid route (mean grid + sfmi_conv3d_cl_f32), kept as the cross-check of the fused first conv
+    G = 64
+
+    def __init__(self, c_dim=128, dim=3, hidden_dim=128, scatter_type="max", downsampler=False, downsampler_kwargs=None,
+                 c2i_order="original", grid_resolution=None, plane_type="grid", padding=0.1, n_blocks=5, state_dict=None,
+                 device=None, workspace=None):
+        _limit(c_dim == 32 and hidden_dim == 32, f"LocalPoolPointnet(c_dim={c_dim}, hidden_dim={hidden_dim}): the point-MLP kernel is built for 32 / 32")
+        _limit(dim == 3 and n_blocks == 5, f"LocalPoolPointnet(dim={dim}, n_blocks={n_blocks}): 3-D points, 5 ResnetBlockFC stages")
+        _limit(scatter_type == "max", f"LocalPoolPointnet(scatter_type={scatter_type!r}): only 'max' local pooling")
+        _limit(c2i_order == "original", f"LocalPoolPointnet(c2i_order={c2i_order!r}): only 'original' (x fastest)")
+        _limit(grid_resolution == 64, f"LocalPoolPointnet(grid_resolution={grid_resolution}): the cell sort is built for the 64^3 feature grid")
+        _limit("grid" in plane_type, f"LocalPoolPointnet(plane_type={plane_type!r}): only the 3-D 'grid' feature volume")
+        _limit(abs(padding - 0.1) < 1e-12, f"LocalPoolPointnet(padding={padding}): the coordinate normalisation is built for 0.1")
+        dk = downsampler_kwargs or {}
+        _limit(bool(downsampler) and dk.get("in_channels") == 32 and dk.get("downsample_steps") in (1, 2),
+               f"LocalPoolPointnet(downsampler={downsampler}, downsampler_kwargs={dk}): a Downsampler of 1 or 2 steps on 32 channels")
+        self.c_dim, self.hidden_dim, self.reso_grid, self.plane_type, self.padding = c_dim, hidden_dim, grid_resolution, plane_type, padding
+        self.steps = int(dk["downsample_steps"])
+        self.res = self.G >> self.steps
+        self.dev = _dev_of(device)
+        L.lib()
+        self.ws = workspace or _Workspace(self.dev)
+        self.load_state_dict(_sub_sd(state_dict, "encoder.", self.res))
+
+    def load_state_dict(self, sd):
+        lib, dev = L.lib(), self.dev
+        self._sd = _np_sd(sd)
+        cat = lambda fmt, n=5: np.ascontiguousarray(np.stack([_np(sd, fmt.format(i)) for i in range(n)]))
+        enc = np.empty(lib.sfmi_enc_pack_floats(), np.float32)
+        a = [_np(sd, "fc_pos.weight"), _np(sd, "fc_pos.bias"), cat("blocks.{}.fc_0.weight"),
+             cat("blocks.{}.fc_0.bias"), cat("blocks.{}.fc_1.weight"), cat("blocks.{}.fc_1.bias"),
+             cat("blocks.{}.shortcut.weight"), _np(sd, "fc_c.weight"), _np(sd, "fc_c.bias"), enc]
+        L.check(lib.sfmi_enc_pack_weights(*[x.ctypes.data for x in a]), "sfmi_enc_pack_weights")
+        self.enc_w = torch.from_numpy(enc).to(dev)
+        self.down = []
+        for s in range(self.steps):
+            self.down.append(_Conv(sd, f"downsampler.blocks.{2 * s}.", dev, 2, 2, 0))
+            self.down.append(_Conv(sd, f"downsampler.blocks.{2 * s + 1}.", dev, 1, 1, 0))
+
     def encode_cl(self, cloud):
-        """cloud (B,T,3) in [-1,1] -> latent (B,R,R,R,d) channels-last, mask (B,R,R,R) uint8."""
+        """cloud (B,T,3) in [-1,1] -> latent (B,R,R,R,d) channels-last, mask (B,R,R,R) uint8 (workspace views)."""
         cloud = cloud.to(self.dev, torch.float32).contiguous()
         B, T, _ = cloud.shape
         R = self.res
@@ -188,13 +222,49 @@ class VQDIF:
         latent = self._affine(x, sc, sh, "latent")
         return latent, mask
 
-    def encode(self, Xbd):
-        """vqdif.py:35-37 -> (grid_feat (B,d,R,R,R) view, grid_mask (B,R,R,R) bool)."""
-        lat, mask = self.encode_cl(Xbd)
-        return lat.permute(0, 4, 1, 2, 3).clone(), mask.bool()      # fresh tensors: the *_cl / *_dev paths return workspace views
+    def forward(self, p):
+        """enc.py:115-140: p (B,T,3) in [-.5,.5]^3 -> (fea (B,k*C,R,R,R), mask (B,R,R,R) bool), fresh tensors.  The kernels take
+        the cloud in [-1,1] and halve it themselves; the doubling here (p + p) is exact in f32."""
+        lat, mask = self.encode_cl(_twice(p, self.dev))
+        return lat.permute(0, 4, 1, 2, 3).clone(), mask.bool()
 
-    # ------------------------------------------------------------------ quantizer (a9, a10)
+    __call__ = forward
+
+
+class Quantizer:
+    """`shapeformer.models.vqdif.quantizer.Quantizer` (quantizer.py:6-89): `Quantizer(vocab_size, n_embd, gamma, x_dim)`,
+    state-dict keys `embedding.weight`, `N`, `z_avg`; `quantizer(x (B,d,R,R,R)) -> (quant_feat, quant_feat_st, idx (B,R,R,R)
+    int64, quant_diff)`, `get_code(idx) -> (B,d,R,R,R)`.  The nearest-code search is csrc/vq_argmin.hip (MFMA distance tiles +
+    wavefront argmin, lowest index on ties = torch.max on CPU); this is the EVAL-mode module - the EMA codebook update of
+    training mode (quantizer.py:68-83) lives in train_vqdif.VQDIFTrainer."""
+    training = False
+
+    def __init__(self, vocab_size, n_embd, gamma=0.99, x_dim=3, state_dict=None, device=None, workspace=None):
+        _limit(n_embd in (64, 128), f"Quantizer(n_embd={n_embd}): the distance kernel is built for 64 / 128 channels")
+        _limit(vocab_size % 32 == 0 and vocab_size > 0, f"Quantizer(vocab_size={vocab_size}): a positive multiple of 32 codes")
+        _limit(x_dim == 3, f"Quantizer(x_dim={x_dim}): 3-D latent grids")
+        self.vocab_size, self.n_embd, self.gamma, self.x_dim = vocab_size, n_embd, gamma, x_dim
+        self.K, self.d = vocab_size, n_embd
+        self.dev = _dev_of(device)
+        L.lib()
+        self.ws = workspace or _Workspace(self.dev)
+        self.load_state_dict(_sub_sd(state_dict, "quantizer.", 16 if n_embd == 128 else 32))
+
+    def _buf(self, name, shape, dtype=torch.float32):
+        return self.ws.buf(name, shape, dtype)
+
+    def load_state_dict(self, sd):
+        lib = L.lib()
+        self._sd = _np_sd(sd)
+        cb = _np(sd, "embedding.weight")
+        _limit(cb.shape == (self.K, self.d), f"Quantizer: embedding.weight {cb.shape} != (vocab_size, n_embd) = {(self.K, self.d)}")
+        pk = np.empty(lib.sfmi_vq_pack_floats(self.K, self.d), np.float32)
+        L.check(lib.sfmi_vq_pack_codebook(cb.ctypes.data, self.K, self.d, pk.ctypes.data), "sfmi_vq_pack_codebook")
+        self.codebook = torch.from_numpy(cb).to(self.dev)
+        self.codebook_packed = torch.from_numpy(pk).to(self.dev)
+
     def quantize_cl(self, latent):
+        """channels-last latent (...,d) -> nearest-code indices (...) int32 (workspace view)."""
         N = latent.numel() // self.d
         idx = self._buf("vq_idx", (N,), torch.int32)
         L.check(L.lib().sfmi_vq_argmin_f32(L.ptr(latent), L.ptr(self.codebook_packed), L.ptr(idx), None, N, self.K, self.d,
@@ -202,43 +272,74 @@ class VQDIF:
         return idx.view(latent.shape[:-1])
 
     def get_code_cl(self, ind):
-        """quantizer.py:19-30 -> channels-last (B,R,R,R,d)."""
+        """quantizer.py:19-30 -> channels-last (B,R,R,R,d) (workspace view)."""
         ind32 = ind.to(self.dev, torch.int32).contiguous()
         N = ind32.numel()
         out = self._buf("vq_code", tuple(ind32.shape) + (self.d,))
         L.check(L.lib().sfmi_vq_gather_f32(L.ptr(self.codebook), L.ptr(ind32), L.ptr(out), N, self.d, L.stream_ptr()), "sfmi_vq_gather_f32")
         return out
 
-    def mode_of(self, idx, name="mode", rows=1):
-        hist = self._buf("hist", (rows * (self.K + 1),), torch.int32)
-        mode = self._buf(name, (rows,), torch.int32)
-        L.check(L.lib().sfmi_mode_i32(L.ptr(idx), idx.numel(), self.K + 1, rows, L.ptr(hist), L.ptr(mode), L.stream_ptr()), "sfmi_mode_i32")
-        return mode
+    def get_code(self, ind, bchw=True):
+        """quantizer.py:19-30: code vectors of an index grid, (B,d,R,R,R) (bchw) or (B,R,R,R,d); a fresh tensor."""
+        code = self.get_code_cl(torch.as_tensor(ind))
+        return code.permute(0, 4, 1, 2, 3).contiguous() if bchw else code.clone()
 
-    def quantize_cloud_dev(self, cloud, per_shape_mode=False):
-        """Device-resident quantize_cloud: (quant_ind int32 (B,R,R,R), mode int32, raw idx, mask u8, latent).
+    def forward(self, grid_feat):
+        """quantizer.py:31-89 (eval): (B,d,R,R,R) -> (quant_feat, quant_feat_st, encoding_indices int64, quant_diff)."""
+        if self.training:
+            raise L.SfmiError("Quantizer: the training-mode EMA update runs in train_vqdif.VQDIFTrainer; this module is eval-mode")
+        x = torch.as_tensor(grid_feat).to(self.dev, torch.float32)
+        _limit(x.dim() == 5 and x.shape[1] == self.d, f"Quantizer input {tuple(x.shape)}: a (B,{self.d},R,R,R) grid")
+        lat = x.permute(0, 2, 3, 4, 1).contiguous()
+        idx = self.quantize_cl(lat)
+        code = self.get_code_cl(idx)
+        q = code.permute(0, 4, 1, 2, 3).contiguous()
+        return q, q.clone(), idx.long(), ((lat - code) ** 2).mean()      # eval: quant_feat_st == quant_feat numerically (:86-87)
 
-        per_shape_mode=False reproduces the reference on a batch (ONE mode over the whole batch, vqdif.py:53);
-        True gives every shape its own empty code = the reference run shape-by-shape at batch size 1, which is
-        how its inference drivers call it (shapeformer.py:227 asserts batch_size == 1)."""
-        latent, mask = self.encode_cl(cloud)
-        raw = self.quantize_cl(latent)
-        rows = raw.shape[0] if per_shape_mode else 1
-        mode = self.mode_of(raw, rows=rows)
-        q = self._buf("quant_ind", tuple(raw.shape), torch.int32)
-        L.check(L.lib().sfmi_apply_mask_i32(L.ptr(raw), L.ptr(mask), L.ptr(mode), L.ptr(q), raw.numel(), rows, L.stream_ptr()), "sfmi_apply_mask_i32")
-        return q, mode, raw, mask, latent
+    __call__ = forward
 
-    def quantize_cloud(self, cloud):
-        """vqdif.py:50-58 -> (quant_ind (B,R,R,R) int64, mode, dict(quant_ind, grid_mask, quant_feat...))."""
-        q, mode, raw, mask, latent = self.quantize_cloud_dev(cloud)
-        code = self.get_code_cl(raw)
-        # encode_quant's dict (vqdif.py:39-48); fresh tensors (the *_dev path returns views of a reused workspace)
-        enc = dict(quant_feat=code.permute(0, 4, 1, 2, 3).clone(), quant_ind=raw.long(), quant_diff=((latent - code) ** 2).mean(),
-                   grid_mask=mask.bool(), grid_feat=latent.permute(0, 4, 1, 2, 3).clone())
-        return q.long(), mode.long()[0], enc
 
-    # ------------------------------------------------------------------ decoder grid (a21, a22)
+class LocalDecoder(_GridOps):
+    """`shapeformer.models.vqdif.dec.LocalDecoder` (dec.py:10-100): ctor kwargs, state-dict keys (`unet3d.*`, `upsampler.*`,
+    `fc_c.{0-4}.*`, `fc_p.*`, `blocks.{0-4}.*`, `fc_out.*`), `decoder(p (B,N,3) in [-.5,.5]^3, c_grid (B,d,R,R,R)) -> (B,N,1)`
+    logits.  UNet3D + Upsampler are csrc/conv3d.hip; trilinear gather + the 17-layer point MLP are ONE kernel (csrc/sdf_query.hip)."""
+
+    def __init__(self, dim=3, c_dim=128, unet3d=False, unet3d_kwargs=None, upsampler=False, upsampler_kwargs=None,
+                 hidden_size=256, n_blocks=5, leaky=False, sample_mode="bilinear", padding=0.1, state_dict=None, device=None,
+                 workspace=None):
+        _limit(dim == 3 and c_dim == 32 and hidden_size == 32 and n_blocks == 5,
+               f"LocalDecoder(dim={dim}, c_dim={c_dim}, hidden_size={hidden_size}, n_blocks={n_blocks}): the fused query kernel is built for 3 / 32 / 32 / 5")
+        _limit(not leaky and sample_mode == "bilinear" and abs(padding - 0.1) < 1e-12,
+               f"LocalDecoder(leaky={leaky}, sample_mode={sample_mode!r}, padding={padding}): ReLU, trilinear ('bilinear') sampling, padding 0.1")
+        uk, pk = unet3d_kwargs or {}, upsampler_kwargs or {}
+        d = uk.get("in_channels")
+        _limit(bool(unet3d) and uk.get("num_levels") == 3 and d in (64, 128) and uk.get("f_maps") == d and uk.get("out_channels") == d,
+               f"LocalDecoder(unet3d={unet3d}, unet3d_kwargs={uk}): a 3-level UNet3D with f_maps = in = out = 64 or 128")
+        _limit(bool(upsampler) and pk.get("in_channels") == d and 32 << int(pk.get("upsampler_steps", 0)) == d,
+               f"LocalDecoder(upsampler={upsampler}, upsampler_kwargs={pk}): an Upsampler from {d} channels down to 32 (steps = log2(d / 32))")
+        self.c_dim, self.n_blocks, self.sample_mode, self.padding = c_dim, n_blocks, sample_mode, padding
+        self.d, self.steps = d, int(pk["upsampler_steps"])
+        self.dev = _dev_of(device)
+        L.lib()
+        self.ws = workspace or _Workspace(self.dev)
+        self.load_state_dict(_sub_sd(state_dict, "decoder.", 64 >> self.steps))
+
+    def load_state_dict(self, sd):
+        dev = self.dev
+        self._sd = _np_sd(sd)
+        self.unet = {}
+        for name in ("encoders.0", "encoders.1", "encoders.2", "decoders.0", "decoders.1"):
+            for sc in ("SingleConv1", "SingleConv2"):
+                self.unet[f"{name}.{sc}"] = _Conv(sd, f"unet3d.{name}.basic_module.{sc}.", dev, 3, 1, 1)
+        self.unet_final = _Conv(sd, "unet3d.final_conv.", dev, 1, 1, 0)
+        self.up = []
+        for s in range(self.steps):
+            self.up.append(_Conv(sd, f"upsampler.blocks.{3 * s + 1}.", dev, 3, 1, 1))
+            self.up[-1].pack_subpixel(dev)
+            self.up.append(_Conv(sd, f"upsampler.blocks.{3 * s + 2}.", dev, 3, 1, 1))
+        from .ops import sdf_pack_weights
+        self.sdf_w = torch.from_numpy(sdf_pack_weights(sd, prefix="")).to(dev)
+
     def _single_gcr(self, x, cv, name):
         sc, sh = self._gn(x, cv.gamma, cv.beta, name)
         return self._conv(x, cv, name, sc, sh, relu=True)
@@ -275,6 +376,154 @@ class VQDIF:
         if final_affine:
             return self._affine(x, sc, sh, "dec_grid")
         return x, sc, sh
+
+    def query(self, grid_cl, Xtg=None, grid_Q=None, sigmoid=False):
+        """Occupancy logits of points Xtg (B,N,3) in [-1,1]^3, or of the makeGrid 'ij' Q^3 lattice, on a decoder feature grid."""
+        from . import ops
+        if grid_Q is not None:
+            axis = torch.from_numpy(np.linspace(-1.0, 1.0, grid_Q).astype(np.float32)).to(self.dev)
+            return ops.sdf_query_grid(axis, grid_cl, self.sdf_w, sigmoid=sigmoid)
+        return ops.sdf_query(Xtg.to(self.dev, torch.float32), grid_cl, self.sdf_w, sigmoid=sigmoid)
+
+    def forward(self, p, c_grid, **kwargs):
+        """dec.py:71-100: p (B,N,3) in [-.5,.5]^3 (= Xtg / 2, vqdif.py:71), c_grid (B,d,R,R,R) -> logits (B,N,1)."""
+        c = torch.as_tensor(c_grid).to(self.dev, torch.float32)
+        _limit(c.dim() == 5 and c.shape[1] == self.d, f"LocalDecoder feature grid {tuple(c.shape)}: (B,{self.d},R,R,R)")
+        grid = self.decoder_grid_cl(c.permute(0, 2, 3, 4, 1).contiguous())
+        return self.query(grid, _twice(p, self.dev))
+
+    __call__ = forward
+
+
+class VQDIF:
+    """Inference-side VQDIF (res16: d=128, 2 down/up steps; res32: d=64, 1 step), composed - as the reference composes it,
+    vqdif.py:28-32 - of an encoder, a quantizer and a decoder module that share one workspace.  Built either from the latent
+    resolution (the shipped configurations) or from three already-instantiated modules (plugin.VQDIFModel: the YAML's
+    `encoder_opt` / `quantizer_opt` / `decoder_opt` classes)."""
+
+    G = 64
+    GROUPS = _GridOps.GROUPS
+    EPS = _GridOps.EPS
+
+    def __init__(self, state_dict=None, res=16, device="cuda:0", vocab_size=4096, encoder=None, quantizer=None, decoder=None):
+        self.dev = _dev_of(device)
+        L.lib()
+        if encoder is not None:
+            res = encoder.res
+        self.res = res
+        self.steps = 2 if res == 16 else 1
+        self.d = 32 * 2 ** self.steps
+        self.K = quantizer.K if quantizer is not None else vocab_size
+        self.ws = _Workspace(self.dev)
+        sd = state_dict if state_dict is not None else (W.make_state_dict(W.vqdif_spec(res)) if None in (encoder, quantizer, decoder) else None)
+        d, steps = self.d, self.steps
+        self.encoder = encoder or LocalPoolPointnet(c_dim=32, hidden_dim=32, grid_resolution=64, plane_type="grid", downsampler=True,
+                                                    downsampler_kwargs=dict(in_channels=32, downsample_steps=steps), state_dict=sd,
+                                                    device=self.dev)
+        self.quantizer = quantizer or Quantizer(self.K, d, state_dict=sd, device=self.dev)
+        self.decoder = decoder or LocalDecoder(c_dim=32, hidden_size=32, unet3d=True, upsampler=True, sample_mode="bilinear",
+                                               unet3d_kwargs=dict(num_levels=3, f_maps=d, in_channels=d, out_channels=d),
+                                               upsampler_kwargs=dict(in_channels=d, upsampler_steps=steps), state_dict=sd, device=self.dev)
+        _limit(self.encoder.res == res and self.quantizer.d == d and self.decoder.d == d and self.decoder.steps == steps,
+               f"VQDIF: encoder latent {self.encoder.res}^3 x {32 << self.encoder.steps}, quantizer n_embd {self.quantizer.d}, decoder "
+               f"channels {self.decoder.d} do not describe one autoencoder")
+        for m in (self.encoder, self.quantizer, self.decoder):
+            if m.dev != self.dev:
+                raise L.SfmiError(f"VQDIF: sub-module on {m.dev}, model on {self.dev}")
+            m.ws = self.ws                 # one workspace: named buffers are shared, nothing is allocated twice
+        if state_dict is not None:                  # handed-in modules take the model's weights; without a state dict they keep their own
+            for given, m, prefix in ((encoder, self.encoder, "encoder."), (quantizer, self.quantizer, "quantizer."), (decoder, self.decoder, "decoder.")):
+                if given is not None:
+                    m.load_state_dict(_sub_sd(state_dict, prefix, res))
+
+    # ------------------------------------------------------------------ weights
+    FUSE_DOWN0 = property(lambda self: self.encoder.FUSE_DOWN0, lambda self, v: setattr(self.encoder, "FUSE_DOWN0", v))
+    enc_w = property(lambda self: self.encoder.enc_w)
+    down = property(lambda self: self.encoder.down)
+    last_cell = property(lambda self: self.encoder.last_cell)
+    codebook = property(lambda self: self.quantizer.codebook)
+    codebook_packed = property(lambda self: self.quantizer.codebook_packed)
+    unet = property(lambda self: self.decoder.unet)
+    unet_final = property(lambda self: self.decoder.unet_final)
+    up = property(lambda self: self.decoder.up)
+    sdf_w = property(lambda self: self.decoder.sdf_w)
+
+    def state_dict_np(self):
+        """The (numpy, reference-layout) state dict the packed device weights were built from (122 / 110 tensors)."""
+        out = {}
+        for prefix, m in (("encoder.", self.encoder), ("quantizer.", self.quantizer), ("decoder.", self.decoder)):
+            out.update({prefix + k: v for k, v in m._sd.items()})
+        return out
+
+    def load_state_dict(self, sd):
+        self.encoder.load_state_dict(_sub_sd(sd, "encoder.", self.res))
+        self.quantizer.load_state_dict(_sub_sd(sd, "quantizer.", self.res))
+        self.decoder.load_state_dict(_sub_sd(sd, "decoder.", self.res))
+
+    # ------------------------------------------------------------------ primitives (delegated to the sub-modules)
+    def _buf(self, name, shape, dtype=torch.float32):
+        return self.ws.buf(name, shape, dtype)
+
+    def _gn(self, x, gamma, beta, name):
+        return self.decoder._gn(x, gamma, beta, name)
+
+    def _affine(self, x, sc, sh, name):
+        return self.decoder._affine(x, sc, sh, name)
+
+    def _conv(self, *a, **kw):
+        return self.decoder._conv(*a, **kw)
+
+    # ------------------------------------------------------------------ encoder (a1-a8)
+    def encode_cl(self, cloud):
+        """cloud (B,T,3) in [-1,1] -> latent (B,R,R,R,d) channels-last, mask (B,R,R,R) uint8."""
+        return self.encoder.encode_cl(cloud)
+
+    def encode(self, Xbd):
+        """vqdif.py:35-37 -> (grid_feat (B,d,R,R,R) view, grid_mask (B,R,R,R) bool)."""
+        lat, mask = self.encode_cl(Xbd)
+        return lat.permute(0, 4, 1, 2, 3).clone(), mask.bool()      # fresh tensors: the *_cl / *_dev paths return workspace views
+
+    # ------------------------------------------------------------------ quantizer (a9, a10)
+    def quantize_cl(self, latent):
+        return self.quantizer.quantize_cl(latent)
+
+    def get_code_cl(self, ind):
+        """quantizer.py:19-30 -> channels-last (B,R,R,R,d)."""
+        return self.quantizer.get_code_cl(ind)
+
+    def mode_of(self, idx, name="mode", rows=1):
+        hist = self._buf("hist", (rows * (self.K + 1),), torch.int32)
+        mode = self._buf(name, (rows,), torch.int32)
+        L.check(L.lib().sfmi_mode_i32(L.ptr(idx), idx.numel(), self.K + 1, rows, L.ptr(hist), L.ptr(mode), L.stream_ptr()), "sfmi_mode_i32")
+        return mode
+
+    def quantize_cloud_dev(self, cloud, per_shape_mode=False):
+        """Device-resident quantize_cloud: (quant_ind int32 (B,R,R,R), mode int32, raw idx, mask u8, latent).
+
+        per_shape_mode=False reproduces the reference on a batch (ONE mode over the whole batch, vqdif.py:53);
+        True gives every shape its own empty code = the reference run shape-by-shape at batch size 1, which is
+        how its inference drivers call it (shapeformer.py:227 asserts batch_size == 1)."""
+        latent, mask = self.encode_cl(cloud)
+        raw = self.quantize_cl(latent)
+        rows = raw.shape[0] if per_shape_mode else 1
+        mode = self.mode_of(raw, rows=rows)
+        q = self._buf("quant_ind", tuple(raw.shape), torch.int32)
+        L.check(L.lib().sfmi_apply_mask_i32(L.ptr(raw), L.ptr(mask), L.ptr(mode), L.ptr(q), raw.numel(), rows, L.stream_ptr()), "sfmi_apply_mask_i32")
+        return q, mode, raw, mask, latent
+
+    def quantize_cloud(self, cloud):
+        """vqdif.py:50-58 -> (quant_ind (B,R,R,R) int64, mode, dict(quant_ind, grid_mask, quant_feat...))."""
+        q, mode, raw, mask, latent = self.quantize_cloud_dev(cloud)
+        code = self.get_code_cl(raw)
+        # encode_quant's dict (vqdif.py:39-48); fresh tensors (the *_dev path returns views of a reused workspace)
+        enc = dict(quant_feat=code.permute(0, 4, 1, 2, 3).clone(), quant_ind=raw.long(), quant_diff=((latent - code) ** 2).mean(),
+                   grid_mask=mask.bool(), grid_feat=latent.permute(0, 4, 1, 2, 3).clone())
+        return q.long(), mode.long()[0], enc
+
+    # ------------------------------------------------------------------ decoder grid (a21, a22)
+    def decoder_grid_cl(self, code_cl, final_affine=True):
+        """dec.py:75-83: UNet3D + Upsampler -> (B,64,64,64,32) channels-last."""
+        return self.decoder.decoder_grid_cl(code_cl, final_affine=final_affine)
 
     # ------------------------------------------------------------------ a20, a23
     def decode_index(self, code_ind, Xtg=None, grid_Q=None, sigmoid=False):

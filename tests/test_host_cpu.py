@@ -85,6 +85,13 @@ def test_yaml_loader_and_plugin_resolution(tmp_path):
     assert P.instantiate_from_opt({"class": None}) is None and P.instantiate_from_opt({}) is None
     assert P.load_object("shapeformer.models.vqdif.vqdif.VQDIF") is P.VQDIFModel
     assert P.load_object("shapeformer.models.shapeformer.representers.AR_N") is P.ARNRepresenter
+    from shapeformer_amd import vqdif as V
+    for path, cls in (("enc.LocalPoolPointnet", V.LocalPoolPointnet), ("quantizer.Quantizer", V.Quantizer), ("dec.LocalDecoder", V.LocalDecoder)):
+        assert P.load_object("shapeformer.models.vqdif." + path) is cls          # B1: the three VQDIF sub-modules (vqdif.py:28-32)
+    with pytest.raises(ValueError, match="c_dim=128"):                           # unsupported hyper-parameters name the limit
+        V.LocalPoolPointnet()                                                    # (the reference's own ctor defaults: c_dim 128)
+    with pytest.raises(ValueError, match="vocab_size=1000"):
+        V.Quantizer(1000, 128)
     with pytest.raises(NotImplementedError):
         P.load_object("shapeformer.trainer.Trainer")
     from shapeformer_amd import data as D
@@ -184,6 +191,10 @@ def test_reference_dotted_paths_become_importable():
         "import importlib\n"
         "m = importlib.import_module('shapeformer.models.vqdif.vqdif')\n"
         "assert m.VQDIF is P.VQDIFModel and callable(m.VisSparseRecon3D)\n"
+        "from shapeformer_amd import vqdif as V\n"
+        "assert importlib.import_module('shapeformer.models.vqdif.enc').LocalPoolPointnet is V.LocalPoolPointnet\n"
+        "assert importlib.import_module('shapeformer.models.vqdif.quantizer').Quantizer is V.Quantizer\n"
+        "assert importlib.import_module('shapeformer.models.vqdif.dec').LocalDecoder is V.LocalDecoder\n"
         "assert importlib.import_module('shapeformer.models.shapeformer.transformer.mingpt').CondTupleGPT is P.CondTupleGPTModel\n"
         "assert importlib.import_module('shapeformer.data.partial').VirtualScanSelector is D.VirtualScanSelector\n"
         "from shapeformer.models.shapeformer.representers import AR_N\n"

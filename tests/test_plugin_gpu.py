@@ -242,3 +242,55 @@ def test_config1_demo_yaml_through_listdataset_and_callback(dev, tmp_path, monke
         assert np.all(err <= 2e-4 + 1e-4 * np.abs(want)), (name, float(err.max()))
         assert os.path.exists(tmp_path / "demo_vqdif" / "meshes" / f"{i}.ply") or len(out[str(i)]["recon_mesh"]["face"]) == 0
     print(f"config 1 via YAML -> ListDataset -> VisSparseRecon3D: logits max |diff| vs the reference {worst:.2e}")
+
+
+def test_b1_vqdif_submodules_from_the_yaml_opts_match_the_reference_vectors(dev, vq16_sd):
+    """`shapeformer.models.vqdif.enc.LocalPoolPointnet`, `...quantizer.Quantizer`, `...dec.LocalDecoder`
+    resolve under their reference dotted names and are built from the opt dicts of configs/vqdif/shapenet_res16.yaml (via the
+    merged tree of the demo YAML, committed under tests/golden/demo_ds), each with the reference's call contract
+    (vqdif.py:28-48,60-76): encoder(Xbd / 2) -> (fea, mask); quantizer(fea) -> (q, q_st, idx, diff), get_code(idx);
+    decoder(Xtg / 2, c_grid) -> (B,N,1).  Chained exactly as VQDIF.forward chains them they must reproduce what the REFERENCE
+    returned on the same weights (tests/golden/vqdif16_small.npz): mask bits, latent taps, code indices, logits."""
+    from oracle import vqdif_oracle as O
+    from shapeformer_amd import plugin as P, vqdif as V
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    kw = P.get_opt(os.path.join(gold, "demo_ds", "demo_vqdif.yaml"))["pl_model_opt"]["kwargs"]
+    z = np.load(os.path.join(gold, "vqdif16_small.npz"))
+
+    def make(o, cls):
+        assert P.load_object(o["class"]) is cls
+        return P.instantiate_from_opt(dict(o, kwargs=dict(o["kwargs"], state_dict=vq16_sd, device=dev)))
+    enc = make(kw["encoder_opt"], V.LocalPoolPointnet)
+    qz = make(kw["quantizer_opt"], V.Quantizer)
+    dec = make(kw["decoder_opt"], V.LocalDecoder)
+    cloud = torch.from_numpy(z["cloud"])
+    fea, mask = enc(cloud / 2.0)                                                     # vqdif.py:36
+    assert fea.shape == (2, 128, 16, 16, 16) and mask.dtype == torch.bool and mask.shape == (2, 16, 16, 16)
+    assert np.array_equal(np.packbits(mask.cpu().numpy()), z["grid_mask"])
+    lat = fea.permute(0, 2, 3, 4, 1).cpu()
+    scale = float(np.abs(z["latent_sel"]).max())
+    np.testing.assert_allclose(lat.reshape(2, -1, 128)[:, ::61].numpy(), z["latent_sel"], atol=2e-5 * scale + 1e-4)
+    q, q_st, idx, diff = qz(fea)                                                     # vqdif.py:41-42
+    assert idx.dtype == torch.int64 and idx.shape == (2, 16, 16, 16) and q.shape == fea.shape and torch.equal(q, q_st)
+    assert np.array_equal(idx.cpu().numpy(), z["quant_ind_raw"].astype(np.int64))
+    assert torch.equal(qz.get_code(idx), q) and qz.get_code(idx, bchw=False).shape == (2, 16, 16, 16, 128)
+    np.testing.assert_allclose(float(diff), float(((fea - q) ** 2).mean()), rtol=1e-5)
+    Q = int(z["Q"])
+    Xtg = torch.from_numpy(O.make_grid(Q))[None].expand(2, -1, -1)
+    code = qz.get_code(torch.from_numpy(z["quant_ind"].astype(np.int64)))           # decode_index (vqdif.py:74-76)
+    lg = dec(Xtg / 2.0, code)                                                        # vqdif.py:71
+    assert lg.shape == (2, Q ** 3, 1)
+    np.testing.assert_allclose(lg.cpu().numpy()[..., 0], z["logits"], atol=2e-4, rtol=1e-4)
+    # a VQDIF composed of these three objects is the model the plugin builds; swapping ONE module keeps the others' weights
+    model = P.instantiate_from_opt({"class": "shapeformer.models.vqdif.vqdif.VQDIF", "kwargs": dict(kw, state_dict=vq16_sd, device=dev)})
+    assert isinstance(model.encoder, V.LocalPoolPointnet) and isinstance(model.quantizer, V.Quantizer) and isinstance(model.decoder, V.LocalDecoder)
+    qi, mode, _ = model.quantize_cloud(cloud)
+    assert int(mode) == int(z["mode"]) and np.array_equal(qi.cpu().numpy(), z["quant_ind"].astype(np.int64))
+    assert sorted(model.core.state_dict_np()) == sorted(vq16_sd)
+    # hyper-parameters outside what the kernels are built for name the limit (never "outside the hot path")
+    with pytest.raises(ValueError, match="n_embd=96"):
+        V.Quantizer(4096, 96, device=dev)
+    with pytest.raises(ValueError, match="hidden_size=256"):
+        V.LocalDecoder(**dict(kw["decoder_opt"]["kwargs"], hidden_size=256), device=dev)
+    with pytest.raises(ValueError, match="grid_resolution=32"):
+        V.LocalPoolPointnet(**dict(kw["encoder_opt"]["kwargs"], grid_resolution=32), device=dev)
