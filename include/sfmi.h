@@ -205,6 +205,17 @@ int sfmi_gelu_f32(const float* x, float* y, long long n, void* stream);         
 int sfmi_gelu_bwd_f32(const float* dy, const float* x, float* dx, long long n, void* stream);
 int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* dgamma,
                            float* dbeta, float* stats, int M, int D, void* stream);
+/* the row part alone (dx and the (M,2) row statistics); the parameter sums then join a block's sfmi_col_reduce_f32 launch */
+int sfmi_layernorm_bwd_rows_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats, int M,
+                                int D, void* stream);
+/* up to 8 column reductions over M rows in ONE launch: kind 0 = bias gradient of a Linear layer (column sums of dY, mingpt.py:46-111),
+ * kind 1 = LayerNorm parameter gradients (dgamma -> out, dbeta -> out2).  Replaces 8 colsum + 4 LayerNorm-parameter launches per
+ * transformer block of the backward pass.  part / cnt: scratch for tall inputs (cnt zeroed once). */
+int sfmi_col_reduce_slices(int M);                                   /* [host] */
+long long sfmi_col_reduce_part_floats(int M, int total_cols);        /* [host] */
+int sfmi_col_reduce_f32(int njobs, const int* kind, const float* const* a, const float* const* x, const float* const* stats, float* const* out,
+                        float* const* out2, const int* N, const int* ld, int M, int accumulate, float* part, long long part_floats, int* cnt,
+                        long long cnt_ints, void* stream);
 int sfmi_ce_fwd_bwd_f32(const float* logits, const int* target, float* loss_rows, float* dlogits, int M, int V, int ld, int L,
                         int t0, float scale, void* stream);                                                    /* shapeformer.py:132-140 */
 int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* lse /*2*B*H*L floats scratch*/, float* dqkv,

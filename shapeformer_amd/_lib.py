@@ -116,6 +116,10 @@ PROTOTYPES = {
     "sfmi_gelu_f32": (i32, [c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_gelu_bwd_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_layernorm_bwd_f32": (i32, [c_ptr] * 8 + [i32, i32, c_ptr]),
+    "sfmi_layernorm_bwd_rows_f32": (i32, [c_ptr] * 6 + [i32, i32, c_ptr]),
+    "sfmi_col_reduce_slices": (i32, [i32]),
+    "sfmi_col_reduce_part_floats": (i64, [i32, i32]),
+    "sfmi_col_reduce_f32": (i32, [i32] + [c_ptr] * 8 + [i32, i32, c_ptr, i64, c_ptr, i64, c_ptr]),
     "sfmi_ce_fwd_bwd_f32": (i32, [c_ptr] * 4 + [i32] * 5 + [C.c_float, c_ptr]),
     "sfmi_attn_bwd_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [f32, C.c_uint, c_ptr]),
     "sfmi_dropout_f32": (i32, [c_ptr, c_ptr, i64, f32, C.c_uint, c_ptr]),

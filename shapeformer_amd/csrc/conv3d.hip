@@ -423,23 +423,21 @@ static int conv_dispatch(const ConvArgs& a, void* stream) {
   } else if (Cout % 64 == 0) {
     constexpr int M_T = 256, N_T = 64;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    if (xr) {
-      static const hipError_t attr = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<2, 1, 4, false, true>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (attr != hipSuccess || lds_bytes(M_T, N_T, true) > 96 * 1024) return SFMI_ELDS;
+    // the framed x-rows of a narrow grid (Wo <= 2: 112 KB) do not fit the 96 KB the x-reuse instance may ask for, and the device
+    // may refuse the raised limit: both fall through to the per-tap form instead of failing the call
+    static const hipError_t attr64 = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<2, 1, 4, false, true>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (xr && attr64 == hipSuccess && lds_bytes(M_T, N_T, true) <= 96 * 1024)
       hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, false, true>), grid, dim3(256), lds_bytes(M_T, N_T, true), st, a);
-    }
     else if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, true>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
     else hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, false>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
   } else {
     constexpr int M_T = 256, N_T = 32;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    if (xr) {
-      static const hipError_t attr = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<1, 1, 4, false, true>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (attr != hipSuccess || lds_bytes(M_T, N_T, true) > 96 * 1024) return SFMI_ELDS;
+    static const hipError_t attr32 = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<1, 1, 4, false, true>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (xr && attr32 == hipSuccess && lds_bytes(M_T, N_T, true) <= 96 * 1024)      // Wo == 1 needs 138 KB: per-tap form
       hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, false, true>), grid, dim3(256), lds_bytes(M_T, N_T, true), st, a);
-    }
     else if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, true>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
     else hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, false>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
   }

@@ -172,6 +172,88 @@ __global__ void ln_bwd_params_finish_kernel(const float* __restrict__ part, floa
   dgamma[c] += g; dbeta[c] += b;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// All column reductions of ONE transformer block's backward in ONE launch (round 5): the four bias gradients (column sums of the
+// four dY's, mingpt.py:46-111 Linear biases) and the two LayerNorm parameter gradients (dgamma = sum_m dy * xhat, dbeta = sum_m dy).
+// They are only consumed by the optimizer, so they are deferred to the end of the block's backward and share a launch (round 4:
+// 8 colsum + 4 LayerNorm-parameter launches per block).  A job is a (kind, M x N operand(s), outputs) record; the grid is
+// (sum of the jobs' 64-column blocks, RS row slices).  RS = 1: direct.  RS > 1 (tall inputs): slice partials go out as agent-scope
+// relaxed atomics (write-through), the block that draws the last ticket of its column block adds them in slice order
+// (deterministic) - the wave-level protocol of csrc/gpt.hip's split-K, here per workgroup (drain, barrier, ticket).
+// Thread layout: 16 row lanes x 16 float4 column quads; fixed-order tree over the row lanes.
+// ------------------------------------------------------------------------------------------------
+constexpr int CR_MAX_JOBS = 8;
+struct ColJob {
+  const float* a;       // (M, N; ld): the summed operand (dY)
+  const float* x;       // kind 1: the LayerNorm input (M, N; ld)
+  const float* stats;   // kind 1: (M, 2) row mean / rstd (ln_bwd_rows_kernel)
+  float* out;           // kind 0: column sums; kind 1: dgamma
+  float* out2;          // kind 1: dbeta
+  int N, ld, kind, blk0;   // blk0: first column block of this job in grid.x
+};
+struct ColJobs { ColJob j[CR_MAX_JOBS]; int njobs, M, accumulate, RS; float* part; int* cnt; };
+
+__global__ __launch_bounds__(256) void col_reduce_kernel(ColJobs J) {
+  __shared__ float red[2][16][64];
+  __shared__ int last_flag;
+  int ji = 0;
+#pragma unroll
+  for (int t = 1; t < CR_MAX_JOBS; ++t)
+    if (t < J.njobs && (int)blockIdx.x >= J.j[t].blk0) ji = t;
+  const ColJob& jb = J.j[ji];
+  const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+  const int n = ((int)blockIdx.x - jb.blk0) * 64 + 4 * cq;
+  const int rows_per = (J.M + J.RS - 1) / J.RS;
+  const int m0 = blockIdx.y * rows_per, m1 = min(J.M, m0 + rows_per);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+  if (n < jb.N) {
+    if (jb.kind == 0) {
+      for (int m = m0 + rl; m < m1; m += 16) s = s + *reinterpret_cast<const f32x4*>(jb.a + (long long)m * jb.ld + n);
+    } else {
+      for (int m = m0 + rl; m < m1; m += 16) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(jb.a + (long long)m * jb.ld + n);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(jb.x + (long long)m * jb.ld + n);
+        const float mean = jb.stats[2 * m], rstd = jb.stats[2 * m + 1];
+        s = s + d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] += d[e] * (xv[e] - mean) * rstd;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][rl][4 * cq + e] = s[e]; red[1][rl][4 * cq + e] = g[e]; }
+  __syncthreads();
+  // threads 0..63: column sums; 64..127: the dgamma sums (kind 1)
+  const int which = tid >> 6, c = tid & 63;
+  float t = 0.f;
+  if (tid < 128) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[which][r][c];
+  }
+  const int nc = ((int)blockIdx.x - jb.blk0) * 64 + c;
+  if (J.RS > 1) {
+    float* part = J.part + ((long long)blockIdx.x * J.RS) * 128;
+    if (tid < 128) __hip_atomic_store(part + (long long)blockIdx.y * 128 + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(J.cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = ticket == J.RS - 1;
+      if (last_flag) __hip_atomic_store(J.cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    t = 0.f;
+    if (tid < 128)
+      for (int r = 0; r < J.RS; ++r) t += __hip_atomic_load(part + (long long)r * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < 128 && nc < jb.N) {
+    float* o = which == 0 ? (jb.kind == 0 ? jb.out : jb.out2) : (jb.kind == 1 ? jb.out : nullptr);
+    if (o) o[nc] = J.accumulate ? o[nc] + t : t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Attention backward on the matrix cores (16x16x4 f32 MFMA): dqkv (B*L,3D) from qkv, y, dy (mingpt.py:73-91), head dim 64.
 // Shared conventions (csrc/gpt.hip attn_prefill_mfma_kernel): 4 waves, wave w owns 16 rows of the block; an A operand is
@@ -578,6 +660,41 @@ int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, 
     hipLaunchKernelGGL(ln_bwd_params_part_kernel, dim3((D + 63) / 64, RS), dim3(256), 0, st, dy, x, stats, part, M, D, rows_per);
     hipLaunchKernelGGL(ln_bwd_params_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, dgamma, dbeta, D, RS);
   }
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// LayerNorm backward, row part only: dx = dLN/dx (+ dres), stats (M,2) = row mean / rstd for the parameter sums, which the caller
+// adds to a block's sfmi_col_reduce_f32 launch (kind 1 job).
+int sfmi_layernorm_bwd_rows_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats, int M,
+                                int D, void* stream) {
+  if (!dy || !x || !gamma || !dx || !stats || M <= 0 || D <= 0) return SFMI_EINVAL;
+  hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, dres, dx, stats, D);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// Up to 8 column reductions over M rows in one launch (csrc/train.hip:col_reduce_kernel).  Job i: kind[i] 0: out[i][n] (=|+=) sum_m
+// a[i][m][n]  (bias gradient of a Linear layer);  kind[i] 1: out[i] = dgamma = sum_m a * (x - mean_m) * rstd_m, out2[i] = dbeta =
+// sum_m a, stats[i] (M,2) from sfmi_layernorm_bwd_rows_f32.  a / x row stride ld[i], N[i] % 4 == 0.  part / cnt: scratch for tall
+// inputs (sfmi_col_reduce_scratch: floats / ints; cnt zeroed ONCE).  Fixed summation order: deterministic.
+int sfmi_col_reduce_slices(int M) { return M <= 1024 ? 1 : (M + 511) / 512 > 16 ? 16 : (M + 511) / 512; }
+long long sfmi_col_reduce_part_floats(int M, int total_cols) { return (long long)((total_cols + 63) / 64 + CR_MAX_JOBS) * sfmi_col_reduce_slices(M) * 128; }
+int sfmi_col_reduce_f32(int njobs, const int* kind, const float* const* a, const float* const* x, const float* const* stats, float* const* out,
+                        float* const* out2, const int* N, const int* ld, int M, int accumulate, float* part, long long part_floats, int* cnt,
+                        long long cnt_ints, void* stream) {
+  if (njobs <= 0 || njobs > CR_MAX_JOBS || !kind || !a || !out || !N || !ld || M <= 0) return SFMI_EINVAL;
+  ColJobs J;
+  int blk = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (!a[i] || !out[i] || N[i] <= 0 || N[i] % 4 || ld[i] % 4 || (kind[i] != 0 && kind[i] != 1)) return SFMI_EINVAL;
+    if (kind[i] == 1 && (!x || !stats || !out2 || !x[i] || !stats[i] || !out2[i])) return SFMI_EINVAL;
+    J.j[i].a = a[i]; J.j[i].x = x ? x[i] : nullptr; J.j[i].stats = stats ? stats[i] : nullptr; J.j[i].out = out[i];
+    J.j[i].out2 = out2 ? out2[i] : nullptr; J.j[i].N = N[i]; J.j[i].ld = ld[i]; J.j[i].kind = kind[i]; J.j[i].blk0 = blk;
+    blk += (N[i] + 63) / 64;
+  }
+  for (int i = njobs; i < CR_MAX_JOBS; ++i) J.j[i] = J.j[0];
+  J.njobs = njobs; J.M = M; J.accumulate = accumulate; J.RS = sfmi_col_reduce_slices(M); J.part = part; J.cnt = cnt;
+  if (J.RS > 1 && (!part || !cnt || (long long)blk * J.RS * 128 > part_floats || blk > cnt_ints)) return SFMI_EINVAL;
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(blk, J.RS), dim3(256), 0, (hipStream_t)stream, J);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

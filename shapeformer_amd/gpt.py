@@ -715,27 +715,41 @@ class CondTupleGPT:
             nr = -(-B // cap)
             rb = [round(i * B / nr) for i in range(nr + 1)]
             sl = lambda t, lo, hi: None if t is None else torch.as_tensor(t)[lo:hi]
-            parts = [self.sample_microbatched(c_tokens[lo:hi], Lc[lo:hi], n_micro=n_micro, max_steps=max_steps, top_k=top_k, top_p=top_p,
-                                              temperature=temperature, best_in_first=best_in_first, mask_invalid=mask_invalid,
-                                              mask_invalid_completion=mask_invalid_completion, seed=seed, stop_early=stop_early,
-                                              check_every=check_every, after_prefill=after_prefill if lo == 0 else None,
-                                              return_logits=return_logits, force_tokens=sl(force_tokens, lo, hi), shared_prefix=shared_prefix,
-                                              z_tokens=sl(z_tokens, lo, hi), use_graph=use_graph, _row0=_row0 + lo, _rows_total=rows_total)
-                     for lo, hi in zip(rb[:-1], rb[1:])]
+            def round_(lo, hi, steps, early):
+                return self.sample_microbatched(c_tokens[lo:hi], Lc[lo:hi], n_micro=n_micro, max_steps=steps, top_k=top_k, top_p=top_p,
+                                                temperature=temperature, best_in_first=best_in_first, mask_invalid=mask_invalid,
+                                                mask_invalid_completion=mask_invalid_completion, seed=seed, stop_early=early,
+                                                check_every=check_every, after_prefill=after_prefill if lo == 0 else None,
+                                                return_logits=return_logits, force_tokens=sl(force_tokens, lo, hi), shared_prefix=shared_prefix,
+                                                z_tokens=sl(z_tokens, lo, hi), use_graph=use_graph, _row0=_row0 + lo, _rows_total=rows_total)
+            spans = list(zip(rb[:-1], rb[1:]))
+            parts = [round_(lo, hi, max_steps, stop_early) for lo, hi in spans]
             # the rounds stop early independently; a single run (shapeformer.py:110-115) keeps stepping every row until ALL rows have
-            # ended, and a row that has ended can only draw end-token pairs from then on (sampling_masker leaves nothing else, with
-            # log-probability 0): pad the rounds that stopped sooner with exactly those tokens up to the longest round's step count
+            # ended.  A row whose last POSITION is the end token can only draw end-token pairs from then on (the position masks leave
+            # nothing else, log-probability 0): a round that stopped sooner and holds only such rows is padded with exactly those
+            # tokens.  A row that "ended" by drawing the end VALUE at a real position is not forced to end tokens (and nothing is with
+            # mask_invalid off): such a round is re-run for the longest round's step count without the early stop - rows keep their
+            # global index and uniforms, so this is what the single run draws for them.
             nmax = max(p["steps"] for p in parts)
-            for p_ in parts:
+            for i, (lo, hi) in enumerate(spans):
+                p_ = parts[i]
                 short = nmax - p_["steps"]
-                if short > 0 and mask_invalid:
-                    stp = p_["state"]
+                if short <= 0:
+                    continue
+                stp = p_["state"]
+                last = stp["seq"][torch.arange(stp["len"].shape[0], device=self.dev), (stp["len"].long() - 1).clamp(min=0), 0]
+                full = stp["len"] >= self.Lmax           # the block is full: nothing more is drawn for this row in a single run either
+                if mask_invalid and bool(((last == self.end[0]) | full).all()):
                     room = (self.Lmax - stp["len"]).clamp(min=0, max=short).long()
                     pos = stp["len"].long()[:, None] + torch.arange(short, device=self.dev)[None, :]
                     ok = torch.arange(short, device=self.dev)[None, :] < room[:, None]
                     rows = torch.arange(stp["len"].shape[0], device=self.dev)[:, None].expand_as(pos)
                     stp["seq"][rows[ok], pos[ok]] = torch.tensor(self.end, device=self.dev, dtype=torch.int32)
                     stp["len"] = stp["len"] + room.to(torch.int32)
+                    if return_logits:      # the padded steps drew from a one-candidate distribution; their logits rows stay zero
+                        p_["logits_history"] = [torch.cat([h, h.new_zeros(h.shape[0], short, h.shape[2])], 1) for h in p_["logits_history"]]
+                else:
+                    parts[i] = round_(lo, hi, nmax, False)
             res = dict(state={k: torch.cat([p["state"][k] for p in parts], 0) for k in parts[0]["state"]}, steps=nmax)
             if return_logits:
                 res["logits_history"] = [torch.cat([p["logits_history"][i] for p in parts], 0) for i in range(2)]

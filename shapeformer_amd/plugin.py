@@ -289,7 +289,11 @@ class ARNRepresenter:
     @torch.no_grad()
     def sampling_masker(self, logits, idx, extra_idx=None, L_cond=None, step_j=None, tuple_i=None):
         """logits (B,V) -> masked copy; idx (B,L+1,2): idx[:, -1] is the position being sampled.  Runs the masking stage of the
-        fused sampler kernel (csrc/gpt.hip:sample_kernel - the code the decode step uses) on a scratch copy of `idx`."""
+        fused sampler kernel (csrc/gpt.hip:sample_kernel - the code the decode step uses) on a scratch copy of `idx`.
+        DEVIATION from the reference for ONE call form: with `L_cond=None` and mask_invalid_completion on, the reference slices
+        `idx[:, :None, 0]`, i.e. takes the WHOLE sequence (generated tokens included) as the condition list (representers.py:139-147,
+        an accident of the default); here L_cond is derived from `step_j` (L_cond = idx.shape[1] - 1 - step_j, shapeformer.py:86-93)
+        and the call is refused when neither is given.  Every call the reference's own sampler makes passes L_cond."""
         from . import _lib as L
         dev = self.dev
         lg = torch.as_tensor(logits).to(dev, torch.float32).contiguous()
@@ -364,6 +368,7 @@ class ShapeFormerModel:
         where every row's newest token is an end token (shapeformer.py:110-115) or at the block size (no crop: DESIGN §2 D4).
         `mask_invalid*` are taken from the representer, as the reference's sampling_masker does (the arguments are unused
         there too); `sample`/`callback` are accepted and unused (as in the reference)."""
+        self._params_current()
         c = torch.as_tensor(c_indices)
         z = torch.as_tensor(z_indices)
         B, L_c, _ = c.shape
@@ -388,6 +393,7 @@ class ShapeFormerModel:
 
     def sample_ragged(self, c_indices, Lc=None, max_steps=512, temperature=1.0, best_in_first=False, top_k=100, top_p=0.8, **kw):
         """Ragged batch of DIFFERENT shapes (row b valid for Lc[b] tokens) -> dict(samples, log_prob, steps) (gpt.sample)."""
+        self._params_current()
         B, Lp, _ = c_indices.shape
         Lc = Lc if Lc is not None else torch.full((B,), Lp, dtype=torch.int32)
         kw.setdefault("mask_invalid", self.representer.mask_invalid)
@@ -404,8 +410,8 @@ class ShapeFormerModel:
     def make_trainer(self, optim_opt=None, dist=None, grad_sync="ring"):
         """AdamW trainer of the transformer (shapeformer.py:198-206).  dist: torch.distributed for data-parallel training
         (trainer.py:22,93); grad_sync "ring" = per-block all-reduce, "rs_ag" = reduce-scatter / sharded AdamW / all-gather (the weights
-        are the same bit for bit; with "rs_ag" `save_checkpoint` gathers the sharded moments, i.e. EVERY rank must call it - only
-        the ranks that should own a file need a distinct path)."""
+        are the same bit for bit).  `save_checkpoint` never runs a collective: with "rs_ag" it stores this rank's shard of the
+        moments unless the training loop hands it the state it gathered on every rank (`trainer.gather_optimizer_state()`)."""
         from .train import GPTTrainer
         lr = (optim_opt or getattr(self, "optim_opt", None) or {}).get("lr", 1e-5)
         self.trainer = GPTTrainer(self.transformer, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, dist=dist, grad_sync=grad_sync)
@@ -419,23 +425,37 @@ class ShapeFormerModel:
         return self.trainer.training_step(c, z)
 
     # ---- checkpoint / resume (Lightning `.ckpt` = torch.save dict) ---------------------------------------------
+    def _params_current(self):
+        """rs_ag with overlapped parameter gathers: the trainer leaves the updated parameters of the last step in flight for the next
+        forward; anything else that reads the weights (checkpoint, sampling) drains them first."""
+        tr = getattr(self, "trainer", None)
+        if tr is not None:
+            tr.finish_param_gather()
+
     def state_dict(self):
         """`transformer.*` + frozen `representer.vqvae_model.*` keys, as in a reference ShapeFormer checkpoint."""
+        self._params_current()
         sd = {"transformer." + k: v for k, v in self.transformer.state_dict().items()}
         sd.update({"representer.vqvae_model." + k: torch.as_tensor(v) for k, v in self.representer.vqvae_model.core.state_dict_np().items()})
         return sd
 
-    def save_checkpoint(self, path, hyper_parameters=None, epoch=0):
+    def save_checkpoint(self, path, hyper_parameters=None, epoch=0, optimizer_state=None):
         """Lightning-layout file: `state_dict` (reference key names), `hyper_parameters` (the ctor kwargs, so that
         `load_from_checkpoint` of either code base can rebuild the module), `epoch`, `global_step`.  The AdamW moments of the
         flat-buffer trainer are NOT a torch.optim state dict; they live under the private key `sfmi_optimizer_state`.
-        path=None: take part in the collectives of a sharded optimizer state (grad_sync "rs_ag") without writing a file."""
-        ck = dict(state_dict=self.state_dict(), hyper_parameters=dict(hyper_parameters or self.hparams), epoch=epoch,
-                  global_step=getattr(getattr(self, "trainer", None), "step_count", 0))
-        if hasattr(self, "trainer"):
-            ck["sfmi_optimizer_state"] = self.trainer.optimizer_state()     # rs_ag: an all-gather of the moments (all ranks)
+        No collective runs here, so the reference's pattern - rank 0 alone writes the file - is safe in every gradient mode:
+        `optimizer_state` = what the training loop gathered on every rank at its sync point (`trainer.gather_optimizer_state()`;
+        resumable anywhere); without it the trainer's LOCAL state is stored (complete with grad_sync "ring"; with "rs_ag" this
+        rank's shard, resumable by the same rank of the same sharding).  path=None: nothing to do (kept for callers that used it
+        to join the former collective)."""
         if path is None:
             return None
+        ck = dict(state_dict=self.state_dict(), hyper_parameters=dict(hyper_parameters or self.hparams), epoch=epoch,
+                  global_step=getattr(getattr(self, "trainer", None), "step_count", 0))
+        if optimizer_state is not None:
+            ck["sfmi_optimizer_state"] = optimizer_state
+        elif hasattr(self, "trainer"):
+            ck["sfmi_optimizer_state"] = self.trainer.optimizer_state()
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save(ck, path)
         return path
@@ -465,6 +485,7 @@ class ShapeFormerModel:
         return ck
 
     def complete(self, Xct, **kw):
+        self._params_current()
         kw.setdefault("mask_invalid", self.representer.mask_invalid)
         kw.setdefault("mask_invalid_completion", self.representer.mask_invalid_completion)
         return self.pipe.complete(Xct, **kw)

@@ -26,9 +26,15 @@ def _ru(x, m):
 
 class GPTTrainer:
     def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0,
-                 single_rank_collectives=False, grad_sync="ring", profile_waits=False):
+                 single_rank_collectives=False, grad_sync="ring", profile_waits=False, gemm="sk", overlap_param_gather=True):
         """grad_sync: "ring" = per-bucket all-reduce, every rank updates every parameter; "rs_ag" = per-bucket reduce-scatter,
-        AdamW on the rank's 1/N shard, all-gather of the updated parameters (dist.GradBuckets).  Same weights either way."""
+        AdamW on the rank's 1/N shard, all-gather of the updated parameters (dist.GradBuckets).  Same weights either way.
+        gemm: "sk" = the work-balanced GEMM with fused GELU epilogues (csrc/sgemm_sk.hip, round 5); "tile" = one workgroup per
+        128 x 128 tile + split-K reduce launches + separate GELU launches (csrc/sgemm.hip, rounds 2-4; kept as the cross-check).
+        overlap_param_gather (rs_ag): the all-gather of bucket k's updated parameters is waited for right before the NEXT step's first
+        kernel that reads them (embeddings, then block by block) instead of all at once after the optimizer."""
+        assert gemm in ("sk", "tile")
+        self.gemm_algo, self.overlap_param_gather = gemm, bool(overlap_param_gather)
         self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
         # (embd_pdrop, resid_pdrop, attn_pdrop): the model's (CondTupleGPT ctor kwargs / YAML) unless given
         self.pdrop = tuple(float(v) for v in (pdrop if pdrop is not None else getattr(gpt, "pdrop", (0.0, 0.0, 0.0))))
@@ -74,6 +80,14 @@ class GPTTrainer:
         self.buckets = GradBuckets(self.flat_grad, rng, dist, single_rank_collectives=single_rank_collectives, mode=grad_sync,
                                    profile_waits=profile_waits)
         self._sync = False
+        self._emb_range = rng["emb"]
+        # order in which a forward pass first reads the buckets' parameters (the order the rs_ag parameter gathers are launched in)
+        self._fwd_order = ["emb"] + [f"L{li}" for li in range(len(g.layers))] + ["heads"]
+        lib = L.lib()
+        self._sk_slab = torch.empty(lib.sfmi_sgemm_sk_slab_floats(), device=self.dev)      # stream-K partial tiles (134 MB)
+        self._sk_cnt = torch.zeros(1 << 20, device=self.dev, dtype=torch.int32)            # tickets: zeroed once, re-armed by the kernel
+        self._cr_cnt = torch.zeros(4096, device=self.dev, dtype=torch.int32)               # same for the column reductions
+        self._cr_part = None
 
     # ------------------------------------------------------------------ small wrappers
     def _f(self, *shape):
@@ -87,35 +101,54 @@ class GPTTrainer:
             self._has_blas = os.environ.get("SFMI_ROCBLAS") == "1" and bool(L.lib().sfmi_blas_available())
         return self._has_blas
 
-    def _sgemm(self, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, accumulate=False, bias=None, act=0, resid=None, drop=(0.0, 0)):
-        """csrc/sgemm.hip with split-K scratch for outputs of few tiles (the weight gradients)."""
+    def _sgemm(self, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, accumulate=False, bias=None, act=0, resid=None, drop=(0.0, 0), c2=None, aux=None):
+        """One GEMM of the step.  "sk": csrc/sgemm_sk.hip (act 2 + c2: GELU with the pre-activation kept; act 3 + aux: times GELU'(aux)).
+        "tile": csrc/sgemm.hip with split-K scratch for outputs of few tiles, the GELU forms as separate launches."""
         lib = L.lib()
+        if self.gemm_algo == "sk":
+            L.check(lib.sfmi_sgemm_sk_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(C), L.ptr(c2), ldc, int(accumulate), L.ptr(bias), act,
+                                          L.ptr(aux), L.ptr(resid), float(drop[0]), int(drop[1]), L.ptr(self._sk_slab), self._sk_slab.numel(),
+                                          L.ptr(self._sk_cnt), self._sk_cnt.numel(), L.stream_ptr()), "sgemm_sk")
+            return
         need = lib.sfmi_sgemm_mfma_splits(M, N, K) * M * N
         ws = None
         if need > M * N:
             if getattr(self, "_sg_ws", None) is None or self._sg_ws.numel() < need:
                 self._sg_ws = torch.empty(need, device=self.dev)
             ws = self._sg_ws
+        if act == 2 and c2 is not None:          # pre-activation kept: GEMM -> c2, then GELU -> C
+            assert resid is None and drop[0] == 0.0 and ldc == N
+            L.check(lib.sfmi_sgemm_mfma_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(c2), ldc, int(accumulate), L.ptr(bias), 0, None,
+                                            L.ptr(ws), ws.numel() if ws is not None else 0, 0.0, 0, L.stream_ptr()), "sgemm_mfma")
+            L.check(lib.sfmi_gelu_f32(L.ptr(c2), L.ptr(C), M * N, L.stream_ptr()), "gelu")
+            return
+        if act == 3:                             # GEMM -> C, then C *= GELU'(aux)
+            assert resid is None and bias is None and drop[0] == 0.0 and ldc == N
+            L.check(lib.sfmi_sgemm_mfma_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(C), ldc, int(accumulate), None, 0, None,
+                                            L.ptr(ws), ws.numel() if ws is not None else 0, 0.0, 0, L.stream_ptr()), "sgemm_mfma")
+            L.check(lib.sfmi_gelu_bwd_f32(L.ptr(C), L.ptr(aux), L.ptr(C), M * N, L.stream_ptr()), "gelu_bwd")
+            return
         L.check(lib.sfmi_sgemm_mfma_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(C), ldc, int(accumulate), L.ptr(bias),
                                         act, L.ptr(resid), L.ptr(ws), ws.numel() if ws is not None else 0, float(drop[0]), int(drop[1]), L.stream_ptr()), "sgemm_mfma")
 
-    def _gemm(self, x, w, bias, resid, y, M, N, K, act=0, drop=(0.0, 0)):
-        if drop[0] == 0.0 and self._blas() and M >= 256 and N % 4 == 0 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
+    def _gemm(self, x, w, bias, resid, y, M, N, K, act=0, drop=(0.0, 0), c2=None):
+        """y (M,N) = x (M,K) w^T (N,K) (+ bias) -> act -> dropout (+ resid)."""
+        if c2 is None and drop[0] == 0.0 and self._blas() and M >= 256 and N % 4 == 0 and not (resid is not None and resid.data_ptr() == y.data_ptr() and act):
             L.check(L.lib().sfmi_gemm_blas_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, L.stream_ptr()), "gemm_blas")
             return
         if N % 4 == 0 and K % 4 == 0:
-            self._sgemm(0, 1, M, N, K, x, K, w, K, y, N, bias=bias, act=act, resid=resid, drop=drop)
+            self._sgemm(0, 1, M, N, K, x, K, w, K, y, N, bias=bias, act=act, resid=resid, drop=drop, c2=c2)
             return
-        assert drop[0] == 0.0
+        assert drop[0] == 0.0 and c2 is None
         L.check(L.lib().sfmi_gemm_f32(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(y), M, N, K, act, 0, 0, L.stream_ptr()), "gemm")
 
-    def _dx(self, dY, wname, w, M, N, K):
-        """dX (M,K) = dY (M,N) W (N,K)."""
+    def _dx(self, dY, wname, w, M, N, K, gelu_aux=None):
+        """dX (M,K) = dY (M,N) W (N,K)  [* GELU'(gelu_aux) elementwise: the backward of the activation that produced this layer's input]."""
         dx = self._f(M, K)
-        if self._blas() and M >= 256:
+        if self._blas() and M >= 256 and gelu_aux is None:
             L.check(L.lib().sfmi_sgemm_f32(0, 0, M, K, N, 1.0, L.ptr(dY), N, L.ptr(w), K, 0.0, L.ptr(dx), K, L.stream_ptr()), "sgemm dx")
-        else:
-            self._sgemm(0, 0, M, K, N, dY, N, w, K, dx, K)      # W (N,K) is the (k,n)-stored right operand: no transposed copy
+        else:      # W (N,K) is the (k,n)-stored right operand: no transposed copy
+            self._sgemm(0, 0, M, K, N, dY, N, w, K, dx, K, act=3 if gelu_aux is not None else 0, aux=gelu_aux)
         return dx
 
     def _T(self, x, R, C, ld=None, Rpad=None):
@@ -141,20 +174,37 @@ class GPTTrainer:
         out = self.grad[gname]
         self._sgemm(1, 0, N, K, M, dY, N, X, K, out, K, accumulate=self._acc)   # dY^T X with dY / X read in place (no transposes)
 
-    def _colsum(self, x, M, N, gname):
-        lib = L.lib()
-        if M >= 256:      # tall: two-stage reduction over (column block, row slice) pairs, fixed order
-            ws = self._f(lib.sfmi_colsum_slices(M, N) * N)
-            L.check(lib.sfmi_colsum_ws_f32(L.ptr(x), L.ptr(self.grad[gname]), M, N, N, int(self._acc), L.ptr(ws), L.stream_ptr()), "colsum_ws")
-        else:
-            L.check(lib.sfmi_colsum_f32(L.ptr(x), L.ptr(self.grad[gname]), M, N, N, int(self._acc), L.stream_ptr()), "colsum")
+    def _ln_rows(self, dy, x, gamma, dres, M):
+        """LayerNorm backward, row part: -> (dx = dLN/dx (+ dres), stats (M,2)); the parameter sums join the block's column reduction."""
+        dx, stats = self._f(M, self.D), self._f(M, 2)
+        L.check(L.lib().sfmi_layernorm_bwd_rows_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(stats), M, self.D, L.stream_ptr()),
+                "ln_bwd_rows")
+        return dx, stats
 
-    def _ln_bwd(self, dy, x, gamma, dres, M, gw, gb):
-        dx = self._f(M, self.D)
-        stats = self._f(L.lib().sfmi_layernorm_bwd_scratch_floats(M, self.D))
-        L.check(L.lib().sfmi_layernorm_bwd_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(self.grad[gw]),
-                                               L.ptr(self.grad[gb]), L.ptr(stats), M, self.D, L.stream_ptr()), "ln_bwd")
-        return dx
+    def _col_reduce(self, jobs, M):
+        """All bias / LayerNorm-parameter gradients of a block in ONE launch (csrc/train.hip:col_reduce_kernel).  jobs: ("b", dY (M,N), N,
+        grad name) | ("ln", dy, x, stats, dgamma name, dbeta name).  Writes (accumulates when the step accumulates)."""
+        import ctypes as C
+        lib = L.lib()
+        n = len(jobs)
+        kind, a, x, st, o, o2, N, ld = [], [], [], [], [], [], [], []
+        for j in jobs:
+            if j[0] == "b":
+                _, dY, cols, gname = j
+                kind.append(0); a.append(dY.data_ptr()); x.append(0); st.append(0); o.append(self.grad[gname].data_ptr()); o2.append(0)
+                N.append(cols); ld.append(cols)
+            else:
+                _, dy, xin, stats, gw, gb = j
+                kind.append(1); a.append(dy.data_ptr()); x.append(xin.data_ptr()); st.append(stats.data_ptr())
+                o.append(self.grad[gw].data_ptr()); o2.append(self.grad[gb].data_ptr()); N.append(self.D); ld.append(self.D)
+        need = lib.sfmi_col_reduce_part_floats(M, sum(N))
+        if lib.sfmi_col_reduce_slices(M) > 1 and (self._cr_part is None or self._cr_part.numel() < need):
+            self._cr_part = torch.empty(need, device=self.dev)
+        IA, PA = C.c_int * n, C.c_void_p * n
+        # the launcher copies the tables into the kernel argument before it returns: the ctypes arrays may die afterwards
+        L.check(lib.sfmi_col_reduce_f32(n, IA(*kind), PA(*a), PA(*x), PA(*st), PA(*o), PA(*o2), IA(*N), IA(*ld), M, int(self._acc),
+                                        L.ptr(self._cr_part), self._cr_part.numel() if self._cr_part is not None else 0, L.ptr(self._cr_cnt),
+                                        self._cr_cnt.numel(), L.stream_ptr()), "col_reduce")
 
     def _scatter(self, dx, idx, table, M, accumulate=True):
         rows = self.grad[table].shape[0]
@@ -168,6 +218,30 @@ class GPTTrainer:
         if self._sync:
             self.buckets.ready(name)
 
+    @torch.no_grad()
+    def _param_ready(self, name):
+        """rs_ag with overlapped parameter gathers: make the compute stream wait for the all-gather of bucket `name` (launched by the
+        previous optimizer_step) and copy its gathered parameters out of the flat buffer into the tensors - right before the first
+        kernel that reads them.  No-op when nothing is pending for the bucket."""
+        if self.buckets.wait_params(name):
+            tb = self._bucket_tab(name)
+            L.check(L.lib().sfmi_unflatten_multi_f32(L.ptr(tb["p"]), L.ptr(tb["foff"]), L.ptr(tb["ct"]), L.ptr(tb["co"]), L.ptr(tb["cl"]), tb["n"],
+                                                     L.ptr(self.flat_grad), L.stream_ptr()), "unflatten_multi")
+
+    def _bucket_tab(self, name):
+        if not hasattr(self, "_bucket_tabs"):
+            self._bucket_tabs = {}
+        if name not in self._bucket_tabs:
+            self._bucket_tabs[name] = self._chunk_table([self.buckets.ranges[name]])
+        return self._bucket_tabs[name]
+
+    @torch.no_grad()
+    def finish_param_gather(self):
+        """Drain every pending parameter all-gather (rs_ag): call before anything but the next training forward reads the parameter
+        tensors (state_dict / checkpoint, sampling, evaluation).  Every rank reaches it at the same point of its program."""
+        for name in self.buckets.params_in_flight():
+            self._param_ready(name)
+
     def loss_and_grad(self, c_indices, z_indices, accumulate=False, sync=False, dropout_key=None):
         """-> loss (0-dim tensor).  Gradients of every parameter are left in self.grad[name] (flat buffer).
         dropout_key=None: eval-mode graph (no dropout); a string: train mode, the mask of site s is hash "dropout-<key>-<s>".
@@ -175,8 +249,12 @@ class GPTTrainer:
         is final, under the backward kernels of the remaining blocks (dist.GradBuckets); finish with all_reduce_grads()."""
         g, D, dev, lib = self.g, self.D, self.dev, L.lib()
         self._acc, self._sync = accumulate, sync
+        self._param_ready("emb")       # rs_ag: the embeddings' gathered parameters leave the flat buffer before it is written again
         if not accumulate:
-            self.flat_grad.zero_()
+            # every gradient below is WRITTEN (GEMM / column-reduction epilogues), except the embedding tables: E0 is accumulated
+            # twice and the positional tables only receive the rows the batch touches - those 57 MB are zeroed, not the 1.3 GB buffer
+            lo, hi = self._emb_range
+            self.flat_grad[lo:hi].zero_()
         c = torch.as_tensor(c_indices).to(dev, torch.int32)
         z = torch.as_tensor(z_indices).to(dev, torch.int32)
         cz = torch.cat([c, z], 1).contiguous()
@@ -214,6 +292,7 @@ class GPTTrainer:
             g._embed(st, B, Lq, resid, xn, g.layers[0].ln1)
         head_in = {}
         for li, ly in enumerate(g.layers):
+            self._param_ready(f"L{li}")
             s = dict(x_in=resid, xn1=xn)
             qkv = self._f(M, 3 * D)
             self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
@@ -224,10 +303,8 @@ class GPTTrainer:
             self._gemm(y, ly.wproj, ly.bproj, resid, r1, M, D, D, drop=site(p_resid, f"L{li}.proj"))
             xn2 = self._f(M, D)
             g._rowprep(r1, None, None, 0, M, None, xn2, ly.ln2)
-            hpre = self._f(M, 4 * D)
-            self._gemm(xn2, ly.wfc1, ly.bfc1, None, hpre, M, 4 * D, D)
-            h = self._f(M, 4 * D)
-            L.check(lib.sfmi_gelu_f32(L.ptr(hpre), L.ptr(h), M * 4 * D, L.stream_ptr()), "gelu")
+            hpre, h = self._f(M, 4 * D), self._f(M, 4 * D)
+            self._gemm(xn2, ly.wfc1, ly.bfc1, None, h, M, 4 * D, D, act=2, c2=hpre)     # h = GELU(hpre), both kept (mingpt.py:102-103)
             r2 = self._f(M, D)
             self._gemm(h, ly.wfc2, ly.bfc2, r1, r2, M, D, 4 * D, drop=site(p_resid, f"L{li}.mlp"))
             s.update(qkv=qkv, y=y, r1=r1, xn2=xn2, hpre=hpre, h=h)
@@ -253,8 +330,9 @@ class GPTTrainer:
         # ---- heads, loss, dlogits ---------------------------------------------------------------------------------
         tgt = cz[:, 1:, :].contiguous()     # targets of every input position (only t >= Lc-1 are active)
         loss = torch.zeros((), device=dev)
-        d_head = {}
+        d_head, head_jobs = {}, []
         scale = 1.0 / (2.0 * B * Lz)
+        self._param_ready("heads")
         for s in range(2):
             xnh = self._f(M, D)
             g._rowprep(head_in[s], None, None, 0, M, None, xnh, g.head_ln[s])
@@ -273,7 +351,9 @@ class GPTTrainer:
             whT = self._T(g.head_w_pad[s], g.Vpad, D, Rpad=g.Vpad)      # (D, Vpad)
             dxnh = self._f(M, D)
             self._gemm(dlg, whT, None, None, dxnh, M, D, g.Vpad)
-            d_head[s] = self._ln_bwd(dxnh, head_in[s], g.head_ln[s][0], None, M, f"head{s}.ln.w", f"head{s}.ln.b")
+            d_head[s], hst = self._ln_rows(dxnh, head_in[s], g.head_ln[s][0], None, M)
+            head_jobs.append(("ln", dxnh, head_in[s], hst, f"head{s}.ln.w", f"head{s}.ln.b"))
+        self._col_reduce(head_jobs, M)
         self._ready("heads")
         # ---- backward through the blocks -----------------------------------------------------------------------------
         dr = d_head[1]
@@ -287,21 +367,16 @@ class GPTTrainer:
                 dsum = self._f(M, D)
                 L.check(lib.sfmi_add_f32(L.ptr(dr), L.ptr(d_head[0]), L.ptr(dsum), M * D, L.stream_ptr()), "add")
                 dr = dsum
-            # fc2
+            # fc2 (the GELU backward rides in the epilogue of dX)
             dm = drop_(dr, site(p_resid, f"L{li}.mlp"))     # gradient of the MLP output before its dropout (residual path: dr)
-            self._colsum(dm, M, D, p + "bfc2")
             self._dW(dm, s["h"], M, D, 4 * D, p + "wfc2")
-            dh = self._dx(dm, p + "wfc2", ly.wfc2, M, D, 4 * D)
-            dhpre = self._f(M, 4 * D)
-            L.check(lib.sfmi_gelu_bwd_f32(L.ptr(dh), L.ptr(s["hpre"]), L.ptr(dhpre), M * 4 * D, L.stream_ptr()), "gelu_bwd")
+            dhpre = self._dx(dm, p + "wfc2", ly.wfc2, M, D, 4 * D, gelu_aux=s["hpre"])
             # fc1
-            self._colsum(dhpre, M, 4 * D, p + "bfc1")
             self._dW(dhpre, s["xn2"], M, 4 * D, D, p + "wfc1")
             dxn2 = self._dx(dhpre, p + "wfc1", ly.wfc1, M, 4 * D, D)
-            dr1 = self._ln_bwd(dxn2, s["r1"], ly.ln2[0], dr, M, p + "ln2.w", p + "ln2.b")
+            dr1, st2 = self._ln_rows(dxn2, s["r1"], ly.ln2[0], dr, M)
             # proj
             dp = drop_(dr1, site(p_resid, f"L{li}.proj"))
-            self._colsum(dp, M, D, p + "bproj")
             self._dW(dp, s["y"], M, D, D, p + "wproj")
             dy = self._dx(dp, p + "wproj", ly.wproj, M, D, D)
             # attention
@@ -309,10 +384,12 @@ class GPTTrainer:
             L.check(lib.sfmi_attn_bwd_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(lse), L.ptr(dqkv), B, Lq, D, g.H,
                                           *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn_bwd")
             # qkv
-            self._colsum(dqkv, M, 3 * D, p + "bqkv")
             self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv")
             dxn1 = self._dx(dqkv, p + "wqkv", ly.wqkv, M, 3 * D, D)
-            dr = self._ln_bwd(dxn1, s["x_in"], ly.ln1[0], dr1, M, p + "ln1.w", p + "ln1.b")
+            dr, st1 = self._ln_rows(dxn1, s["x_in"], ly.ln1[0], dr1, M)
+            # the block's four bias gradients and two LayerNorm parameter gradients: one launch
+            self._col_reduce([("b", dm, D, p + "bfc2"), ("b", dhpre, 4 * D, p + "bfc1"), ("b", dp, D, p + "bproj"), ("b", dqkv, 3 * D, p + "bqkv"),
+                              ("ln", dxn2, s["r1"], st2, p + "ln2.w", p + "ln2.b"), ("ln", dxn1, s["x_in"], st1, p + "ln1.w", p + "ln1.b")], M)
             saved[li] = None
             self._ready(f"L{li}")     # this block's 50 MB of gradients are final: all-reduce under the next blocks' backward
         # ---- embeddings (mingpt.py:256-286): E0[pos] + E1[val] + Ex[extra] + positional --------------------------------
@@ -357,10 +434,16 @@ class GPTTrainer:
                                                    self.betas[1], self.eps, self.step_count, L.ptr(self.flat_grad) if sharded else None,
                                                    L.stream_ptr()), "adamw_multi")
         if sharded:
-            self.buckets.all_gather_params()
-            fb = self._adam_tab
-            L.check(L.lib().sfmi_unflatten_multi_f32(L.ptr(fb["p"]), L.ptr(fb["foff"]), L.ptr(fb["ct"]), L.ptr(fb["co"]), L.ptr(fb["cl"]), fb["n"],
-                                                     L.ptr(self.flat_grad), L.stream_ptr()), "unflatten_multi")
+            # NOTE: from here on the flat buffer (and the self.grad[name] views into it) holds PARAMETER values, not gradients
+            if self.overlap_param_gather:
+                # one all-gather per bucket, launched in the order the next forward reads the parameters; each is waited for (and
+                # unflattened) right before its first use: _param_ready() in loss_and_grad / finish_param_gather()
+                self.buckets.launch_param_gathers(self._fwd_order)
+            else:
+                self.buckets.all_gather_params()
+                fb = self._adam_tab
+                L.check(L.lib().sfmi_unflatten_multi_f32(L.ptr(fb["p"]), L.ptr(fb["foff"]), L.ptr(fb["ct"]), L.ptr(fb["co"]), L.ptr(fb["cl"]), fb["n"],
+                                                         L.ptr(self.flat_grad), L.stream_ptr()), "unflatten_multi")
         self.g.mark_decode_weights_stale()  # LN-folded / fragment-packed decode weights are rebuilt at the next decode use
 
     def _chunk_table(self, ranges, CH=16384):
@@ -381,20 +464,37 @@ class GPTTrainer:
                     wd=torch.tensor(wd, dtype=torch.float32, device=dev), ct=torch.tensor(ct, dtype=torch.int32, device=dev),
                     co=torch.tensor(co, dtype=torch.int64, device=dev), cl=torch.tensor(cl, dtype=torch.int32, device=dev), n=len(ct))
 
+    def _sharded(self):
+        return self.buckets.active and self.buckets.mode == "rs_ag"
+
     def optimizer_state(self):
-        """Resume state: AdamW moments (flat, in parameter-table order) and the step count."""
-        m, v = self.flat_m, self.flat_v
-        if self.buckets.active and self.buckets.mode == "rs_ag":
-            # optimizer sharding: a rank holds the moments of its own slices only - gather them (a collective: every rank must call
-            # this) so that the checkpoint is complete and can be resumed in either synchronisation mode, on any world size
-            m, v = m.clone(), v.clone()
-            self.buckets.all_gather_flat(m)
-            self.buckets.all_gather_flat(v)
-        return dict(step=self.step_count, exp_avg=m.detach().cpu(), exp_avg_sq=v.detach().cpu(),
-                    names=[n for n, _, _ in self.params])
+        """Resume state, LOCAL (no collective): AdamW moments (flat, in parameter-table order) and the step count.  With the
+        sharded optimizer (grad_sync "rs_ag") a rank only holds the moments of its own slices: the dict then carries `shard_ranges`
+        (+ rank / world) and the other elements are zero; `gather_optimizer_state()` is the collective that completes it."""
+        st = dict(step=self.step_count, exp_avg=self.flat_m.detach().cpu(), exp_avg_sq=self.flat_v.detach().cpu(),
+                  names=[n for n, _, _ in self.params])
+        if self._sharded():
+            st.update(shard_ranges=[tuple(r) for r in self.buckets.shard_ranges()], rank=self.buckets.rank, world=self.buckets.world)
+        return st
+
+    def gather_optimizer_state(self):
+        """The complete optimizer state on EVERY rank (grad_sync "rs_ag": an all-gather of both moment buffers - a collective, to be
+        called by all ranks at the same point of the training loop, e.g. once per checkpoint interval; the result can be resumed in
+        either synchronisation mode, on any world size).  Without sharding this is optimizer_state()."""
+        if not self._sharded():
+            return self.optimizer_state()
+        m, v = self.flat_m.clone(), self.flat_v.clone()
+        self.buckets.all_gather_flat(m)
+        self.buckets.all_gather_flat(v)
+        return dict(step=self.step_count, exp_avg=m.cpu(), exp_avg_sq=v.cpu(), names=[n for n, _, _ in self.params])
 
     def load_optimizer_state(self, st):
         assert st["names"] == [n for n, _, _ in self.params], "optimizer state does not match this parameter table"
+        if st.get("shard_ranges") is not None:       # a rank-local state of a sharded run: only valid for the same rank of the same sharding
+            if not self._sharded() or (st["rank"], st["world"]) != (self.buckets.rank, self.buckets.world) or \
+                    [tuple(r) for r in st["shard_ranges"]] != [tuple(r) for r in self.buckets.shard_ranges()]:
+                raise ValueError("load_optimizer_state: a rank-local shard of a sharded optimizer can only be resumed by the same rank of the same "
+                                 "sharding; save gather_optimizer_state() to resume elsewhere")
         self.step_count = int(st["step"])
         self.flat_m.copy_(st["exp_avg"].to(self.dev))
         self.flat_v.copy_(st["exp_avg_sq"].to(self.dev))

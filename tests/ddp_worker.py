@@ -52,9 +52,20 @@ def main():
     out["rsag_table_chunks"] = np.int64(tr2._adam_tab_shard["n"])
     out["ring_table_chunks"] = np.int64(tr2._adam_tab["n"])
     tr2.training_step(c, z)
+    # the parameter all-gathers of the step were launched, not waited for: the next forward (or finish_param_gather) consumes them
+    out["rsag_gathers_in_flight"] = np.int64(len(tr2.buckets.params_in_flight()))
+    tr2.finish_param_gather()
     out["gpt_w_rsag"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr2.params])
     out["gpt_m_rsag"] = tr2.flat_m.detach().cpu().numpy().copy()     # moments exist only on the rank's shard
-    out["gpt_m_rsag_state"] = tr2.optimizer_state()["exp_avg"].numpy().copy()     # ... and are gathered when a checkpoint is written
+    local = tr2.optimizer_state()                                      # local, no collective: this rank's shard + its ranges
+    out["rsag_local_state_ranges"] = np.array(local["shard_ranges"], np.int64)
+    out["gpt_m_rsag_state"] = tr2.gather_optimizer_state()["exp_avg"].numpy().copy()     # the explicit collective completes it
+    # the blocking form (all gathers waited for right after the optimizer) leaves the same weights
+    g3 = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    tr3 = GPTTrainer(g3, lr=1e-3, dist=dist, grad_sync="rs_ag", overlap_param_gather=False)
+    tr3.training_step(c, z); tr3.training_step(c, z)
+    out["rsag_blocking_in_flight"] = np.int64(len(tr3.buckets.params_in_flight()))
+    out["gpt_w_rsag_blocking"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr3.params])
     out["gpt_m_ring"] = tr.flat_m.detach().cpu().numpy().copy()
     # ---- VQDIF autoencoder: item r of a 2-item batch; gradients averaged, EMA statistics summed over ranks ------
     T = np.load(os.path.join(G, "vqdif_train.npz"))

@@ -85,8 +85,15 @@ def test_gpt_trainer_reduce_scatter_all_gather_equals_ring(ranks):
     own0, own1 = m0 != 0, m1 != 0
     assert not np.any(own0 & own1) and np.array_equal(np.where(own0, m0, m1), np.where(own0 | own1, mr, 0))
     assert np.count_nonzero(own0 | own1) > 0.5 * np.count_nonzero(mr)
-    # optimizer_state() (what a checkpoint stores) gathers the shards: complete on every rank, equal to the ring mode's moments
+    # optimizer_state() is local (this rank's shard and its ranges: no collective); gather_optimizer_state() is the collective that
+    # completes it: the same on every rank, equal to the ring mode's moments
     assert np.array_equal(r0["gpt_m_rsag_state"], r1["gpt_m_rsag_state"]) and np.array_equal(r0["gpt_m_rsag_state"], mr)
+    assert r0["rsag_local_state_ranges"].shape == r1["rsag_local_state_ranges"].shape and not np.array_equal(r0["rsag_local_state_ranges"], r1["rsag_local_state_ranges"])
+    # the parameter all-gathers overlap the NEXT forward: after a step all five buckets (3 blocks, heads, embeddings) were still in
+    # flight, and the weights equal the blocking form's (and, above, the ring mode's) bit for bit
+    for r in (r0, r1):
+        assert int(r["rsag_gathers_in_flight"]) == 5 and int(r["rsag_blocking_in_flight"]) == 0
+        assert np.array_equal(r["gpt_w_rsag_blocking"], r["gpt_w_rsag"])
 
 
 def test_vqdif_trainer_two_ranks_gradient_mean_and_shared_ema_codebook(dev, ranks):

@@ -36,11 +36,13 @@ SO = os.path.join(ROOT, "tools", "ubench", "libstream_power.so")
 
 def build():
     if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(SRC):
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSFMI_NO_TUNE", "-o", SO, SRC])
     lib = ctypes.CDLL(SO)
     lib.sp_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               ctypes.c_void_p]
     lib.sp_launch.restype = ctypes.c_int
+    lib.sp_launch_attn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.sp_launch_attn.restype = ctypes.c_int
     return lib
 
 
@@ -51,8 +53,11 @@ def main():
     ap.add_argument("--rows", type=int, default=384)
     ap.add_argument("--L", type=int, default=416, help="cached length (mean over the 512 steps of the bench's conditions)")
     ap.add_argument("--variants", default="16040,16041,16042,16043,16020,16080,8080,8081,8082,8040,4160,4161,4162,4080")
+    ap.add_argument("--attn-flags", default="", help="comma list of attention-ingredient FLAGS variants (tools/ubench/stream_power.hip:attn_like_kernel), "
+                    "run in the layered launch form after the stream variants, e.g. 0,1,3,7,15,31,63")
+    ap.add_argument("--build-only", action="store_true", help="compile tools/ubench/stream_power.hip (no GPU needed) and exit")
     a = ap.parse_args()
-    if "--build-only" in sys.argv:
+    if a.build_only:
         build(); return
     lib = build()
     dev = torch.device("cuda:0")
@@ -76,7 +81,15 @@ def main():
         f"probe {probe.bdf} {sorted(probe.files)}")
     streams = [torch.cuda.Stream() for _ in range(2)]
 
+    qkv = torch.randn(4096 * 192, device=dev)
+
     def step(variant, form):
+        if form == "attn":             # the attention's ingredients on top of the stream (variant = FLAGS), the product's launch form
+            for li in range(NL * chains):
+                s = streams[li % 2]
+                rc = lib.sp_launch_attn(variant, buf.data_ptr(), qkv.data_ptr(), out.data_ptr(), li * items_launch, items_launch, a.L, s.cuda_stream)
+                assert rc == 0, (variant, rc)
+            return
         if form == "big":
             rc = lib.sp_launch(variant, buf.data_ptr(), out.data_ptr(), 0, nitems, a.L, nitems, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (variant, rc)
@@ -109,11 +122,16 @@ def main():
         e1.record(); e1.synchronize()
         pw = probe.stop()
         ms = e0.elapsed_time(e1) / n
+        if form == "attn":
+            names = ["dot+dpp", "lds-scores", "max-barrier", "exp-acc", "prologue", "epilogue"]
+            what = "+".join(n for i, n in enumerate(names) if variant >> i & 1) or "two-loop stream"
+            say(f"attn flags {variant:2d} {what:60s} ms/step {ms:7.3f}  {step_bytes / ms / 1e9:6.3f} TB/s {pw}")
+            return
         w, u, p = variant // 1000, variant % 1000 // 10, variant % 10
         pol = {0: "nt", 1: "default", 2: "buffer sc1", 3: "buffer default"}[p]
         say(f"v{variant:05d} {form:8s} {w:2d} waves U={u:<2d} {pol:14s} ms/step {ms:7.3f}  {step_bytes / ms / 1e9:6.3f} TB/s {pw}")
 
-    vs = [int(v) for v in a.variants.split(",")]
+    vs = [int(v) for v in a.variants.split(",") if v]
     for form in ("big", "layered"):
         for v in vs:
             try:
@@ -121,6 +139,12 @@ def main():
             except Exception as e:
                 say(f"v{v} {form} FAILED {type(e).__name__}: {e}")
                 torch.cuda.synchronize()
+    for f in (int(x) for x in a.attn_flags.split(",") if x):
+        try:
+            run(f, "attn")
+        except Exception as e:
+            say(f"attn flags {f} FAILED {type(e).__name__}: {e}")
+            torch.cuda.synchronize()
     # idle floor: the same probe with nothing running
     probe.start(); time.sleep(2.0)
     say("idle" + probe.stop())
