@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--grad-sync", default="ring", choices=["ring", "rs_ag"],
                     help="--mode train: ring = per-bucket all-reduce, every rank updates everything; rs_ag = per-bucket reduce-scatter, "
                          "AdamW on the rank's 1/N shard, all-gather of the updated parameters (north_star's path)")
+    ap.add_argument("--train-gemm", default="sk", choices=["sk", "tile"],
+                    help="--mode train: GEMM of the step: sk = work-balanced csrc/sgemm_sk.hip with fused GELU epilogues (default), tile = csrc/sgemm.hip + split-K reduce / GELU launches (rounds 2-4)")
     ap.add_argument("--train-lc", type=int, default=200)
     ap.add_argument("--train-lz", type=int, default=300)
     return ap.parse_args()
@@ -505,7 +507,7 @@ def main_train(a, rank, world, dev, dist):
     from shapeformer_amd.gpt import CondTupleGPT
     from shapeformer_amd.train import GPTTrainer
     g = CondTupleGPT(device=dev)
-    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist, grad_sync=a.grad_sync, profile_waits=True)
+    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist, grad_sync=a.grad_sync, profile_waits=True, gemm=a.train_gemm)
     c, z = synth_tokens(1000 + rank, a.train_batch, a.train_lc, a.train_lz)
     losses = []
     for _ in range(a.warmup):
@@ -518,6 +520,7 @@ def main_train(a, rank, world, dev, dist):
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = tr.training_step(c, z)
+    t_enq = time.perf_counter() - t0       # the host has ENQUEUED all steps (launches are asynchronous); if this is ~ the total, the step is host-bound
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -538,7 +541,7 @@ def main_train(a, rank, world, dev, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ShapeFormer DDP training step, synthetic IMNet-style token batches (BASELINE config 5)",
                        "batch_per_gpu": a.train_batch, "L_c": a.train_lc, "L_z": a.train_lz, "parallelism": f"dp{world}",
-                       "grad_sync_mode": a.grad_sync,
+                       "grad_sync_mode": a.grad_sync, "gemm": a.train_gemm,
                        "grad_sync": ("26 gradient buckets (one per block) all-reduced under the backward pass" if a.grad_sync == "ring" else
                                      "26 gradient buckets reduce-scattered under the backward pass, AdamW on the rank's 1/N shard, updated "
                                      "parameters all-gathered in place through the same flat buffer")},
@@ -547,6 +550,7 @@ def main_train(a, rank, world, dev, dist):
                                     "running after the last backward kernel = the EXPOSED communication (ms_per_step - this = compute); "
                                     "null without a process group"),
             "param_allgather_wait_ms": None if gather_ms is None else round(gather_ms, 3),
+            "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
             "grad_bytes_per_step": int(tr.flat_grad.numel() * 4),
             "model_TFLOPs": round(6 * 324.95e6 * tok / dt / 1e12, 2),
             "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}), flush=True)
@@ -573,6 +577,8 @@ def main():
     if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")      # --force-dist without torchrun: a one-rank group still needs a rendezvous
+        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         if a.share_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

@@ -122,7 +122,11 @@ int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* 
                          const float* beta, int S, int M, int P, int D, int Lmax, const int* rowoff, int B, void* stream);
 /* CausalSelfAttention.forward over the rows of a prefix (mingpt.py:73-91) on f32 MFMA; also writes the (B,H,Lmax,64) KV caches */
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
-                              int Lmax, const int* rowoff, void* stream);
+                              int Lmax, const int* rowoff, float attn_drop_p, unsigned attn_drop_seed /* training: mingpt.py:85 */, void* stream);
+/* the same launch; lse != NULL also receives the (B,H,P) row log-sum-exps of the scaled scores (the training forward: the backward
+ * pass, sfmi_attn_bwd_lse_f32, starts from them instead of recomputing Q K^T) */
+int sfmi_gpt_attn_prefill_lse_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
+                                  int Lmax, const int* rowoff, float attn_drop_p, unsigned attn_drop_seed, float* lse, void* stream);
 /* plain f32 GEMM on the matrix cores (csrc/sgemm.hip): row-major C (M,N;ldc) = op(A) op(B) (+C) (+bias[n]) -> act -> (+resid).
  * transA == 0: A stored (M,K;lda), else (K,M;lda); transB != 0: B stored (N,K;ldb) (nn.Linear weight), else (K,N;ldb).
  * Replaces the sgemm behind nn.Linear and its autograd (mingpt.py:46-111) in the prefill and the training step.
@@ -220,6 +224,10 @@ int sfmi_ce_fwd_bwd_f32(const float* logits, const int* target, float* loss_rows
                         int t0, float scale, void* stream);                                                    /* shapeformer.py:132-140 */
 int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* lse /*2*B*H*L floats scratch*/, float* dqkv,
                       int B, int L, int D, int H, float attn_drop_p, unsigned attn_drop_seed /* the forward's mask */, void* stream);
+/* the same gradients from the forward's row log-sum-exps (sfmi_gpt_attn_prefill_lse_f32): a row-sum launch (delta = sum_d dO O, (B,H,L)
+ * scratch) + ONE launch that runs the dQ blocks and the dK/dV blocks side by side (2 x the workgroups: fills the chip at batch 1) */
+int sfmi_attn_bwd_lse_f32(const float* qkv, const float* y, const float* dy, const float* lse, float* delta /*B*H*L floats scratch*/,
+                          float* dqkv, int B, int L, int D, int H, float attn_drop_p, unsigned attn_drop_seed, void* stream);
 /* nn.Dropout(p) forward == backward on a flat tensor: y = x * mask / (1-p), mask_i = hash(seed, i) >= p (mingpt.py:90,105,218,292) */
 int sfmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned seed, void* stream);                                                                           /* mingpt.py:73-91 */
 int sfmi_embed_scatter_f32(const float* dx, const int* idx, long long* acc, long long M, int D, void* stream);

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr, c_ptr]),
     "sfmi_gpt_attn_decode_gated_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [c_ptr, c_ptr, c_ptr, i32, c_ptr, c_ptr]),
     "sfmi_gpt_attn_prefill_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, f32, C.c_uint, c_ptr]),
+    "sfmi_gpt_attn_prefill_lse_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, f32, C.c_uint, c_ptr, c_ptr]),
     "sfmi_gpt_sample_f32": (i32, [c_ptr] * 12 + [i32] * 10 + [C.c_float, C.c_float] + [i32] * 4 + [C.c_uint, c_ptr, i32, i32, i32, i32, c_ptr]),
     "sfmi_gpt_mask_logits_f32": (i32, [c_ptr] * 5 + [i32] * 9 + [c_ptr]),
     "sfmi_decode_gemm_f32": (i32, [c_ptr] * 6 + [i32] * 8 + [c_ptr, c_ptr, c_ptr]),
@@ -122,6 +123,7 @@ PROTOTYPES = {
     "sfmi_col_reduce_f32": (i32, [i32] + [c_ptr] * 8 + [i32, i32, c_ptr, i64, c_ptr, i64, c_ptr]),
     "sfmi_ce_fwd_bwd_f32": (i32, [c_ptr] * 4 + [i32] * 5 + [C.c_float, c_ptr]),
     "sfmi_attn_bwd_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [f32, C.c_uint, c_ptr]),
+    "sfmi_attn_bwd_lse_f32": (i32, [c_ptr] * 6 + [i32] * 4 + [f32, C.c_uint, c_ptr]),
     "sfmi_dropout_f32": (i32, [c_ptr, c_ptr, i64, f32, C.c_uint, c_ptr]),
     "sfmi_embed_scatter_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, c_ptr]),
     "sfmi_fixed_to_float_f32": (i32, [c_ptr, c_ptr, i64, i32, c_ptr]),

@@ -609,7 +609,8 @@ template <int HD>           // head dim 16 / 32 / 64
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ Kc,
                                                                 float* __restrict__ Vc, const int* __restrict__ nval,
                                                                 float* __restrict__ y, int P, int D, int Lmax, float scale,
-                                                                const int* __restrict__ rowoff, float drop_p, unsigned drop_seed) {
+                                                                const int* __restrict__ rowoff, float drop_p, unsigned drop_seed,
+                                                                float* __restrict__ lse) {
   // row strides HD + 4: 16-byte aligned rows whose ds_read_b128 of 16 consecutive rows hit distinct banks; 51 KB of LDS per workgroup
   // at HD = 64 -> three resident workgroups per CU (a workgroup walks only 1-4 key blocks: its prologue latency needs company)
   constexpr int AP_KS = HD + 4, AP_VS = HD + 4, KK = HD / 4, DT = HD / 16;
@@ -761,6 +762,8 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     float* yp = y + (base + tq) * D + h * HD + lr;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) yp[16 * dt] = o[dt][j] * inv;
+    // training forward: the row's log-sum-exp of the scaled scores, (B,H,P) - the backward pass starts from it instead of recomputing Q K^T
+    if (lse && lr == 0) lse[((long long)b * gridDim.y + h) * P + tq] = mrun[j] + __logf(lrun[j]);
   }
 }
 
@@ -1307,16 +1310,23 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_part, const float* bqkv, float* Kc
 }
 
 // causal self-attention over the conditioning prefix (positions 0..Lc[b]-2), also fills the KV caches
+int sfmi_gpt_attn_prefill_lse_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
+                                  int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, float* lse, void* stream);
 int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                               int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, void* stream) {
+  return sfmi_gpt_attn_prefill_lse_f32(qkv, Kc, Vc, nval, y, B, P, D, H, Lmax, rowoff, drop_p, drop_seed, nullptr, stream);
+}
+// the same launch; lse != NULL also receives the (B,H,P) row log-sum-exps of the scaled scores (what sfmi_attn_bwd_lse_f32 starts from)
+int sfmi_gpt_attn_prefill_lse_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
+                                  int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, float* lse, void* stream) {
   const int HD = H > 0 ? D / H : 0;
   if (!qkv || !Kc || !Vc || !nval || !y || H <= 0 || D % H || (HD != 16 && HD != 32 && HD != 64) || P <= 0 || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   const dim3 grid(B, H, (P + 63) / 64);
   const float scale = 1.0f / sqrtf((float)HD);
   hipStream_t st = (hipStream_t)stream;
-  if (HD == 64) hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
-  else if (HD == 32) hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
-  else hipLaunchKernelGGL(attn_prefill_mfma_kernel<16>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed);
+  if (HD == 64) hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse);
+  else if (HD == 32) hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse);
+  else hipLaunchKernelGGL(attn_prefill_mfma_kernel<16>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -16,8 +16,8 @@
 // __syncthreads, no release/acquire fences: write-through stores + drained vmcnt + relaxed agent-scope ticket, MI355X guide G16) and
 // placement-independent.
 //
-// Two tile shapes: 128 x 128 (4 waves x 64 x 64, as csrc/sgemm.hip) when the output has >= 512 such tiles, else 64 x 64 (4 waves x
-// 32 x 32): four times the tiles, so a 500-row product is cut into 1-4 slices per tile instead of 8-16, and the partial traffic
+// Two tile shapes: 128 x 128 (4 waves x 64 x 64, as csrc/sgemm.hip) when a workgroup's share is >= 12 such chunks, else 64 x 64 (4 waves
+// x 32 x 32): four times the tiles, so a 500-row product is cut into 1-4 slices per tile instead of 8-16, and the partial traffic
 // stays a fraction of the output.  f32 MFMA issues one 32x32x2 per 64 cycles: LDS bandwidth is nowhere near a limit at either shape.
 // Operand storage, LDS layouts and the chunk pipeline follow csrc/sgemm.hip (two register prefetch sets, one barrier per chunk).
 //
@@ -342,12 +342,15 @@ hipError_t sk_attr() {
 
 extern "C" {
 
-// Tile shape of sfmi_sgemm_sk_f32 for a product: 2 = 128 x 128 workgroup tiles (>= 512 of them), 1 = 64 x 64.
+// Tile shape of sfmi_sgemm_sk_f32 for a product: 2 = 128 x 128 workgroup tiles, 1 = 64 x 64 (the `sk_tile` knob overrides).
 int sfmi_sgemm_sk_tile(int M, int N, int K) {
   (void)K;
   if (g_sfmi_tune.sk_tile) return g_sfmi_tune.sk_tile;
-  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-  return t128 >= 512 ? 2 : 1;
+  // 128 x 128 tiles run ~12 % faster per FLOP (half the operand traffic and barriers) but a cut tile costs a 64 KB slab round trip:
+  // they pay once a workgroup's share is >= 12 chunks of 128 x 128 x 32 (profiles/r05_kbench_sk_call1.txt: 3992-row products and
+  // long-K weight gradients); the 500-row products of the batch-1 step stay on 64 x 64
+  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128), nch = (K + 31) / 32;
+  return t128 * nch >= 12 * 512 ? 2 : 1;
 }
 // Scratch of sfmi_sgemm_sk_f32, valid for ANY product and any `sk_grid`: slab floats (1024 workgroups x 2 slots x 128 x 128 = 134 MB)
 // and the ticket counters a product of this output size needs (4 per 64 x 64 tile; zero them ONCE, the kernel re-arms them).

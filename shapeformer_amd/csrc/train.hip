@@ -342,15 +342,56 @@ __global__ __launch_bounds__(256) void attn_stats_mfma_kernel(const float* __res
   if (lq == 0 && q0 + 16 * wave + lr < L) delta[sb + q0 + 16 * wave + lr] = dl;
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
-                                                               unsigned drop_seed) {
-  __shared__ __attribute__((aligned(16))) float Ks[64 * AB_S], Vs[64 * AB_S], Ts[4][16 * AB_S];
-  const int b = blockIdx.x, h = blockIdx.y, qb = blockIdx.z, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// delta[b][h][t] = sum_d dO[b,t,h,d] * O[b,t,h,d]: one wave per row, lane l covers the H floats l*H .. l*H+H-1 of the row (D = 64 H, so a
+// head is 64 / H consecutive lanes).  Needed by both halves of the backward; a few microseconds.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ delta,
+                                                         int B, int L, int D, int H) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * L) return;
+  const float* yp = y + (long long)row * D + lane * H;
+  const float* dp = dy + (long long)row * D + lane * H;
+  float sacc = 0.f;
+  for (int e = 0; e < H; ++e) sacc += yp[e] * dp[e];
+  const int lph = 64 / H;      // lanes per head
+  for (int o = 1; o < lph; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
+  if (lane % lph == 0) {
+    const int b = row / L, t = row - b * L, h = lane / lph;
+    delta[((long long)b * H + h) * L + t] = sacc;
+  }
+}
+
+// one 64-row tile of a (b, h) slice: global -> registers (4 float4 per thread) -> stride-68 LDS tile.  The loads of block i+1 are
+// issued right after block i has been handed to LDS, so their latency runs under the block's 192 / 256 MFMAs per wave.
+__device__ __forceinline__ void ab_load(f32x4 (&r)[4], const float* __restrict__ src, long long row_base, int r0, int L, int ld, int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = tid + 256 * it, rr = i >> 4, c = i & 15;
+    const int t = min(r0 + rr, L - 1);
+    r[it] = *reinterpret_cast<const f32x4*>(src + (row_base + t) * ld + 4 * c);
+  }
+}
+__device__ __forceinline__ void ab_store(float* __restrict__ dst, const f32x4 (&r)[4], int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = tid + 256 * it, rr = i >> 4, c = i & 15;
+    *reinterpret_cast<f32x4*>(&dst[rr * AB_S + 4 * c]) = r[it];
+  }
+}
+
+// dQ of query block qb (the former attn_bwd_dq_mfma_kernel: same arithmetic, same order)
+__device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem, const float* __restrict__ qkv, const float* __restrict__ dy,
+                                                 const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
+                                                 int b, int h, int H, int qb, int L, int D, float scale, float drop_p, unsigned drop_seed) {
+  float* Ks = smem;
+  float* Vs = smem + 64 * AB_S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Tw = smem + 2 * 64 * AB_S + wave * 16 * AB_S;
   const int lr = lane & 15, lq = lane >> 4, q0 = qb * 64;
   const long long rb = (long long)b * L, sb = ((long long)b * H + h) * L;
   const int trow = min(q0 + 16 * wave + lr, L - 1);
+  f32x4 pk[4], pv[4];
+  ab_load(pk, qkv + D + h * 64, rb, 0, L, 3 * D, tid);
+  ab_load(pv, qkv + 2 * D + h * 64, rb, 0, L, 3 * D, tid);
   float qf[16], dof[16];
   {
     const float* qp = qkv + (rb + trow) * 3 * D + h * 64 + lq;
@@ -367,13 +408,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
   f32x4 dq[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float* Tw = Ts[wave];
   const int kend = min(L, q0 + 64);
   for (int k0 = 0; k0 < kend; k0 += 64) {
     __syncthreads();
-    ab_stage(Ks, qkv + D + h * 64, rb, k0, L, 3 * D, tid);
-    ab_stage(Vs, qkv + 2 * D + h * 64, rb, k0, L, 3 * D, tid);
+    ab_store(Ks, pk, tid);
+    ab_store(Vs, pv, tid);
     __syncthreads();
+    if (k0 + 64 < kend) {
+      ab_load(pk, qkv + D + h * 64, rb, k0 + 64, L, 3 * D, tid);
+      ab_load(pv, qkv + 2 * D + h * 64, rb, k0 + 64, L, 3 * D, tid);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
@@ -412,15 +456,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
-                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
-                                                                unsigned drop_seed) {
-  __shared__ __attribute__((aligned(16))) float Qs[64 * AB_S], Os[64 * AB_S], Pt[4][16 * AB_S], St[4][16 * AB_S];
-  const int b = blockIdx.x, h = blockIdx.y, kb_ = blockIdx.z, H = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// dK / dV of key block kb_ (the former attn_bwd_dkv_mfma_kernel: same arithmetic, same order)
+__device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem, const float* __restrict__ qkv, const float* __restrict__ dy,
+                                                  const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
+                                                  int b, int h, int H, int kb_, int L, int D, float scale, float drop_p, unsigned drop_seed) {
+  float* Qs = smem;
+  float* Os = smem + 64 * AB_S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Pw = smem + 2 * 64 * AB_S + wave * 16 * AB_S;
+  float* Sw = smem + 2 * 64 * AB_S + 4 * 16 * AB_S + wave * 16 * AB_S;
   const int lr = lane & 15, lq = lane >> 4, k0 = kb_ * 64;
   const long long rb = (long long)b * L, sb = ((long long)b * H + h) * L;
   const int krow = min(k0 + 16 * wave + lr, L - 1);
+  f32x4 pq[4], po[4];
+  ab_load(pq, qkv + h * 64, rb, k0, L, 3 * D, tid);
+  ab_load(po, dy + h * 64, rb, k0, L, D, tid);
   float kf[16], vf[16];
   {
     const float* kp = qkv + (rb + krow) * 3 * D + D + h * 64 + lq;
@@ -430,13 +480,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
   f32x4 dk[4], dv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
-  float* Pw = Pt[wave];
-  float* Sw = St[wave];
   for (int q0 = k0; q0 < L; q0 += 64) {
     __syncthreads();
-    ab_stage(Qs, qkv + h * 64, rb, q0, L, 3 * D, tid);
-    ab_stage(Os, dy + h * 64, rb, q0, L, D, tid);
+    ab_store(Qs, pq, tid);
+    ab_store(Os, po, tid);
     __syncthreads();
+    if (q0 + 64 < L) {
+      ab_load(pq, qkv + h * 64, rb, q0 + 64, L, 3 * D, tid);
+      ab_load(po, dy + h * 64, rb, q0 + 64, L, D, tid);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
@@ -478,6 +530,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { o[16 * dt] = dk[dt][j] * scale; o[D + 16 * dt] = dv[dt][j]; }
   }
+}
+
+// Both halves of the attention backward in ONE launch (round 5; rounds 1-4: stats + dq + dkv = three launches, the first of which
+// recomputed Q K^T only to get the row log-sum-exps the forward pass already had): grid (B, H, 2 * ceil(L / 64)); z even: dQ of query
+// block nqb - 1 - z / 2, z odd: dK / dV of key block z / 2 - the longest loops of either kind are dispatched first.  The two kinds are
+// independent given lse and delta, so the launch has twice the workgroups of either (256 at batch 1: every CU gets one), and the
+// causal imbalance of one kind (1 .. nqb blocks per workgroup) is filled by the other.
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
+                                                                unsigned drop_seed) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 64 * AB_S + 8 * 16 * AB_S];
+  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, z = blockIdx.z, nqb = gridDim.z >> 1;
+  if (z & 1) attn_bwd_dkv_role(smem, qkv, dy, lse, delta, dqkv, b, h, H, z >> 1, L, D, scale, drop_p, drop_seed);
+  else attn_bwd_dq_role(smem, qkv, dy, lse, delta, dqkv, b, h, H, nqb - 1 - (z >> 1), L, D, scale, drop_p, drop_seed);
 }
 
 // softmax cross-entropy: loss_row[m] = lse - logit[target] ; dlogits = (softmax - onehot) * scale for rows with
@@ -707,16 +774,28 @@ int sfmi_ce_fwd_bwd_f32(const float* logits, const int* target, float* loss_rows
   return SFMI_OK;
 }
 // causal self-attention backward (mingpt.py:73-91), head dim 64: dqkv (B*L,3D) from qkv, y, dy.  lse: 2*B*H*L floats of scratch
-// (row log-sum-exps, then row sums of dO*O).
+// (row log-sum-exps, then row sums of dO*O), both recomputed here (attn_stats_mfma_kernel) - the form for callers that did not keep
+// the forward's log-sum-exps; then the fused dQ | dK/dV launch.
 int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* lse, float* dqkv, int B, int L, int D, int H,
                       float drop_p, unsigned drop_seed, void* stream) {
-  if (!qkv || !y || !dy || !lse || !dqkv || D / H != 64 || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
+  if (!qkv || !y || !dy || !lse || !dqkv || D / H != 64 || D % H || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(B, H, (L + 63) / 64);
+  const int nqb = (L + 63) / 64;
   float* delta = lse + (size_t)B * H * L;
-  hipLaunchKernelGGL(attn_stats_mfma_kernel, grid, dim3(256), 0, st, qkv, y, dy, lse, delta, L, D, 0.125f);
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  hipLaunchKernelGGL(attn_stats_mfma_kernel, dim3(B, H, nqb), dim3(256), 0, st, qkv, y, dy, lse, delta, L, D, 0.125f);
+  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B, H, 2 * nqb), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// the same from the forward's (B,H,L) log-sum-exps (sfmi_gpt_attn_prefill_lse_f32): a row-sum launch for delta (B*H*L floats of scratch)
+// + the fused launch.  H must divide 64 (head dim 64: D = 64 H).
+int sfmi_attn_bwd_lse_f32(const float* qkv, const float* y, const float* dy, const float* lse, float* delta, float* dqkv, int B, int L,
+                          int D, int H, float drop_p, unsigned drop_seed, void* stream) {
+  if (!qkv || !y || !dy || !lse || !delta || !dqkv || H <= 0 || D != 64 * H || 64 % H || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nqb = (L + 63) / 64;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long long)B * L + 3) / 4)), dim3(256), 0, st, y, dy, delta, B, L, D, H);
+  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B, H, 2 * nqb), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

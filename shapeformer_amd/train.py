@@ -250,6 +250,7 @@ class GPTTrainer:
         g, D, dev, lib = self.g, self.D, self.dev, L.lib()
         self._acc, self._sync = accumulate, sync
         self._param_ready("emb")       # rs_ag: the embeddings' gathered parameters leave the flat buffer before it is written again
+        self._param_ready("L0")        # the embedding kernel also applies block 0's first LayerNorm
         if not accumulate:
             # every gradient below is WRITTEN (GEMM / column-reduction epilogues), except the embedding tables: E0 is accumulated
             # twice and the positional tables only receive the rows the batch touches - those 57 MB are zeroed, not the 1.3 GB buffer
@@ -292,13 +293,13 @@ class GPTTrainer:
             g._embed(st, B, Lq, resid, xn, g.layers[0].ln1)
         head_in = {}
         for li, ly in enumerate(g.layers):
-            self._param_ready(f"L{li}")
             s = dict(x_in=resid, xn1=xn)
             qkv = self._f(M, 3 * D)
             self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
             y = self._f(M, D)
-            L.check(lib.sfmi_gpt_attn_prefill_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
-                                                  g.H, g.Lmax + 1, None, *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn")
+            lse_l = self._f(B, g.H, Lq)        # row log-sum-exps of the scaled scores: the attention backward starts from them
+            L.check(lib.sfmi_gpt_attn_prefill_lse_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
+                                                      g.H, g.Lmax + 1, None, *site(p_attn, f"L{li}.attn"), L.ptr(lse_l), L.stream_ptr()), "attn")
             r1 = self._f(M, D)
             self._gemm(y, ly.wproj, ly.bproj, resid, r1, M, D, D, drop=site(p_resid, f"L{li}.proj"))
             xn2 = self._f(M, D)
@@ -307,7 +308,7 @@ class GPTTrainer:
             self._gemm(xn2, ly.wfc1, ly.bfc1, None, h, M, 4 * D, D, act=2, c2=hpre)     # h = GELU(hpre), both kept (mingpt.py:102-103)
             r2 = self._f(M, D)
             self._gemm(h, ly.wfc2, ly.bfc2, r1, r2, M, D, 4 * D, drop=site(p_resid, f"L{li}.mlp"))
-            s.update(qkv=qkv, y=y, r1=r1, xn2=xn2, hpre=hpre, h=h)
+            s.update(qkv=qkv, y=y, r1=r1, xn2=xn2, hpre=hpre, h=h, lse=lse_l)
             saved.append(s)
             resid = r2
             last = li + 1 == len(g.layers) or g.layers[li + 1].stage != ly.stage
@@ -315,6 +316,7 @@ class GPTTrainer:
                 head_in[ly.stage] = resid
             if li + 1 < len(g.layers):
                 nxt = g.layers[li + 1]
+                self._param_ready(f"L{li + 1}")      # the next block's parameters (its ln1 is applied right here)
                 xn = self._f(M, D)
                 if nxt.stage != ly.stage:
                     r3 = self._f(M, D)
@@ -357,7 +359,7 @@ class GPTTrainer:
         self._ready("heads")
         # ---- backward through the blocks -----------------------------------------------------------------------------
         dr = d_head[1]
-        lse = self._f(2, B, g.H, Lq)      # row log-sum-exps + row sums of dO*O (scratch of sfmi_attn_bwd_f32)
+        delta = self._f(B, g.H, Lq)       # row sums of dO * O (scratch of sfmi_attn_bwd_lse_f32)
         for li in range(len(g.layers) - 1, -1, -1):
             ly, s, p = g.layers[li], saved[li], f"L{li}."
             if li + 1 < len(g.layers) and g.layers[li + 1].stage != ly.stage:
@@ -381,8 +383,8 @@ class GPTTrainer:
             dy = self._dx(dp, p + "wproj", ly.wproj, M, D, D)
             # attention
             dqkv = self._f(M, 3 * D)
-            L.check(lib.sfmi_attn_bwd_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(lse), L.ptr(dqkv), B, Lq, D, g.H,
-                                          *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn_bwd")
+            L.check(lib.sfmi_attn_bwd_lse_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(s["lse"]), L.ptr(delta), L.ptr(dqkv), B, Lq, D, g.H,
+                                              *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn_bwd")
             # qkv
             self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv")
             dxn1 = self._dx(dqkv, p + "wqkv", ly.wqkv, M, 3 * D, D)

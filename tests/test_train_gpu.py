@@ -188,3 +188,59 @@ def test_library_gemm_binding_and_large_row_training_path(dev, monkeypatch):
             got = tr.grad[name].cpu().reshape(want.shape)
             err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
             assert err < 2e-3, (name, use_lib, err)
+
+
+@pytest.mark.parametrize("B,L,H", [(1, 499, 16), (2, 150, 2), (3, 64, 4)])
+def test_attention_backward_fused_launch_from_the_forward_lse(dev, B, L, H):
+    """Round 5: the training forward keeps the rows' log-sum-exps (sfmi_gpt_attn_prefill_lse_f32) and the backward is a row-sum launch
+    + ONE launch that runs the dQ and the dK / dV blocks side by side (sfmi_attn_bwd_lse_f32).  Against torch autograd of the same
+    causal attention (mingpt.py:73-91, fp64 on the CPU), and against the form that recomputes the log-sum-exps (sfmi_attn_bwd_f32)."""
+    from shapeformer_amd import _lib as L_
+    lib = L_.lib()
+    D = 64 * H
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    qkv = torch.randn(B * L, 3 * D, generator=g)
+    dy = torch.randn(B * L, D, generator=g)
+    # reference
+    x = qkv.double().clone().requires_grad_(True)
+    q, k, v = (x[:, i * D:(i + 1) * D].view(B, L, H, 64).transpose(1, 2) for i in range(3))
+    att = (q @ k.transpose(-1, -2)) / 8.0
+    att = att.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf")).softmax(-1)
+    yref = (att @ v).transpose(1, 2).reshape(B * L, D)
+    yref.backward(dy.double())
+    lse_ref = torch.logsumexp((q @ k.transpose(-1, -2) / 8.0).masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf")), -1)
+    # device
+    qd, dyd = qkv.to(dev), dy.to(dev)
+    Lmax = L + 1
+    kv = torch.empty(2, B, Lmax, D, device=dev)
+    nval = torch.full((B,), L, device=dev, dtype=torch.int32)
+    y, lse = torch.empty(B * L, D, device=dev), torch.empty(B, H, L, device=dev)
+    L_.check(lib.sfmi_gpt_attn_prefill_lse_f32(L_.ptr(qd), L_.ptr(kv[0]), L_.ptr(kv[1]), L_.ptr(nval), L_.ptr(y), B, L, D, H, Lmax, None, 0.0, 0,
+                                               L_.ptr(lse), L_.stream_ptr()), "attn fwd")
+    assert float((y.cpu().double() - yref.detach()).abs().max()) < 2e-5
+    assert float((lse.cpu().double() - lse_ref.detach()).abs().max()) < 2e-5
+    delta, dq1 = torch.empty(B, H, L, device=dev), torch.full((B * L, 3 * D), float("nan"), device=dev)
+    L_.check(lib.sfmi_attn_bwd_lse_f32(L_.ptr(qd), L_.ptr(y), L_.ptr(dyd), L_.ptr(lse), L_.ptr(delta), L_.ptr(dq1), B, L, D, H, 0.0, 0, L_.stream_ptr()), "bwd lse")
+    scale = float(x.grad.abs().max())
+    assert float((dq1.cpu().double() - x.grad).abs().max()) < 3e-5 * scale
+    scratch, dq2 = torch.empty(2, B, H, L, device=dev), torch.full((B * L, 3 * D), float("nan"), device=dev)
+    L_.check(lib.sfmi_attn_bwd_f32(L_.ptr(qd), L_.ptr(y), L_.ptr(dyd), L_.ptr(scratch), L_.ptr(dq2), B, L, D, H, 0.0, 0, L_.stream_ptr()), "bwd stats")
+    assert float((dq1 - dq2).abs().max()) < 2e-5 * scale
+    assert float((scratch[0] - lse).abs().max()) < 1e-5 and float((scratch[1] - delta).abs().max()) < 1e-4 * float(delta.abs().max())
+    # with attention dropout the two forms still agree (same counter-hash mask in both halves)
+    L_.check(lib.sfmi_attn_bwd_lse_f32(L_.ptr(qd), L_.ptr(y), L_.ptr(dyd), L_.ptr(lse), L_.ptr(delta), L_.ptr(dq1), B, L, D, H, 0.1, 99, L_.stream_ptr()), "bwd lse")
+    L_.check(lib.sfmi_attn_bwd_f32(L_.ptr(qd), L_.ptr(y), L_.ptr(dyd), L_.ptr(scratch), L_.ptr(dq2), B, L, D, H, 0.1, 99, L_.stream_ptr()), "bwd stats")
+    assert float((dq1 - dq2).abs().max()) < 2e-5 * scale and bool(torch.isfinite(dq1).all())
+
+
+def test_training_step_gemm_forms_agree(dev):
+    """The step on the work-balanced GEMM with fused GELU epilogues (gemm="sk", the default) and on the round 2-4 form (one workgroup
+    per tile + split-K reduce + separate GELU launches, gemm="tile") give the same loss and gradients to fp32 rounding."""
+    from shapeformer_amd.train import GPTTrainer
+    sd, cfg, g, c, z = _setup(dev)
+    ta, tb = GPTTrainer(g, gemm="sk"), GPTTrainer(g, gemm="tile")
+    la, lb = ta.loss_and_grad(c, z, dropout_key="k"), tb.loss_and_grad(c, z, dropout_key="k")
+    assert abs(float(la) - float(lb)) < 1e-5
+    for name in ta.grad:
+        a, b = ta.grad[name], tb.grad[name]
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, name

@@ -9,6 +9,8 @@
 #   sweep=<tools/sweeps file>[,reps]   tools/ar_sweep.py < file                                  -> ar_sweep_<file>.txt
 #   bench[=<bench.py args>]       python bench.py <args, default the driver's "--gpus 1 --steps 20 --warmup 5">  -> bench_<n>.json
 #   trace=<name>:<command>        rocprofv3 --kernel-trace --stats of <command> (tools/prof_run.sh)  -> prof_<name>.txt
+#   pmc=<name>:<counters>:<kernel LIKE pattern>:<command>   one rocprofv3 --pmc pass (--kernel-trace only, as the pool requires) and the
+#                                 per-kernel counter averages (tools/pmc_summary.py); counters separated by "+"     -> pmc_<name>.txt
 # Steps that contain spaces must be quoted by the caller.
 cd "$(dirname "$0")/.."
 TAG=$1; shift
@@ -32,6 +34,12 @@ for step in "$@"; do
     trace)
       name=${arg%%:*}; cmd=${arg#*:}
       PROF_OUT=$PWD/$O timeout 1000 tools/prof_run.sh $name $cmd > $O/trace_$name.log 2>&1; head -n 30 $O/prof_$name.txt | cut -c1-200 ;;
+    pmc)
+      name=${arg%%:*}; rest=${arg#*:}; ctr=${rest%%:*}; rest=${rest#*:}; pat=${rest%%:*}; cmd=${rest#*:}
+      rm -rf /tmp/pmc_$name
+      (cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --pmc ${ctr//+/ } -d /tmp/pmc_$name -- $cmd > /tmp/pmc_$name.log 2>&1)
+      DB=$(find /tmp/pmc_$name -name "*.db" | head -1)
+      { echo "### --pmc ${ctr//+/ } -- $cmd"; python tools/pmc_summary.py $DB "$pat"; } > $O/pmc_$name.txt 2>&1; tail -n 40 $O/pmc_$name.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
