@@ -95,40 +95,58 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
     ka[i] = AK ? 4 * (tid & 7) : tid / CPR + (256 / CPR) * i;
     kb[i] = BK ? 4 * (tid & 7) : tid / CPR + (256 / CPR) * i;
   }
+  // TM == 2: the per-thread pointers include the thread's k offset inside a chunk (as in csrc/sgemm.hip).  TM == 1: they point at k = 0
+  // of the thread's row / column, and the k term is added per load - so that an out-of-range k can fall back to k = 0 (a valid address)
   auto set_tile = [&](int m0, int n0) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      if (AK) pa[i] = a.A + (long long)min(m0 + (tid >> 3) + 32 * i, a.M - 1) * a.lda + ka[i];
-      else pa[i] = a.A + (long long)ka[i] * a.lda + min(m0 + 4 * (tid % CPR), a.M - 4);
-      if (BK) pb[i] = a.B + (long long)min(n0 + (tid >> 3) + 32 * i, a.N - 1) * a.ldb + kb[i];
-      else pb[i] = a.B + (long long)kb[i] * a.ldb + min(n0 + 4 * (tid % CPR), a.N - 4);
+      const int kpa = TM == 2 ? ka[i] : 0, kpb = TM == 2 ? kb[i] : 0;
+      if (AK) pa[i] = a.A + (long long)min(m0 + (tid >> 3) + 32 * i, a.M - 1) * a.lda + kpa;
+      else pa[i] = a.A + (long long)kpa * a.lda + min(m0 + 4 * (tid % CPR), a.M - 4);
+      if (BK) pb[i] = a.B + (long long)min(n0 + (tid >> 3) + 32 * i, a.N - 1) * a.ldb + kpb;
+      else pb[i] = a.B + (long long)kpb * a.ldb + min(n0 + 4 * (tid % CPR), a.N - 4);
     }
   };
+  // Branch-free: a k beyond K (the zero-filled tail of the last chunk) reads a valid address instead (k offset 0) and the VALUE is
+  // replaced by zero when the registers are handed to LDS (store_chunk: not here, or the select would wait for the load at once).  A conditional load - or two code paths that join - would make hipcc wait for ALL outstanding loads
+  // at the next use (the prefetch of the other register set included), which exposes a full memory latency per chunk.
   auto load_chunk = [&](f32x4 (&xa)[NL], f32x4 (&xb)[NL], int k0) {
-    const long long oa = AK ? (long long)k0 : (long long)k0 * a.lda, ob = BK ? (long long)k0 : (long long)k0 * a.ldb;
-    if (k0 + SK_KC <= a.K) {
+    if constexpr (TM == 2) {      // the 128 x 128 form sits at the 256-register budget: the two-path loads of csrc/sgemm.hip (no select to carry)
+      const long long oa = AK ? (long long)k0 : (long long)k0 * a.lda, ob = BK ? (long long)k0 : (long long)k0 * a.ldb;
+      if (k0 + SK_KC <= a.K) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          xa[i] = *reinterpret_cast<const f32x4*>(pa[i] + oa);
+          xb[i] = *reinterpret_cast<const f32x4*>(pb[i] + ob);
+        }
+      } else {      // the tail chunk zero-fills k >= K
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          xa[i] = k0 + ka[i] < a.K ? *reinterpret_cast<const f32x4*>(pa[i] + oa) : f32x4{0.f, 0.f, 0.f, 0.f};
+          xb[i] = k0 + kb[i] < a.K ? *reinterpret_cast<const f32x4*>(pb[i] + ob) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    } else {
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
+        const int kA = k0 + ka[i] < a.K ? k0 + ka[i] : 0, kB = k0 + kb[i] < a.K ? k0 + kb[i] : 0;      // k = 0 .. 3 always exists
+        const long long oa = AK ? (long long)kA : (long long)kA * a.lda, ob = BK ? (long long)kB : (long long)kB * a.ldb;
         xa[i] = *reinterpret_cast<const f32x4*>(pa[i] + oa);
         xb[i] = *reinterpret_cast<const f32x4*>(pb[i] + ob);
       }
-    } else {      // the tail chunk zero-fills k >= K
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        xa[i] = k0 + ka[i] < a.K ? *reinterpret_cast<const f32x4*>(pa[i] + oa) : f32x4{0.f, 0.f, 0.f, 0.f};
-        xb[i] = k0 + kb[i] < a.K ? *reinterpret_cast<const f32x4*>(pb[i] + ob) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
     }
   };
-  auto store_chunk = [&](const f32x4 (&xa)[NL], const f32x4 (&xb)[NL], int buf) {
+  auto store_chunk = [&](const f32x4 (&xa)[NL], const f32x4 (&xb)[NL], int buf, int k0) {      // k0: the k the registers were loaded for
     float* as = As + buf * TILE;
     float* bs = Bs + buf * TILE;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      if (AK) *reinterpret_cast<f32x4*>(as + ((tid >> 3) + 32 * i) * SK_KS + 4 * (tid & 7)) = xa[i];
-      else *reinterpret_cast<f32x4*>(as + ka[i] * RS + 4 * (tid % CPR)) = xa[i];
-      if (BK) *reinterpret_cast<f32x4*>(bs + ((tid >> 3) + 32 * i) * SK_KS + 4 * (tid & 7)) = xb[i];
-      else *reinterpret_cast<f32x4*>(bs + kb[i] * RS + 4 * (tid % CPR)) = xb[i];
+      const f32x4 va = (TM == 2 || k0 + ka[i] < a.K) ? xa[i] : zero, vb = (TM == 2 || k0 + kb[i] < a.K) ? xb[i] : zero;
+      if (AK) *reinterpret_cast<f32x4*>(as + ((tid >> 3) + 32 * i) * SK_KS + 4 * (tid & 7)) = va;
+      else *reinterpret_cast<f32x4*>(as + ka[i] * RS + 4 * (tid % CPR)) = va;
+      if (BK) *reinterpret_cast<f32x4*>(bs + ((tid >> 3) + 32 * i) * SK_KS + 4 * (tid & 7)) = vb;
+      else *reinterpret_cast<f32x4*>(bs + kb[i] * RS + 4 * (tid % CPR)) = vb;
     }
   };
 
@@ -137,28 +155,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
     const float* as = As + buf * TILE;
     const float* bs = Bs + buf * TILE;
     if constexpr (TM == 1) {
-      // one 32 x 32 tile per wave: 16 MFMAs on ONE accumulator per chunk.  All eight operand fragments of the chunk are requested up
-      // front (32 registers), so the MFMAs of group g never wait for an LDS round trip issued after group g - 1 (the compiler does
-      // not pipeline the reads on its own: 2 reads -> wait -> 4 dependent MFMAs would expose ~100 cycles per 256)
-      f32x4 mf[SK_KC / 8], nf[SK_KC / 8];
-#pragma unroll
-      for (int g = 0; g < SK_KC / 8; ++g) {
-        if (AK) mf[g] = *reinterpret_cast<const f32x4*>(as + (32 * wm + pl) * SK_KS + 8 * g + 4 * hi);
-        else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) mf[g][q] = as[(8 * g + 4 * hi + q) * RS + 32 * wm + pl];
-        }
-        if (BK) nf[g] = *reinterpret_cast<const f32x4*>(bs + (32 * wn + pl) * SK_KS + 8 * g + 4 * hi);
-        else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) nf[g][q] = bs[(8 * g + 4 * hi + q) * RS + 32 * wn + pl];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs (the scheduler would sink each pair to its use)
-#pragma unroll
-      for (int g = 0; g < SK_KC / 8; ++g)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[0][0] = SK_MFMA(nf[g][q], mf[g][q], acc[0][0]);
+      (void)as; (void)bs;      // TM == 1 runs the pipelined loop below (read_frags / mfma_frags)
     } else {
 #pragma unroll
       for (int g = 0; g < SK_KC / 8; ++g) {     // k8 groups: MFMA q of the group multiplies k = 8 g + 4 hi + q
@@ -191,6 +188,33 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
             for (int j = 0; j < TM; ++j) acc[i][j] = SK_MFMA(nf[i][q], mf[j][q], acc[i][j]);
       }
     }
+  };
+
+  // TM == 1: one 32 x 32 tile per wave, 16 MFMAs on ONE accumulator per chunk.  All eight operand fragments of a chunk (32 registers)
+  // are read in one burst right after the barrier that publishes the chunk, i.e. one iteration AHEAD of their MFMAs (see the loop).
+  f32x4 fm[SK_KC / 8], fn[SK_KC / 8];
+  auto read_frags = [&](int buf) {
+    const float* as = As + buf * TILE;
+    const float* bs = Bs + buf * TILE;
+#pragma unroll
+    for (int g = 0; g < SK_KC / 8; ++g) {
+      if (AK) fm[g] = *reinterpret_cast<const f32x4*>(as + (32 * wm + pl) * SK_KS + 8 * g + 4 * hi);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fm[g][q] = as[(8 * g + 4 * hi + q) * RS + 32 * wm + pl];
+      }
+      if (BK) fn[g] = *reinterpret_cast<const f32x4*>(bs + (32 * wn + pl) * SK_KS + 8 * g + 4 * hi);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fn[g][q] = bs[(8 * g + 4 * hi + q) * RS + 32 * wn + pl];
+      }
+    }
+  };
+  auto mfma_frags = [&]() {
+#pragma unroll
+    for (int g = 0; g < SK_KC / 8; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[0][0] = SK_MFMA(fn[g][q], fm[g][q], acc[0][0]);
   };
 
   // ---- epilogue of one finished tile (this wave's sub-tile) ---------------------------------------------------------------------
@@ -264,17 +288,67 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
     load_chunk(ra[0], rb[0], c_lo * SK_KC);
-    if (nchunks > 1) load_chunk(ra[1], rb[1], (c_lo + 1) * SK_KC);
-    for (int c = 0; c < nchunks; c += 2) {
-      store_chunk(ra[0], rb[0], 0);
+    if (TM == 1) __builtin_amdgcn_sched_barrier(0);      // keep the prologue's loads in chunk order (see the loop's comment)
+    if (TM == 1 || nchunks > 1) load_chunk(ra[1], rb[1], min(c_lo + 1, c_lo + nchunks - 1) * SK_KC);
+    if constexpr (TM == 1) {
+      // Pipelined so that a wave's MFMAs run back to back (PMC of the plain loop at 500 rows: matrix pipes busy 45 % of the launch, the
+      // waves of a workgroup - and of the two workgroups of a CU - hit store / barrier / fragment-read phases together).  Iteration c:
+      //   [A] chunk c+1: staging registers -> LDS buffer (c+1)&1     (its global loads were issued two iterations ago)
+      //   [B] chunk c+3: global loads into the registers [A] just freed
+      //   [C] the 16 MFMAs of chunk c, from fragment registers read in the PREVIOUS iteration
+      //   [D] barrier: chunk c+1 is published (every wave's reads of that buffer - [E] of iteration c-1 - precede it in program order)
+      //   [E] the fragments of chunk c+1 -> registers
+      // The LDS-write latency of [A] and the read latency of [E] run under the MFMAs instead of between them; one barrier per chunk.
+      // The body carries no condition but the loop exit: loads beyond the segment re-read its last chunk, stores / fragment reads
+      // beyond it move unused data through a free buffer - so the compiler counts the loads in flight exactly (vmcnt(4): the
+      // other register set's prefetch stays in flight across the use of this one).
+      // The loads must also be ISSUED in chunk order, in the prologue exactly as in the body (sched_barrier between the groups): the
+      // wait-count pass merges the loop-entry state with the back edge, and a prologue whose loads were interleaved (hipcc groups them by
+      // address) degrades every wait of the steady state to "all loads done".
+      const int last = c_lo + nchunks - 1;
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk(ra[0], rb[0], 0, c_lo * SK_KC);
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(ra[0], rb[0], min(c_lo + 2, last) * SK_KC);
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
-      if (c + 2 < nchunks) load_chunk(ra[0], rb[0], (c_lo + c + 2) * SK_KC);
-      compute(0);
-      if (c + 1 < nchunks) {
-        store_chunk(ra[1], rb[1], 1);
+      read_frags(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // No exit in the middle of the body either (an odd last chunk is peeled off below): the structurised back edge would merge
+      // the state of the early exit into the loop header and degrade the waits of the first half again.
+      for (int c = 0; c + 1 < nchunks; c += 2) {
+        store_chunk(ra[1], rb[1], 1, min(c_lo + c + 1, last) * SK_KC);       // [A] chunk c+1
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(ra[1], rb[1], min(c_lo + c + 3, last) * SK_KC);           // [B] chunk c+3
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frags();                                                        // [C] chunk c
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                                     // [D]
+        read_frags(1);                                                       // [E] chunk c+1
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(ra[0], rb[0], 0, min(c_lo + c + 2, last) * SK_KC);       // [A] chunk c+2
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(ra[0], rb[0], min(c_lo + c + 4, last) * SK_KC);           // [B] chunk c+4
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frags();                                                        // [C] chunk c+1
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if (c + 3 < nchunks) load_chunk(ra[1], rb[1], (c_lo + c + 3) * SK_KC);
-        compute(1);
+        read_frags(0);                                                       // [E] chunk c+2
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nchunks & 1) mfma_frags();      // the last chunk of an odd count: its fragments were read by the prologue / the last [E]
+    } else {
+      for (int c = 0; c < nchunks; c += 2) {
+        store_chunk(ra[0], rb[0], 0, 0);
+        __syncthreads();
+        if (c + 2 < nchunks) load_chunk(ra[0], rb[0], (c_lo + c + 2) * SK_KC);
+        compute(0);
+        if (c + 1 < nchunks) {
+          store_chunk(ra[1], rb[1], 1, 0);
+          __syncthreads();
+          if (c + 3 < nchunks) load_chunk(ra[1], rb[1], (c_lo + c + 3) * SK_KC);
+          compute(1);
+        }
       }
     }
     bool finished = nchunks == C;      // wave-uniform
@@ -329,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
     }
     if (finished) epilogue(m0, n0);
     u += nchunks;
-    if (u < u_hi) __syncthreads();      // the next segment's first store_chunk rewrites the LDS tiles other waves may still be reading
+    if (u < u_hi) __syncthreads();      // the next segment's first store_chunk rewrites LDS tiles other waves may still be reading
   }
 }
 
