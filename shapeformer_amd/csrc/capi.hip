@@ -2,7 +2,7 @@
 #include "sfmi_common.h"
 #include <string>
 
-SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512, 1, 0, 0, 1, 512, 0};
+SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512, 1, 0, 0, 1, 512, 0, 0, 0};
 static int g_sfmi_tune_generation = 0;
 
 // One wavefront that waits `ticks` of the constant 100 MHz wall clock: the probe `shapeformer_amd/gpt.py:_chain_streams` uses to
@@ -30,6 +30,8 @@ int sfmi_tune_set(const char* name, int value) {
   else if (n == "conv_xreuse" && (value == 0 || value == 1)) t.conv_xreuse = value;
   else if (n == "sk_grid" && value >= 256 && value <= 1024 && value % 256 == 0) t.sk_grid = value;
   else if (n == "sk_tile" && value >= 0 && value <= 2) t.sk_tile = value;
+  else if (n == "sk_loop" && value >= 0 && value <= 1) t.sk_loop = value;
+  else if (n == "sk_stagger" && value >= 0 && value <= 64) t.sk_stagger = value;
   else return SFMI_EINVAL;
   ++g_sfmi_tune_generation;
   return SFMI_OK;
@@ -49,6 +51,8 @@ int sfmi_tune_get(const char* name) {
   if (n == "conv_xreuse") return t.conv_xreuse;
   if (n == "sk_grid") return t.sk_grid;
   if (n == "sk_tile") return t.sk_tile;
+  if (n == "sk_loop") return t.sk_loop;
+  if (n == "sk_stagger") return t.sk_stagger;
   return -1;
 }
 int sfmi_tune_generation(void) { return g_sfmi_tune_generation; }

@@ -96,5 +96,7 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   sk_grid     : workgroups of the work-balanced training GEMM (csrc/sgemm_sk.hip): 512 (default: two per CU) / 256 / 768 / 1024.  NOT
 //                 bit-identical to each other (a tile's K range is cut at other places: fp32 rounding only)
 //   sk_tile     : its workgroup tile: 0 = by output size (default), 1 = 64 x 64, 2 = 128 x 128 (same remark)
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse, sk_grid, sk_tile; };
+//   sk_loop     : chunk loop of its 64 x 64 form: 0 = store / barrier / load / read / MFMA (default), 1 = pipelined + interleaved (bit-identical)
+//   sk_stagger  : experiment: the second resident workgroup of a CU starts `sk_stagger` x 256 cycles late (0 = off; bit-identical)
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse, sk_grid, sk_tile, sk_loop, sk_stagger; };
 extern SfmiTune g_sfmi_tune;

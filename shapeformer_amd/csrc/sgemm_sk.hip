@@ -43,13 +43,27 @@ struct SkArgs {
   float drop_p; unsigned drop_seed;
   float* slab;     // [G][2][BM * BN] partial tiles (slot 0: a workgroup's first segment, slot 1: its last)
   int* cnt;        // [tiles][4] arrival tickets, zero before the first launch, re-armed by the last arriver
-  int nbm, nbn, nch;
+  int nbm, nbn, nch, stagger;
   long long units; // tiles * nch
 };
 
 __device__ __forceinline__ float sk_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float sk_gelu_grad(float x) {      // == csrc/train.hip:gelu_grad
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// Issue order of one pipelined iteration (TM == 1): the 16 MFMAs of a chunk form one dependent chain (64 cycles each), so everything
+// else of the iteration - the selects and LDS stores of [A], the address arithmetic and global loads of [B] - is issued in the shadow of
+// an MFMA that is already executing: MFMA, a few VALU, one LDS store (first four gaps) or one global load (next four gaps), MFMA, ...
+// Serialising [A] / [B] in front of the chain instead costs ~400 issue cycles per 1024 (measured: 0.52 against 0.45 ms per block).
+__device__ __forceinline__ void sk_interleave() {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+    __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);      // VALU / SALU that became ready
+    if (i < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);        // one LDS store
+    else if (i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one global load
+  }
 }
 
 // buffer descriptor over a wave-uniform address (readfirstlane makes the uniformity explicit: no waterfall loop around the buffer ops)
@@ -63,8 +77,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const float* p, int by
 __device__ __forceinline__ long long sk_first_unit(long long v, long long U, long long G) { return v * U / G; }
 __device__ __forceinline__ int sk_owner(long long u, long long U, long long G) { return (int)(((u + 1) * G - 1) / U); }
 
-template <bool AK, bool BK, int TM>
+template <bool AK, bool BK, int TM, int LOOP>      // LOOP (TM == 1 only): 0 = store / barrier / load / read / MFMA per chunk, 1 = pipelined + interleaved
 __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
+  constexpr bool PIPE = TM == 1 && LOOP == 1;
   constexpr int BM = 64 * TM, BN = 64 * TM;          // workgroup tile
   constexpr int NL = 2 * TM;                         // float4 loads per thread, operand and chunk
   constexpr int RS = BM + 4;                         // row stride of a row-contiguous LDS tile ([k][rows])
@@ -77,6 +92,10 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, pl = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const long long G = gridDim.x, U = a.units;
+  // `sk_stagger` experiment: the second resident workgroup of every CU starts half a chunk late, so that the two waves of a SIMD take
+  // turns on the matrix pipe instead of colliding on it and idling together (timing only: no result depends on it)
+  if (a.stagger > 0 && blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(4);
   long long v = blockIdx.x;
   {    // block b runs on XCD b % 8: give every XCD one contiguous range of the work (bijective for any G)
     const long long q = G / 8, r = G % 8, xcd = v % 8, k = v / 8;
@@ -95,12 +114,12 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
     ka[i] = AK ? 4 * (tid & 7) : tid / CPR + (256 / CPR) * i;
     kb[i] = BK ? 4 * (tid & 7) : tid / CPR + (256 / CPR) * i;
   }
-  // TM == 2: the per-thread pointers include the thread's k offset inside a chunk (as in csrc/sgemm.hip).  TM == 1: they point at k = 0
+  // Plain loops: the per-thread pointers include the thread's k offset inside a chunk (as in csrc/sgemm.hip).  Pipelined loop: they point at k = 0
   // of the thread's row / column, and the k term is added per load - so that an out-of-range k can fall back to k = 0 (a valid address)
   auto set_tile = [&](int m0, int n0) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int kpa = TM == 2 ? ka[i] : 0, kpb = TM == 2 ? kb[i] : 0;
+      const int kpa = !PIPE ? ka[i] : 0, kpb = !PIPE ? kb[i] : 0;
       if (AK) pa[i] = a.A + (long long)min(m0 + (tid >> 3) + 32 * i, a.M - 1) * a.lda + kpa;
       else pa[i] = a.A + (long long)kpa * a.lda + min(m0 + 4 * (tid % CPR), a.M - 4);
       if (BK) pb[i] = a.B + (long long)min(n0 + (tid >> 3) + 32 * i, a.N - 1) * a.ldb + kpb;
@@ -111,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
   // replaced by zero when the registers are handed to LDS (store_chunk: not here, or the select would wait for the load at once).  A conditional load - or two code paths that join - would make hipcc wait for ALL outstanding loads
   // at the next use (the prefetch of the other register set included), which exposes a full memory latency per chunk.
   auto load_chunk = [&](f32x4 (&xa)[NL], f32x4 (&xb)[NL], int k0) {
-    if constexpr (TM == 2) {      // the 128 x 128 form sits at the 256-register budget: the two-path loads of csrc/sgemm.hip (no select to carry)
+    if constexpr (!PIPE) {      // (the 128 x 128 form sits at the 256-register budget: the two-path loads of csrc/sgemm.hip, no select to carry)
       const long long oa = AK ? (long long)k0 : (long long)k0 * a.lda, ob = BK ? (long long)k0 : (long long)k0 * a.ldb;
       if (k0 + SK_KC <= a.K) {
 #pragma unroll
@@ -142,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const f32x4 va = (TM == 2 || k0 + ka[i] < a.K) ? xa[i] : zero, vb = (TM == 2 || k0 + kb[i] < a.K) ? xb[i] : zero;
+      const f32x4 va = (!PIPE || k0 + ka[i] < a.K) ? xa[i] : zero, vb = (!PIPE || k0 + kb[i] < a.K) ? xb[i] : zero;
       if (AK) *reinterpret_cast<f32x4*>(as + ((tid >> 3) + 32 * i) * SK_KS + 4 * (tid & 7)) = va;
       else *reinterpret_cast<f32x4*>(as + ka[i] * RS + 4 * (tid % CPR)) = va;
       if (BK) *reinterpret_cast<f32x4*>(bs + ((tid >> 3) + 32 * i) * SK_KS + 4 * (tid & 7)) = vb;
@@ -151,11 +170,41 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
   };
 
   f32x16 acc[TM][TM];     // [n tile][m tile]
+  // TM == 1: one 32 x 32 tile per wave, 16 MFMAs on ONE accumulator per chunk.  All eight operand fragments of a chunk (32 registers)
+  // are read in one burst right after the barrier that publishes the chunk, i.e. one iteration AHEAD of their MFMAs (see the loop).
+  f32x4 fm[SK_KC / 8], fn[SK_KC / 8];
+  auto read_frags = [&](int buf) {
+    const float* as = As + buf * TILE;
+    const float* bs = Bs + buf * TILE;
+#pragma unroll
+    for (int g = 0; g < SK_KC / 8; ++g) {
+      if (AK) fm[g] = *reinterpret_cast<const f32x4*>(as + (32 * wm + pl) * SK_KS + 8 * g + 4 * hi);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fm[g][q] = as[(8 * g + 4 * hi + q) * RS + 32 * wm + pl];
+      }
+      if (BK) fn[g] = *reinterpret_cast<const f32x4*>(bs + (32 * wn + pl) * SK_KS + 8 * g + 4 * hi);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fn[g][q] = bs[(8 * g + 4 * hi + q) * RS + 32 * wn + pl];
+      }
+    }
+  };
+  auto mfma_frags = [&]() {
+#pragma unroll
+    for (int g = 0; g < SK_KC / 8; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[0][0] = SK_MFMA(fn[g][q], fm[g][q], acc[0][0]);
+  };
+
   auto compute = [&](int buf) {
     const float* as = As + buf * TILE;
     const float* bs = Bs + buf * TILE;
     if constexpr (TM == 1) {
-      (void)as; (void)bs;      // TM == 1 runs the pipelined loop below (read_frags / mfma_frags)
+      (void)as; (void)bs;
+      read_frags(buf);                        // all eight fragments of the chunk up front (the compiler would read 2, wait, issue 4 MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_frags();
     } else {
 #pragma unroll
       for (int g = 0; g < SK_KC / 8; ++g) {     // k8 groups: MFMA q of the group multiplies k = 8 g + 4 hi + q
@@ -188,33 +237,6 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
             for (int j = 0; j < TM; ++j) acc[i][j] = SK_MFMA(nf[i][q], mf[j][q], acc[i][j]);
       }
     }
-  };
-
-  // TM == 1: one 32 x 32 tile per wave, 16 MFMAs on ONE accumulator per chunk.  All eight operand fragments of a chunk (32 registers)
-  // are read in one burst right after the barrier that publishes the chunk, i.e. one iteration AHEAD of their MFMAs (see the loop).
-  f32x4 fm[SK_KC / 8], fn[SK_KC / 8];
-  auto read_frags = [&](int buf) {
-    const float* as = As + buf * TILE;
-    const float* bs = Bs + buf * TILE;
-#pragma unroll
-    for (int g = 0; g < SK_KC / 8; ++g) {
-      if (AK) fm[g] = *reinterpret_cast<const f32x4*>(as + (32 * wm + pl) * SK_KS + 8 * g + 4 * hi);
-      else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fm[g][q] = as[(8 * g + 4 * hi + q) * RS + 32 * wm + pl];
-      }
-      if (BK) fn[g] = *reinterpret_cast<const f32x4*>(bs + (32 * wn + pl) * SK_KS + 8 * g + 4 * hi);
-      else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fn[g][q] = bs[(8 * g + 4 * hi + q) * RS + 32 * wn + pl];
-      }
-    }
-  };
-  auto mfma_frags = [&]() {
-#pragma unroll
-    for (int g = 0; g < SK_KC / 8; ++g)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[0][0] = SK_MFMA(fn[g][q], fm[g][q], acc[0][0]);
   };
 
   // ---- epilogue of one finished tile (this wave's sub-tile) ---------------------------------------------------------------------
@@ -288,9 +310,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
     load_chunk(ra[0], rb[0], c_lo * SK_KC);
-    if (TM == 1) __builtin_amdgcn_sched_barrier(0);      // keep the prologue's loads in chunk order (see the loop's comment)
-    if (TM == 1 || nchunks > 1) load_chunk(ra[1], rb[1], min(c_lo + 1, c_lo + nchunks - 1) * SK_KC);
-    if constexpr (TM == 1) {
+    if (PIPE) __builtin_amdgcn_sched_barrier(0);      // keep the prologue's loads in chunk order (see the loop's comment)
+    if (PIPE || nchunks > 1) load_chunk(ra[1], rb[1], min(c_lo + 1, c_lo + nchunks - 1) * SK_KC);
+    if constexpr (PIPE) {
       // Pipelined so that a wave's MFMAs run back to back (PMC of the plain loop at 500 rows: matrix pipes busy 45 % of the launch, the
       // waves of a workgroup - and of the two workgroups of a CU - hit store / barrier / fragment-read phases together).  Iteration c:
       //   [A] chunk c+1: staging registers -> LDS buffer (c+1)&1     (its global loads were issued two iterations ago)
@@ -318,19 +340,17 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
       // the state of the early exit into the loop header and degrade the waits of the first half again.
       for (int c = 0; c + 1 < nchunks; c += 2) {
         store_chunk(ra[1], rb[1], 1, min(c_lo + c + 1, last) * SK_KC);       // [A] chunk c+1
-        __builtin_amdgcn_sched_barrier(0);
         load_chunk(ra[1], rb[1], min(c_lo + c + 3, last) * SK_KC);           // [B] chunk c+3
-        __builtin_amdgcn_sched_barrier(0);
         mfma_frags();                                                        // [C] chunk c
+        sk_interleave();
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                                     // [D]
         read_frags(1);                                                       // [E] chunk c+1
         __builtin_amdgcn_sched_barrier(0);
         store_chunk(ra[0], rb[0], 0, min(c_lo + c + 2, last) * SK_KC);       // [A] chunk c+2
-        __builtin_amdgcn_sched_barrier(0);
         load_chunk(ra[0], rb[0], min(c_lo + c + 4, last) * SK_KC);           // [B] chunk c+4
-        __builtin_amdgcn_sched_barrier(0);
         mfma_frags();                                                        // [C] chunk c+1
+        sk_interleave();
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         read_frags(0);                                                       // [E] chunk c+2
@@ -407,9 +427,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
   }
 }
 
-template <bool AK, bool BK, int TM>
+template <bool AK, bool BK, int TM, int LOOP>
 hipError_t sk_attr() {
-  return hipFuncSetAttribute((const void*)sgemm_sk_kernel<AK, BK, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * TM * SK_KS * (int)sizeof(float));
+  return hipFuncSetAttribute((const void*)sgemm_sk_kernel<AK, BK, TM, LOOP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * TM * SK_KS * (int)sizeof(float));
 }
 
 }  // namespace
@@ -458,8 +478,9 @@ int sfmi_sgemm_sk_f32(int transA, int transB, int M, int N, int K, const float* 
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    const hipError_t es[8] = {sk_attr<true, true, 1>(), sk_attr<true, false, 1>(), sk_attr<false, false, 1>(), sk_attr<false, true, 1>(),
-                              sk_attr<true, true, 2>(), sk_attr<true, false, 2>(), sk_attr<false, false, 2>(), sk_attr<false, true, 2>()};
+    const hipError_t es[12] = {sk_attr<true, true, 1, 0>(), sk_attr<true, false, 1, 0>(), sk_attr<false, false, 1, 0>(), sk_attr<false, true, 1, 0>(),
+                               sk_attr<true, true, 1, 1>(), sk_attr<true, false, 1, 1>(), sk_attr<false, false, 1, 1>(), sk_attr<false, true, 1, 1>(),
+                               sk_attr<true, true, 2, 0>(), sk_attr<true, false, 2, 0>(), sk_attr<false, false, 2, 0>(), sk_attr<false, true, 2, 0>()};
     for (hipError_t e : es)
       if (e != hipSuccess) attr_err = e;
   });
@@ -467,9 +488,12 @@ int sfmi_sgemm_sk_f32(int transA, int transB, int M, int N, int K, const float* 
   const size_t lds = (size_t)4 * BM * SK_KS * sizeof(float);
   const dim3 grid((unsigned)G), block(256);
   hipStream_t st = (hipStream_t)stream;
+  a.stagger = g_sfmi_tune.sk_stagger;
+  const int loop = g_sfmi_tune.sk_loop;
 #define SK_LAUNCH(AK_, BK_) do { \
-    if (TM == 2) hipLaunchKernelGGL((sgemm_sk_kernel<AK_, BK_, 2>), grid, block, lds, st, a); \
-    else hipLaunchKernelGGL((sgemm_sk_kernel<AK_, BK_, 1>), grid, block, lds, st, a); } while (0)
+    if (TM == 2) hipLaunchKernelGGL((sgemm_sk_kernel<AK_, BK_, 2, 0>), grid, block, lds, st, a); \
+    else if (loop == 1) hipLaunchKernelGGL((sgemm_sk_kernel<AK_, BK_, 1, 1>), grid, block, lds, st, a); \
+    else hipLaunchKernelGGL((sgemm_sk_kernel<AK_, BK_, 1, 0>), grid, block, lds, st, a); } while (0)
   if (!transA && transB) SK_LAUNCH(true, true);
   else if (!transA && !transB) SK_LAUNCH(true, false);
   else if (transA && !transB) SK_LAUNCH(false, false);

@@ -26,15 +26,20 @@ def _ru(x, m):
 
 class GPTTrainer:
     def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0,
-                 single_rank_collectives=False, grad_sync="ring", profile_waits=False, gemm="sk", overlap_param_gather=True):
+                 single_rank_collectives=False, grad_sync="ring", profile_waits=False, gemm="sk", overlap_param_gather=True, side_stream=True):
         """grad_sync: "ring" = per-bucket all-reduce, every rank updates every parameter; "rs_ag" = per-bucket reduce-scatter,
         AdamW on the rank's 1/N shard, all-gather of the updated parameters (dist.GradBuckets).  Same weights either way.
         gemm: "sk" = the work-balanced GEMM with fused GELU epilogues (csrc/sgemm_sk.hip, round 5); "tile" = one workgroup per
         128 x 128 tile + split-K reduce launches + separate GELU launches (csrc/sgemm.hip, rounds 2-4; kept as the cross-check).
         overlap_param_gather (rs_ag): the all-gather of bucket k's updated parameters is waited for right before the NEXT step's first
         kernel that reads them (embeddings, then block by block) instead of all at once after the optimizer."""
+        side_stream: the weight-gradient GEMMs and the per-block column reductions - needed by nobody before the optimizer - are issued
+        on a second HIP stream, so that their workgroups fill the launch ramps and tails of the dependent chain (dX GEMMs, LayerNorm and
+        attention backward) instead of queueing behind it; per-stream scratch, event-ordered, joined before the gradient collectives."""
         assert gemm in ("sk", "tile")
         self.gemm_algo, self.overlap_param_gather = gemm, bool(overlap_param_gather)
+        self._side = torch.cuda.Stream(device=gpt.dev) if side_stream else None
+        self._on_side, self._keep = False, []
         self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
         # (embd_pdrop, resid_pdrop, attn_pdrop): the model's (CondTupleGPT ctor kwargs / YAML) unless given
         self.pdrop = tuple(float(v) for v in (pdrop if pdrop is not None else getattr(gpt, "pdrop", (0.0, 0.0, 0.0))))
@@ -84,10 +89,12 @@ class GPTTrainer:
         # order in which a forward pass first reads the buckets' parameters (the order the rs_ag parameter gathers are launched in)
         self._fwd_order = ["emb"] + [f"L{li}" for li in range(len(g.layers))] + ["heads"]
         lib = L.lib()
-        self._sk_slab = torch.empty(lib.sfmi_sgemm_sk_slab_floats(), device=self.dev)      # stream-K partial tiles (134 MB)
-        self._sk_cnt = torch.zeros(1 << 20, device=self.dev, dtype=torch.int32)            # tickets: zeroed once, re-armed by the kernel
-        self._cr_cnt = torch.zeros(4096, device=self.dev, dtype=torch.int32)               # same for the column reductions
-        self._cr_part = None
+        # scratch per stream that issues these launches ([0]: the main stream, [1]: the side stream)
+        ns = 2 if self._side is not None else 1
+        self._sk_slab = [torch.empty(lib.sfmi_sgemm_sk_slab_floats(), device=self.dev) for _ in range(ns)]      # stream-K partial tiles (134 MB)
+        self._sk_cnt = [torch.zeros(1 << 20, device=self.dev, dtype=torch.int32) for _ in range(ns)]            # tickets: zeroed once, re-armed by the kernel
+        self._cr_cnt = [torch.zeros(4096, device=self.dev, dtype=torch.int32) for _ in range(ns)]               # same for the column reductions
+        self._cr_part = [None] * ns
 
     # ------------------------------------------------------------------ small wrappers
     def _f(self, *shape):
@@ -106,16 +113,18 @@ class GPTTrainer:
         "tile": csrc/sgemm.hip with split-K scratch for outputs of few tiles, the GELU forms as separate launches."""
         lib = L.lib()
         if self.gemm_algo == "sk":
+            slab, cnt = self._sk_slab[int(self._on_side)], self._sk_cnt[int(self._on_side)]
             L.check(lib.sfmi_sgemm_sk_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(C), L.ptr(c2), ldc, int(accumulate), L.ptr(bias), act,
-                                          L.ptr(aux), L.ptr(resid), float(drop[0]), int(drop[1]), L.ptr(self._sk_slab), self._sk_slab.numel(),
-                                          L.ptr(self._sk_cnt), self._sk_cnt.numel(), L.stream_ptr()), "sgemm_sk")
+                                          L.ptr(aux), L.ptr(resid), float(drop[0]), int(drop[1]), L.ptr(slab), slab.numel(), L.ptr(cnt), cnt.numel(),
+                                          L.stream_ptr()), "sgemm_sk")
             return
         need = lib.sfmi_sgemm_mfma_splits(M, N, K) * M * N
         ws = None
         if need > M * N:
-            if getattr(self, "_sg_ws", None) is None or self._sg_ws.numel() < need:
-                self._sg_ws = torch.empty(need, device=self.dev)
-            ws = self._sg_ws
+            key = "_sg_ws1" if self._on_side else "_sg_ws"
+            if getattr(self, key, None) is None or getattr(self, key).numel() < need:
+                setattr(self, key, torch.empty(need, device=self.dev))
+            ws = getattr(self, key)
         if act == 2 and c2 is not None:          # pre-activation kept: GEMM -> c2, then GELU -> C
             assert resid is None and drop[0] == 0.0 and ldc == N
             L.check(lib.sfmi_sgemm_mfma_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(c2), ldc, int(accumulate), L.ptr(bias), 0, None,
@@ -174,6 +183,29 @@ class GPTTrainer:
         out = self.grad[gname]
         self._sgemm(1, 0, N, K, M, dY, N, X, K, out, K, accumulate=self._acc)   # dY^T X with dY / X read in place (no transposes)
 
+    def _aside(self, fn, *tensors):
+        """Run `fn()` (launches that only the optimizer waits for: weight-gradient GEMMs, column reductions) on the side stream, ordered
+        after everything the main stream has enqueued so far.  `tensors`: what those launches read - kept alive until the streams are
+        joined (their memory must not be handed to a later main-stream allocation while the side stream still reads it)."""
+        if self._side is None:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record()
+        self._side.wait_event(ev)
+        self._keep.extend(tensors)
+        self._on_side = True
+        try:
+            with torch.cuda.stream(self._side):
+                return fn()
+        finally:
+            self._on_side = False
+
+    def _join_side(self):
+        """The main stream waits for the side stream (before gradients are consumed: collectives, optimizer) and the kept tensors go."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._keep.clear()
+
     def _ln_rows(self, dy, x, gamma, dres, M):
         """LayerNorm backward, row part: -> (dx = dLN/dx (+ dres), stats (M,2)); the parameter sums join the block's column reduction."""
         dx, stats = self._f(M, self.D), self._f(M, 2)
@@ -198,13 +230,14 @@ class GPTTrainer:
                 kind.append(1); a.append(dy.data_ptr()); x.append(xin.data_ptr()); st.append(stats.data_ptr())
                 o.append(self.grad[gw].data_ptr()); o2.append(self.grad[gb].data_ptr()); N.append(self.D); ld.append(self.D)
         need = lib.sfmi_col_reduce_part_floats(M, sum(N))
-        if lib.sfmi_col_reduce_slices(M) > 1 and (self._cr_part is None or self._cr_part.numel() < need):
-            self._cr_part = torch.empty(need, device=self.dev)
+        si = int(self._on_side)
+        if lib.sfmi_col_reduce_slices(M) > 1 and (self._cr_part[si] is None or self._cr_part[si].numel() < need):
+            self._cr_part[si] = torch.empty(need, device=self.dev)
+        part, cnt = self._cr_part[si], self._cr_cnt[si]
         IA, PA = C.c_int * n, C.c_void_p * n
         # the launcher copies the tables into the kernel argument before it returns: the ctypes arrays may die afterwards
         L.check(lib.sfmi_col_reduce_f32(n, IA(*kind), PA(*a), PA(*x), PA(*st), PA(*o), PA(*o2), IA(*N), IA(*ld), M, int(self._acc),
-                                        L.ptr(self._cr_part), self._cr_part.numel() if self._cr_part is not None else 0, L.ptr(self._cr_cnt),
-                                        self._cr_cnt.numel(), L.stream_ptr()), "col_reduce")
+                                        L.ptr(part), part.numel() if part is not None else 0, L.ptr(cnt), cnt.numel(), L.stream_ptr()), "col_reduce")
 
     def _scatter(self, dx, idx, table, M, accumulate=True):
         rows = self.grad[table].shape[0]
@@ -215,8 +248,13 @@ class GPTTrainer:
     # ------------------------------------------------------------------ forward + backward
     @torch.no_grad()
     def _ready(self, name):
+        """Bucket `name` is final once the launches enqueued so far - on BOTH streams - have run: its collective is launched from the
+        side stream after that stream has been ordered behind the main one (RCCL orders a collective after the launching stream)."""
         if self._sync:
-            self.buckets.ready(name)
+            if self._side is not None and self.buckets.active:
+                self._aside(lambda: self.buckets.ready(name))
+            else:
+                self.buckets.ready(name)
 
     @torch.no_grad()
     def _param_ready(self, name):
@@ -371,27 +409,28 @@ class GPTTrainer:
                 dr = dsum
             # fc2 (the GELU backward rides in the epilogue of dX)
             dm = drop_(dr, site(p_resid, f"L{li}.mlp"))     # gradient of the MLP output before its dropout (residual path: dr)
-            self._dW(dm, s["h"], M, D, 4 * D, p + "wfc2")
+            self._aside(lambda: self._dW(dm, s["h"], M, D, 4 * D, p + "wfc2"), dm, s["h"])
             dhpre = self._dx(dm, p + "wfc2", ly.wfc2, M, D, 4 * D, gelu_aux=s["hpre"])
             # fc1
-            self._dW(dhpre, s["xn2"], M, 4 * D, D, p + "wfc1")
+            self._aside(lambda: self._dW(dhpre, s["xn2"], M, 4 * D, D, p + "wfc1"), dhpre, s["xn2"])
             dxn2 = self._dx(dhpre, p + "wfc1", ly.wfc1, M, 4 * D, D)
             dr1, st2 = self._ln_rows(dxn2, s["r1"], ly.ln2[0], dr, M)
             # proj
             dp = drop_(dr1, site(p_resid, f"L{li}.proj"))
-            self._dW(dp, s["y"], M, D, D, p + "wproj")
+            self._aside(lambda: self._dW(dp, s["y"], M, D, D, p + "wproj"), dp, s["y"])
             dy = self._dx(dp, p + "wproj", ly.wproj, M, D, D)
             # attention
             dqkv = self._f(M, 3 * D)
             L.check(lib.sfmi_attn_bwd_lse_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(s["lse"]), L.ptr(delta), L.ptr(dqkv), B, Lq, D, g.H,
                                               *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn_bwd")
             # qkv
-            self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv")
+            self._aside(lambda: self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv"), dqkv, s["xn1"])
             dxn1 = self._dx(dqkv, p + "wqkv", ly.wqkv, M, 3 * D, D)
             dr, st1 = self._ln_rows(dxn1, s["x_in"], ly.ln1[0], dr1, M)
             # the block's four bias gradients and two LayerNorm parameter gradients: one launch
-            self._col_reduce([("b", dm, D, p + "bfc2"), ("b", dhpre, 4 * D, p + "bfc1"), ("b", dp, D, p + "bproj"), ("b", dqkv, 3 * D, p + "bqkv"),
-                              ("ln", dxn2, s["r1"], st2, p + "ln2.w", p + "ln2.b"), ("ln", dxn1, s["x_in"], st1, p + "ln1.w", p + "ln1.b")], M)
+            jobs = [("b", dm, D, p + "bfc2"), ("b", dhpre, 4 * D, p + "bfc1"), ("b", dp, D, p + "bproj"), ("b", dqkv, 3 * D, p + "bqkv"),
+                    ("ln", dxn2, s["r1"], st2, p + "ln2.w", p + "ln2.b"), ("ln", dxn1, s["x_in"], st1, p + "ln1.w", p + "ln1.b")]
+            self._aside(lambda: self._col_reduce(jobs, M), dxn2, dxn1, s["r1"], s["x_in"], st1, st2)
             saved[li] = None
             self._ready(f"L{li}")     # this block's 50 MB of gradients are final: all-reduce under the next blocks' backward
         # ---- embeddings (mingpt.py:256-286): E0[pos] + E1[val] + Ex[extra] + positional --------------------------------
@@ -407,6 +446,7 @@ class GPTTrainer:
             L.check(lib.sfmi_colsum_f32(dr.data_ptr() + Lc * D * 4, L.ptr(gp), B, (Lq - Lc) * D, Lq * D, int(accumulate),
                                         L.stream_ptr()), "colsum")
         self._ready("emb")
+        self._join_side()      # the gradients of every block are complete on the main stream from here on
         return loss
 
     # ------------------------------------------------------------------ optimizer / data parallel

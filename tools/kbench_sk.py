@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--m", default="499,3992")
 ap.add_argument("--grids", default="512")
 ap.add_argument("--tiles", default="0")
+ap.add_argument("--loops", default="0", help="sk_loop values (64 x 64 form: 0 plain, 1 pipelined + interleaved)")
+ap.add_argument("--staggers", default="0", help="sk_stagger values (x 256 cycles start delay of the second workgroup of a CU)")
 ap.add_argument("--reps", type=int, default=20)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -48,11 +50,15 @@ for M in (int(x) for x in a.m.split(",")):
         tot[(M, "old")] += t0
         for tile in (int(x) for x in a.tiles.split(",")):
             for grid in (int(x) for x in a.grids.split(",")):
-                L.check(lib.sfmi_tune_set(b"sk_tile", tile), "tune"); L.check(lib.sfmi_tune_set(b"sk_grid", grid), "tune")
-                t1 = ev_time(f_new, a.reps)
-                line += f" sk t{tile if tile else lib.sfmi_sgemm_sk_tile(m, n, k)}{'*' if not tile else ''} g{grid} {t1 * 1e3:7.1f} us {fl / t1 / 1e9:6.1f} TF |"
-                tot.setdefault((M, tile, grid), 0.0)
-                tot[(M, tile, grid)] += t1
+                for loop in (int(x) for x in a.loops.split(",")):
+                    for stg in (int(x) for x in a.staggers.split(",")):
+                        for kname, val in ((b"sk_tile", tile), (b"sk_grid", grid), (b"sk_loop", loop), (b"sk_stagger", stg)):
+                            L.check(lib.sfmi_tune_set(kname, val), "tune")
+                        t1 = ev_time(f_new, a.reps)
+                        line += f" t{tile if tile else lib.sfmi_sgemm_sk_tile(m, n, k)}{'*' if not tile else ''} g{grid} l{loop} s{stg} {t1 * 1e3:6.1f} us {fl / t1 / 1e9:5.1f} TF |"
+                        tot.setdefault((M, tile, grid, loop, stg), 0.0)
+                        tot[(M, tile, grid, loop, stg)] += t1
         print(line, flush=True)
-L.check(lib.sfmi_tune_set(b"sk_tile", 0), "tune"); L.check(lib.sfmi_tune_set(b"sk_grid", 512), "tune")
+for kname, val in ((b"sk_tile", 0), (b"sk_grid", 512), (b"sk_loop", 0), (b"sk_stagger", 0)):
+    L.check(lib.sfmi_tune_set(kname, val), "tune")
 print("sum over the 12 GEMMs of a block (ms):", {str(k): round(v, 3) for k, v in tot.items()})
