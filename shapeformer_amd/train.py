@@ -32,7 +32,7 @@ class GPTTrainer:
         gemm: "sk" = the work-balanced GEMM with fused GELU epilogues (csrc/sgemm_sk.hip, round 5); "tile" = one workgroup per
         128 x 128 tile + split-K reduce launches + separate GELU launches (csrc/sgemm.hip, rounds 2-4; kept as the cross-check).
         overlap_param_gather (rs_ag): the all-gather of bucket k's updated parameters is waited for right before the NEXT step's first
-        kernel that reads them (embeddings, then block by block) instead of all at once after the optimizer."""
+        kernel that reads them (embeddings, then block by block) instead of all at once after the optimizer.
         side_stream: the weight-gradient GEMMs and the per-block column reductions - needed by nobody before the optimizer - are issued
         on a second HIP stream, so that their workgroups fill the launch ramps and tails of the dependent chain (dX GEMMs, LayerNorm and
         attention backward) instead of queueing behind it; per-stream scratch, event-ordered, joined before the gradient collectives."""
