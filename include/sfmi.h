@@ -212,6 +212,10 @@ int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, 
 /* the row part alone (dx and the (M,2) row statistics); the parameter sums then join a block's sfmi_col_reduce_f32 launch */
 int sfmi_layernorm_bwd_rows_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats, int M,
                                 int D, void* stream);
+/* the same; dx2 != NULL also receives nn.Dropout(dx) with the counter-hash mask of `drop_seed` (the backward of a forward dropout
+ * on this tensor, mingpt.py:90,105, fused instead of a separate sfmi_dropout_f32 launch) */
+int sfmi_layernorm_bwd_rows_drop_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats,
+                                     float* dx2, float drop_p, unsigned drop_seed, int M, int D, void* stream);
 /* up to 8 column reductions over M rows in ONE launch: kind 0 = bias gradient of a Linear layer (column sums of dY, mingpt.py:46-111),
  * kind 1 = LayerNorm parameter gradients (dgamma -> out, dbeta -> out2).  Replaces 8 colsum + 4 LayerNorm-parameter launches per
  * transformer block of the backward pass.  part / cnt: scratch for tall inputs (cnt zeroed once). */

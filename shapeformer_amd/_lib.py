@@ -118,6 +118,7 @@ PROTOTYPES = {
     "sfmi_gelu_bwd_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_layernorm_bwd_f32": (i32, [c_ptr] * 8 + [i32, i32, c_ptr]),
     "sfmi_layernorm_bwd_rows_f32": (i32, [c_ptr] * 6 + [i32, i32, c_ptr]),
+    "sfmi_layernorm_bwd_rows_drop_f32": (i32, [c_ptr] * 7 + [f32, C.c_uint, i32, i32, c_ptr]),
     "sfmi_col_reduce_slices": (i32, [i32]),
     "sfmi_col_reduce_part_floats": (i64, [i32, i32]),
     "sfmi_col_reduce_f32": (i32, [i32] + [c_ptr] * 8 + [i32, i32, c_ptr, i64, c_ptr, i64, c_ptr]),

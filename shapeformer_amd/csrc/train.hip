@@ -120,6 +120,49 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
   if (tid == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
 }
 
+// The same row part with ONE WAVE PER ROW (round 5): the row lives in registers (NE = D / 64 elements per lane, element lane + 64 i:
+// every load / store is a full 256-byte line per wave), read once, every reduction is a wavefront butterfly - no LDS, no barriers,
+// four rows per workgroup.  The block-per-row form above re-reads the row four times through three barriers and was launch-latency
+// bound (8.4 us for 499 rows).  Optional second output: dx2 = nn.Dropout(dx) with the counter-hash mask of `drop_seed` - the gradient the
+// next GEMMs of the backward pass need when the forward dropped this tensor (mingpt.py:90,105), instead of a separate dropout launch.
+template <int NE>
+__global__ __launch_bounds__(256) void ln_bwd_rows_wave_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                               float* __restrict__ dx, float* __restrict__ stats, float* __restrict__ dx2,
+                                                               int M, float drop_p, unsigned drop_seed) {
+  constexpr int D = 64 * NE;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const long long rb = (long long)m * D;
+  float xv[NE], gv[NE];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) { xv[i] = x[rb + lane + 64 * i]; s += xv[i]; }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) { xv[i] -= mean; q += xv[i] * xv[i]; }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    xv[i] *= rstd;                                              // xhat
+    gv[i] = dy[rb + lane + 64 * i] * gamma[lane + 64 * i];
+    a += gv[i]; b += gv[i] * xv[i];
+  }
+  const float ma = wave_sum(a) / (float)D, mb = wave_sum(b) / (float)D;
+  const float inv_keep = 1.0f / (1.0f - drop_p);
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const long long o = rb + lane + 64 * i;
+    float v = rstd * (gv[i] - ma - xv[i] * mb);
+    if (dres) v += dres[o];
+    dx[o] = v;
+    if (dx2) dx2[o] = v * sfmi_dropout_mul(drop_seed, (unsigned)o, drop_p, inv_keep);
+  }
+  if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+}
+
 // LayerNorm backward, parameter part: dgamma[c] += sum_m dy*xhat ; dbeta[c] += sum_m dy
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ stats, float* __restrict__ dgamma,
@@ -378,20 +421,30 @@ __device__ __forceinline__ void ab_store(float* __restrict__ dst, const f32x4 (&
   }
 }
 
-// dQ of query block qb (the former attn_bwd_dq_mfma_kernel: same arithmetic, same order)
-__device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem, const float* __restrict__ qkv, const float* __restrict__ dy,
+// dQ of query block qb (the former attn_bwd_dq_mfma_kernel: same arithmetic, same order).
+// NG wave groups (NG = 2: 512-thread workgroups at small batch): group g walks the key blocks g, g + NG, ... with its own LDS tiles, the
+// partial dQ's are added through LDS at the end - half the dependent blocks per workgroup (the loop of the last query block is the launch's
+// critical path when B * H * blocks <= the CU count).  NG = 1 is bit-identical to rounds 1-4.
+template <int NG>
+__device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem_all, const float* __restrict__ qkv, const float* __restrict__ dy,
                                                  const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                  int b, int h, int H, int qb, int L, int D, float scale, float drop_p, unsigned drop_seed) {
+  constexpr int GROUP_FLOATS = 2 * 64 * AB_S + 8 * 16 * AB_S;
+  const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
+  float* smem = smem_all + grp * GROUP_FLOATS;
   float* Ks = smem;
   float* Vs = smem + 64 * AB_S;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   float* Tw = smem + 2 * 64 * AB_S + wave * 16 * AB_S;
   const int lr = lane & 15, lq = lane >> 4, q0 = qb * 64;
   const long long rb = (long long)b * L, sb = ((long long)b * H + h) * L;
   const int trow = min(q0 + 16 * wave + lr, L - 1);
+  const int kend = min(L, q0 + 64), nblk = (kend + 63) / 64, rounds = (nblk + NG - 1) / NG;
   f32x4 pk[4], pv[4];
-  ab_load(pk, qkv + D + h * 64, rb, 0, L, 3 * D, tid);
-  ab_load(pv, qkv + 2 * D + h * 64, rb, 0, L, 3 * D, tid);
+  if (grp < nblk) {
+    ab_load(pk, qkv + D + h * 64, rb, 64 * grp, L, 3 * D, tid);
+    ab_load(pv, qkv + 2 * D + h * 64, rb, 64 * grp, L, 3 * D, tid);
+  }
   float qf[16], dof[16];
   {
     const float* qp = qkv + (rb + trow) * 3 * D + h * 64 + lq;
@@ -408,15 +461,19 @@ __device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem, const
   f32x4 dq[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int kend = min(L, q0 + 64);
-  for (int k0 = 0; k0 < kend; k0 += 64) {
+  for (int r = 0; r < rounds; ++r) {
+    const int k0 = 64 * (r * NG + grp);
+    const bool active = k0 < kend;           // group-uniform; the barriers below are executed by every wave of the workgroup
     __syncthreads();
-    ab_store(Ks, pk, tid);
-    ab_store(Vs, pv, tid);
+    if (active) {
+      ab_store(Ks, pk, tid);
+      ab_store(Vs, pv, tid);
+    }
     __syncthreads();
-    if (k0 + 64 < kend) {
-      ab_load(pk, qkv + D + h * 64, rb, k0 + 64, L, 3 * D, tid);
-      ab_load(pv, qkv + 2 * D + h * 64, rb, k0 + 64, L, 3 * D, tid);
+    if (!active) continue;
+    if (k0 + 64 * NG < kend) {
+      ab_load(pk, qkv + D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
+      ab_load(pv, qkv + 2 * D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -446,6 +503,18 @@ __device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem, const
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (NG > 1) {      // group 1's partial sums -> LDS (its own tiles are free after the barrier) -> group 0 adds them, in group order
+    __syncthreads();
+    float* xch = smem_all + GROUP_FLOATS;        // 256 threads x 16 floats
+    if (grp == 1) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&xch[(dt * 256 + tid) * 4]) = dq[dt];
+    }
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = dq[dt] + *reinterpret_cast<const f32x4*>(&xch[(dt * 256 + tid) * 4]);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int tq = q0 + 16 * wave + 4 * lq + j;
@@ -456,21 +525,28 @@ __device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem, const
   }
 }
 
-// dK / dV of key block kb_ (the former attn_bwd_dkv_mfma_kernel: same arithmetic, same order)
-__device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem, const float* __restrict__ qkv, const float* __restrict__ dy,
+// dK / dV of key block kb_ (the former attn_bwd_dkv_mfma_kernel: same arithmetic, same order); NG wave groups as above, over the query blocks
+template <int NG>
+__device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem_all, const float* __restrict__ qkv, const float* __restrict__ dy,
                                                   const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                   int b, int h, int H, int kb_, int L, int D, float scale, float drop_p, unsigned drop_seed) {
+  constexpr int GROUP_FLOATS = 2 * 64 * AB_S + 8 * 16 * AB_S;
+  const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
+  float* smem = smem_all + grp * GROUP_FLOATS;
   float* Qs = smem;
   float* Os = smem + 64 * AB_S;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   float* Pw = smem + 2 * 64 * AB_S + wave * 16 * AB_S;
   float* Sw = smem + 2 * 64 * AB_S + 4 * 16 * AB_S + wave * 16 * AB_S;
   const int lr = lane & 15, lq = lane >> 4, k0 = kb_ * 64;
   const long long rb = (long long)b * L, sb = ((long long)b * H + h) * L;
   const int krow = min(k0 + 16 * wave + lr, L - 1);
+  const int nblk = (L - k0 + 63) / 64, rounds = (nblk + NG - 1) / NG;
   f32x4 pq[4], po[4];
-  ab_load(pq, qkv + h * 64, rb, k0, L, 3 * D, tid);
-  ab_load(po, dy + h * 64, rb, k0, L, D, tid);
+  if (grp < nblk) {
+    ab_load(pq, qkv + h * 64, rb, k0 + 64 * grp, L, 3 * D, tid);
+    ab_load(po, dy + h * 64, rb, k0 + 64 * grp, L, D, tid);
+  }
   float kf[16], vf[16];
   {
     const float* kp = qkv + (rb + krow) * 3 * D + D + h * 64 + lq;
@@ -480,14 +556,19 @@ __device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem, cons
   f32x4 dk[4], dv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
-  for (int q0 = k0; q0 < L; q0 += 64) {
+  for (int r = 0; r < rounds; ++r) {
+    const int q0 = k0 + 64 * (r * NG + grp);
+    const bool active = q0 < L;
     __syncthreads();
-    ab_store(Qs, pq, tid);
-    ab_store(Os, po, tid);
+    if (active) {
+      ab_store(Qs, pq, tid);
+      ab_store(Os, po, tid);
+    }
     __syncthreads();
-    if (q0 + 64 < L) {
-      ab_load(pq, qkv + h * 64, rb, q0 + 64, L, 3 * D, tid);
-      ab_load(po, dy + h * 64, rb, q0 + 64, L, D, tid);
+    if (!active) continue;
+    if (q0 + 64 * NG < L) {
+      ab_load(pq, qkv + h * 64, rb, q0 + 64 * NG, L, 3 * D, tid);
+      ab_load(po, dy + h * 64, rb, q0 + 64 * NG, L, D, tid);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -522,6 +603,24 @@ __device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem, cons
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (NG > 1) {
+    __syncthreads();
+    float* xch = smem_all + GROUP_FLOATS;        // 256 threads x 32 floats
+    if (grp == 1) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<f32x4*>(&xch[(dt * 256 + tid) * 4]) = dk[dt];
+        *reinterpret_cast<f32x4*>(&xch[((4 + dt) * 256 + tid) * 4]) = dv[dt];
+      }
+    }
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dk[dt] = dk[dt] + *reinterpret_cast<const f32x4*>(&xch[(dt * 256 + tid) * 4]);
+      dv[dt] = dv[dt] + *reinterpret_cast<const f32x4*>(&xch[((4 + dt) * 256 + tid) * 4]);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int tk = k0 + 16 * wave + 4 * lq + j;
@@ -537,14 +636,26 @@ __device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem, cons
 // block nqb - 1 - z / 2, z odd: dK / dV of key block z / 2 - the longest loops of either kind are dispatched first.  The two kinds are
 // independent given lse and delta, so the launch has twice the workgroups of either (256 at batch 1: every CU gets one), and the
 // causal imbalance of one kind (1 .. nqb blocks per workgroup) is filled by the other.
-__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
-                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
-                                                                unsigned drop_seed) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 64 * AB_S + 8 * 16 * AB_S];
+template <int NG>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
+                                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                                   float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
+                                                                                   unsigned drop_seed) {
+  __shared__ __attribute__((aligned(16))) float smem[NG * (2 * 64 * AB_S + 8 * 16 * AB_S)];
   const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, z = blockIdx.z, nqb = gridDim.z >> 1;
-  if (z & 1) attn_bwd_dkv_role(smem, qkv, dy, lse, delta, dqkv, b, h, H, z >> 1, L, D, scale, drop_p, drop_seed);
-  else attn_bwd_dq_role(smem, qkv, dy, lse, delta, dqkv, b, h, H, nqb - 1 - (z >> 1), L, D, scale, drop_p, drop_seed);
+  if (z & 1) attn_bwd_dkv_role<NG>(smem, qkv, dy, lse, delta, dqkv, b, h, H, z >> 1, L, D, scale, drop_p, drop_seed);
+  else attn_bwd_dq_role<NG>(smem, qkv, dy, lse, delta, dqkv, b, h, H, nqb - 1 - (z >> 1), L, D, scale, drop_p, drop_seed);
+}
+
+// small launches (every workgroup resident at once: the longest block loop is the launch's duration) run two wave groups per workgroup
+static void attn_bwd_fused_launch(hipStream_t st, const float* qkv, const float* dy, const float* lse, const float* delta, float* dqkv, int B,
+                                  int L, int D, int H, float drop_p, unsigned drop_seed) {
+  const int nqb = (L + 63) / 64;
+  const dim3 grid(B, H, 2 * nqb);
+  if ((long long)B * H * 2 * nqb <= 256 && nqb > 1)
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, grid, dim3(512), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  else
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<1>, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
 }
 
 // softmax cross-entropy: loss_row[m] = lse - logit[target] ; dlogits = (softmax - onehot) * scale for rows with
@@ -648,6 +759,31 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
   const int n = a.clen[c];
   float* p = a.p[t] + o;
   const float decay = 1.0f - a.lr * a.wd[t], sb2 = sqrtf(a.bc2), step = a.lr / a.bc1;
+  // 9.1 GB of pure streaming per step at d = 1024 (read p, g, m, v; write p, m, v): 16-byte nontemporal accesses (the bare-stream
+  // probe of round 5 reads 7.1 TB/s nontemporal against 6.4 TB/s with the default policy); the per-element arithmetic is unchanged
+  if (((fo | o | (long long)n) & 3) == 0) {
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(a.g + fo);
+    f32x4* m4 = reinterpret_cast<f32x4*>(a.m + fo);
+    f32x4* v4 = reinterpret_cast<f32x4*>(a.v + fo);
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    f32x4* pf4 = a.pflat ? reinterpret_cast<f32x4*>(a.pflat + fo) : nullptr;
+    for (int i = threadIdx.x; i < n / 4; i += 256) {
+      const f32x4 gi = __builtin_nontemporal_load(g4 + i), mo = __builtin_nontemporal_load(m4 + i), vo = __builtin_nontemporal_load(v4 + i);
+      const f32x4 po = __builtin_nontemporal_load(p4 + i);
+      f32x4 mi, vi, pn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mi[e] = a.b1 * mo[e] + (1.0f - a.b1) * gi[e];
+        vi[e] = a.b2 * vo[e] + (1.0f - a.b2) * gi[e] * gi[e];
+        pn[e] = po[e] * decay - step * (mi[e] / (sqrtf(vi[e]) / sb2 + a.eps));
+      }
+      __builtin_nontemporal_store(mi, m4 + i);
+      __builtin_nontemporal_store(vi, v4 + i);
+      p4[i] = pn;
+      if (pf4) pf4[i] = pn;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < n; i += 256) {
     const float gi = a.g[fo + i];
     const float mi = a.b1 * a.m[fo + i] + (1.0f - a.b1) * gi;
@@ -732,12 +868,29 @@ int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, 
 }
 // LayerNorm backward, row part only: dx = dLN/dx (+ dres), stats (M,2) = row mean / rstd for the parameter sums, which the caller
 // adds to a block's sfmi_col_reduce_f32 launch (kind 1 job).
-int sfmi_layernorm_bwd_rows_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats, int M,
-                                int D, void* stream) {
-  if (!dy || !x || !gamma || !dx || !stats || M <= 0 || D <= 0) return SFMI_EINVAL;
-  hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, dres, dx, stats, D);
+int sfmi_layernorm_bwd_rows_drop_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats,
+                                     float* dx2, float drop_p, unsigned drop_seed, int M, int D, void* stream) {
+  if (!dy || !x || !gamma || !dx || !stats || M <= 0 || D <= 0 || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((M + 3) / 4);
+  if (D == 1024) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<16>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed);
+  else if (D == 512) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<8>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed);
+  else if (D == 256) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<4>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed);
+  else if (D == 128) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<2>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed);
+  else {      // other widths: the block-per-row form, then the dropout as its own launch
+    hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3(M), dim3(256), 0, st, dy, x, gamma, dres, dx, stats, D);
+    if (dx2) {
+      const long long n = (long long)M * D;
+      if (n % 4) return SFMI_EINVAL;
+      hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dx, dx2, n / 4, drop_p, 1.0f / (1.0f - drop_p), drop_seed);
+    }
+  }
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
+}
+int sfmi_layernorm_bwd_rows_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats, int M,
+                                int D, void* stream) {
+  return sfmi_layernorm_bwd_rows_drop_f32(dy, x, gamma, dres, dx, stats, nullptr, 0.f, 0, M, D, stream);
 }
 // Up to 8 column reductions over M rows in one launch (csrc/train.hip:col_reduce_kernel).  Job i: kind[i] 0: out[i][n] (=|+=) sum_m
 // a[i][m][n]  (bias gradient of a Linear layer);  kind[i] 1: out[i] = dgamma = sum_m a * (x - mean_m) * rstd_m, out2[i] = dbeta =
@@ -783,7 +936,7 @@ int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* 
   const int nqb = (L + 63) / 64;
   float* delta = lse + (size_t)B * H * L;
   hipLaunchKernelGGL(attn_stats_mfma_kernel, dim3(B, H, nqb), dim3(256), 0, st, qkv, y, dy, lse, delta, L, D, 0.125f);
-  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B, H, 2 * nqb), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  attn_bwd_fused_launch(st, qkv, dy, lse, delta, dqkv, B, L, D, H, drop_p, drop_seed);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
@@ -795,7 +948,7 @@ int sfmi_attn_bwd_lse_f32(const float* qkv, const float* y, const float* dy, con
   hipStream_t st = (hipStream_t)stream;
   const int nqb = (L + 63) / 64;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long long)B * L + 3) / 4)), dim3(256), 0, st, y, dy, delta, B, L, D, H);
-  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B, H, 2 * nqb), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  attn_bwd_fused_launch(st, qkv, dy, lse, delta, dqkv, B, L, D, H, drop_p, drop_seed);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -206,12 +206,15 @@ class GPTTrainer:
             torch.cuda.current_stream().wait_stream(self._side)
             self._keep.clear()
 
-    def _ln_rows(self, dy, x, gamma, dres, M):
-        """LayerNorm backward, row part: -> (dx = dLN/dx (+ dres), stats (M,2)); the parameter sums join the block's column reduction."""
+    def _ln_rows(self, dy, x, gamma, dres, M, drop=(0.0, 0)):
+        """LayerNorm backward, row part: -> (dx = dLN/dx (+ dres), stats (M,2), dropped); the parameter sums join the block's column
+        reduction.  drop = (p, seed) with p > 0: `dropped` = nn.Dropout(dx) under that site's mask, from the same launch (the gradient
+        the next GEMMs need when the forward dropped this tensor); else `dropped` is dx itself."""
         dx, stats = self._f(M, self.D), self._f(M, 2)
-        L.check(L.lib().sfmi_layernorm_bwd_rows_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(stats), M, self.D, L.stream_ptr()),
-                "ln_bwd_rows")
-        return dx, stats
+        dx2 = self._f(M, self.D) if drop[0] > 0.0 else None
+        L.check(L.lib().sfmi_layernorm_bwd_rows_drop_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(stats), L.ptr(dx2),
+                                                         float(drop[0]), int(drop[1]), M, self.D, L.stream_ptr()), "ln_bwd_rows")
+        return dx, stats, (dx2 if dx2 is not None else dx)
 
     def _col_reduce(self, jobs, M):
         """All bias / LayerNorm-parameter gradients of a block in ONE launch (csrc/train.hip:col_reduce_kernel).  jobs: ("b", dY (M,N), N,
@@ -391,12 +394,13 @@ class GPTTrainer:
             whT = self._T(g.head_w_pad[s], g.Vpad, D, Rpad=g.Vpad)      # (D, Vpad)
             dxnh = self._f(M, D)
             self._gemm(dlg, whT, None, None, dxnh, M, D, g.Vpad)
-            d_head[s], hst = self._ln_rows(dxnh, head_in[s], g.head_ln[s][0], None, M)
+            d_head[s], hst, _ = self._ln_rows(dxnh, head_in[s], g.head_ln[s][0], None, M)
             head_jobs.append(("ln", dxnh, head_in[s], hst, f"head{s}.ln.w", f"head{s}.ln.b"))
         self._col_reduce(head_jobs, M)
         self._ready("heads")
         # ---- backward through the blocks -----------------------------------------------------------------------------
         dr = d_head[1]
+        dm_pre = None                     # nn.Dropout(dr) for the current block's MLP site, when the block above already produced it
         delta = self._f(B, g.H, Lq)       # row sums of dO * O (scratch of sfmi_attn_bwd_lse_f32)
         for li in range(len(g.layers) - 1, -1, -1):
             ly, s, p = g.layers[li], saved[li], f"L{li}."
@@ -406,17 +410,17 @@ class GPTTrainer:
                 self._scatter(dr, tgt[..., 0].contiguous().view(-1), "E0", M, accumulate=True)
                 dsum = self._f(M, D)
                 L.check(lib.sfmi_add_f32(L.ptr(dr), L.ptr(d_head[0]), L.ptr(dsum), M * D, L.stream_ptr()), "add")
-                dr = dsum
+                dr, dm_pre = dsum, None
             # fc2 (the GELU backward rides in the epilogue of dX)
-            dm = drop_(dr, site(p_resid, f"L{li}.mlp"))     # gradient of the MLP output before its dropout (residual path: dr)
+            # gradient of the MLP output before its dropout (residual path: dr); the block above emitted it with its LayerNorm backward
+            dm = dm_pre if dm_pre is not None else drop_(dr, site(p_resid, f"L{li}.mlp"))
             self._aside(lambda: self._dW(dm, s["h"], M, D, 4 * D, p + "wfc2"), dm, s["h"])
             dhpre = self._dx(dm, p + "wfc2", ly.wfc2, M, D, 4 * D, gelu_aux=s["hpre"])
             # fc1
             self._aside(lambda: self._dW(dhpre, s["xn2"], M, 4 * D, D, p + "wfc1"), dhpre, s["xn2"])
             dxn2 = self._dx(dhpre, p + "wfc1", ly.wfc1, M, 4 * D, D)
-            dr1, st2 = self._ln_rows(dxn2, s["r1"], ly.ln2[0], dr, M)
-            # proj
-            dp = drop_(dr1, site(p_resid, f"L{li}.proj"))
+            dr1, st2, dp = self._ln_rows(dxn2, s["r1"], ly.ln2[0], dr, M, drop=site(p_resid, f"L{li}.proj"))
+            # proj (dp = the gradient through the projection's dropout, from the same launch)
             self._aside(lambda: self._dW(dp, s["y"], M, D, D, p + "wproj"), dp, s["y"])
             dy = self._dx(dp, p + "wproj", ly.wproj, M, D, D)
             # attention
@@ -426,7 +430,11 @@ class GPTTrainer:
             # qkv
             self._aside(lambda: self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv"), dqkv, s["xn1"])
             dxn1 = self._dx(dqkv, p + "wqkv", ly.wqkv, M, 3 * D, D)
-            dr, st1 = self._ln_rows(dxn1, s["x_in"], ly.ln1[0], dr1, M)
+            # ... and through the MLP dropout of the block below, unless a stage boundary rewrites dr first
+            below = li > 0 and g.layers[li - 1].stage == ly.stage
+            dr, st1, dm_pre = self._ln_rows(dxn1, s["x_in"], ly.ln1[0], dr1, M, drop=site(p_resid, f"L{li - 1}.mlp") if below else (0.0, 0))
+            if not below:
+                dm_pre = None
             # the block's four bias gradients and two LayerNorm parameter gradients: one launch
             jobs = [("b", dm, D, p + "bfc2"), ("b", dhpre, 4 * D, p + "bfc1"), ("b", dp, D, p + "bproj"), ("b", dqkv, 3 * D, p + "bqkv"),
                     ("ln", dxn2, s["r1"], st2, p + "ln2.w", p + "ln2.b"), ("ln", dxn1, s["x_in"], st1, p + "ln1.w", p + "ln1.b")]
