@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--train-gemm", default="sk", choices=["sk", "tile"],
                     help="--mode train: GEMM of the step: sk = work-balanced csrc/sgemm_sk.hip with fused GELU epilogues (default), tile = csrc/sgemm.hip + split-K reduce / GELU launches (rounds 2-4)")
     ap.add_argument("--train-side-stream", type=int, default=1, help="--mode train: 1 = weight-gradient GEMMs / column reductions on a second HIP stream (default), 0 = one stream")
+    ap.add_argument("--train-fused-opt", type=int, default=1, help="--mode train: 1 = AdamW per bucket inside the backward pass (default), 0 = one AdamW launch after it")
     ap.add_argument("--train-lc", type=int, default=200)
     ap.add_argument("--train-lz", type=int, default=300)
     return ap.parse_args()
@@ -508,7 +509,7 @@ def main_train(a, rank, world, dev, dist):
     from shapeformer_amd.gpt import CondTupleGPT
     from shapeformer_amd.train import GPTTrainer
     g = CondTupleGPT(device=dev)
-    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist, grad_sync=a.grad_sync, profile_waits=True, gemm=a.train_gemm, side_stream=bool(a.train_side_stream))
+    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist, grad_sync=a.grad_sync, profile_waits=True, gemm=a.train_gemm, side_stream=bool(a.train_side_stream), fused_optimizer=bool(a.train_fused_opt))
     c, z = synth_tokens(1000 + rank, a.train_batch, a.train_lc, a.train_lz)
     losses = []
     for _ in range(a.warmup):
@@ -542,7 +543,7 @@ def main_train(a, rank, world, dev, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ShapeFormer DDP training step, synthetic IMNet-style token batches (BASELINE config 5)",
                        "batch_per_gpu": a.train_batch, "L_c": a.train_lc, "L_z": a.train_lz, "parallelism": f"dp{world}",
-                       "grad_sync_mode": a.grad_sync, "gemm": a.train_gemm, "side_stream": bool(a.train_side_stream),
+                       "grad_sync_mode": a.grad_sync, "gemm": a.train_gemm, "side_stream": bool(a.train_side_stream), "fused_optimizer": bool(a.train_fused_opt),
                        "grad_sync": ("26 gradient buckets (one per block) all-reduced under the backward pass" if a.grad_sync == "ring" else
                                      "26 gradient buckets reduce-scattered under the backward pass, AdamW on the rank's 1/N shard, updated "
                                      "parameters all-gathered in place through the same flat buffer")},

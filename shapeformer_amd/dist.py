@@ -157,6 +157,40 @@ class GradBuckets:
         self.pending.append((name, work))
         self.done.add(name)
 
+    def wait_bucket(self, name):
+        """Wait (stream-ordered on the CURRENT stream for RCCL) for the gradient collective of ONE bucket and apply the 1/world mean where
+        the backend has no AVG - the per-bucket form of finish(), for an optimizer that updates a bucket as soon as its gradients are
+        final (GPTTrainer's fused step).  True when a collective was pending for it."""
+        if not self.active:
+            return False
+        for i, (n, work) in enumerate(self.pending):
+            if n == name:
+                ev = self._bracket()
+                work.wait()
+                if not self.avg:
+                    lo, hi = self.shard(name)
+                    self.flat[lo:hi].div_(self.world)
+                if ev is not None:
+                    ev[1].record()
+                    self._wait_events.append(ev)
+                del self.pending[i]
+                return True
+        return False
+
+    def end_step(self):
+        """Close the books of a step whose buckets were all consumed through wait_bucket()."""
+        assert not self.pending, f"buckets still pending: {[n for n, _ in self.pending]}"
+        self.done = set()
+        if self.active and self.mode == "rs_ag":
+            self._gather_steps += 1
+
+    def launch_param_gather(self, name):
+        """mode rs_ag: launch the all-gather of ONE bucket's updated parameters (the fused step: right after that bucket's sharded AdamW,
+        while the backward pass of the blocks below is still running); consumed by wait_params(name)."""
+        if self.active and self.mode == "rs_ag" and self.sharded(name):
+            assert name not in self._param_works, f"the gather of bucket {name} was never consumed"
+            self._param_works[name] = self._all_gather_bucket(self.flat, name)
+
     def _bracket(self):
         if self.profile_waits and self.flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -26,7 +26,7 @@ def _ru(x, m):
 
 class GPTTrainer:
     def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0,
-                 single_rank_collectives=False, grad_sync="ring", profile_waits=False, gemm="sk", overlap_param_gather=True, side_stream=True):
+                 single_rank_collectives=False, grad_sync="ring", profile_waits=False, gemm="sk", overlap_param_gather=True, side_stream=True, fused_optimizer=True):
         """grad_sync: "ring" = per-bucket all-reduce, every rank updates every parameter; "rs_ag" = per-bucket reduce-scatter,
         AdamW on the rank's 1/N shard, all-gather of the updated parameters (dist.GradBuckets).  Same weights either way.
         gemm: "sk" = the work-balanced GEMM with fused GELU epilogues (csrc/sgemm_sk.hip, round 5); "tile" = one workgroup per
@@ -35,10 +35,17 @@ class GPTTrainer:
         kernel that reads them (embeddings, then block by block) instead of all at once after the optimizer.
         side_stream: the weight-gradient GEMMs and the per-block column reductions - needed by nobody before the optimizer - are issued
         on a second HIP stream, so that their workgroups fill the launch ramps and tails of the dependent chain (dX GEMMs, LayerNorm and
-        attention backward) instead of queueing behind it; per-stream scratch, event-ordered, joined before the gradient collectives."""
+        attention backward) instead of queueing behind it; per-stream scratch, event-ordered, joined before the gradient collectives.
+        fused_optimizer: training_step() updates a bucket (one transformer block / the heads / the embeddings) as soon as its gradients
+        are final - gradient collective waited for per bucket, AdamW launched per bucket on the side stream - so the 9 GB of optimizer
+        traffic (HBM-bound) runs under the backward pass of the blocks below (MFMA-bound) instead of after it.  Same update, same bits."""
         assert gemm in ("sk", "tile")
-        self.gemm_algo, self.overlap_param_gather = gemm, bool(overlap_param_gather)
+        self.gemm_algo, self.overlap_param_gather, self.fused_optimizer = gemm, bool(overlap_param_gather), bool(fused_optimizer)
+        self._fused = False
         self._side = torch.cuda.Stream(device=gpt.dev) if side_stream else None
+        # the per-bucket optimizer of the fused step gets a stream of its own: it has to wait for the bucket's gradient collective, and
+        # the weight-gradient GEMMs of the blocks below must not queue behind that wait
+        self._opt_stream = torch.cuda.Stream(device=gpt.dev) if (side_stream and fused_optimizer) else None
         self._on_side, self._keep = False, []
         self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
         # (embd_pdrop, resid_pdrop, attn_pdrop): the model's (CondTupleGPT ctor kwargs / YAML) unless given
@@ -201,9 +208,12 @@ class GPTTrainer:
             self._on_side = False
 
     def _join_side(self):
-        """The main stream waits for the side stream (before gradients are consumed: collectives, optimizer) and the kept tensors go."""
+        """The main stream waits for the side streams (before gradients / updated parameters are consumed) and the kept tensors go."""
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._side)
+            if self._opt_stream is not None:
+                cur.wait_stream(self._opt_stream)
             self._keep.clear()
 
     def _ln_rows(self, dy, x, gamma, dres, M, drop=(0.0, 0)):
@@ -253,11 +263,50 @@ class GPTTrainer:
     def _ready(self, name):
         """Bucket `name` is final once the launches enqueued so far - on BOTH streams - have run: its collective is launched from the
         side stream after that stream has been ordered behind the main one (RCCL orders a collective after the launching stream)."""
-        if self._sync:
-            if self._side is not None and self.buckets.active:
-                self._aside(lambda: self.buckets.ready(name))
-            else:
+        def go():
+            if self._sync:
                 self.buckets.ready(name)
+            if self._fused:
+                if self._opt_stream is None:
+                    self._opt_bucket(name)
+                else:      # optimizer stream: after the side stream's work so far (this bucket's weight gradients, its collective launch)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._opt_stream.wait_event(ev)
+                    with torch.cuda.stream(self._opt_stream):
+                        self._opt_bucket(name)
+        if self._side is not None and ((self._sync and self.buckets.active) or self._fused):
+            self._aside(go)
+        else:
+            go()
+
+    @torch.no_grad()
+    def _opt_bucket(self, name):
+        """The fused step's update of ONE bucket (called where the bucket's gradients are final, on the side stream when there is one):
+        wait for its gradient collective, AdamW over the bucket (rs_ag: over this rank's slice, the updated values also go into the
+        flat buffer), rs_ag: launch the all-gather of the bucket's parameters.  step_count was advanced by training_step()."""
+        bk = self.buckets
+        bk.wait_bucket(name)
+        sharded = bk.active and bk.mode == "rs_ag"
+        key = (name, sharded)
+        if not hasattr(self, "_opt_tabs"):
+            self._opt_tabs = {}
+        if key not in self._opt_tabs:
+            self._opt_tabs[key] = self._chunk_table([bk.shard(name) if sharded else bk.ranges[name]])
+        tb = self._opt_tabs[key]
+        L.check(L.lib().sfmi_adamw_multi_shard_f32(L.ptr(tb["p"]), L.ptr(tb["foff"]), L.ptr(tb["wd"]), L.ptr(tb["ct"]), L.ptr(tb["co"]), L.ptr(tb["cl"]),
+                                                   tb["n"], L.ptr(self.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), self.lr, self.betas[0],
+                                                   self.betas[1], self.eps, self.step_count, L.ptr(self.flat_grad) if sharded else None,
+                                                   L.stream_ptr()), "adamw_multi")
+        if sharded and bk.sharded(name):
+            if self.overlap_param_gather:
+                bk.launch_param_gather(name)
+            else:
+                w = bk._all_gather_bucket(self.flat_grad, name)
+                w.wait()
+                fb = self._bucket_tab(name)
+                L.check(L.lib().sfmi_unflatten_multi_f32(L.ptr(fb["p"]), L.ptr(fb["foff"]), L.ptr(fb["ct"]), L.ptr(fb["co"]), L.ptr(fb["cl"]), fb["n"],
+                                                         L.ptr(self.flat_grad), L.stream_ptr()), "unflatten_multi")
 
     @torch.no_grad()
     def _param_ready(self, name):
@@ -283,13 +332,13 @@ class GPTTrainer:
         for name in self.buckets.params_in_flight():
             self._param_ready(name)
 
-    def loss_and_grad(self, c_indices, z_indices, accumulate=False, sync=False, dropout_key=None):
+    def loss_and_grad(self, c_indices, z_indices, accumulate=False, sync=False, dropout_key=None, _fused=False):
         """-> loss (0-dim tensor).  Gradients of every parameter are left in self.grad[name] (flat buffer).
         dropout_key=None: eval-mode graph (no dropout); a string: train mode, the mask of site s is hash "dropout-<key>-<s>".
         sync=True (last micro-step of a data-parallel step): each block's gradient bucket is all-reduced as soon as it
         is final, under the backward kernels of the remaining blocks (dist.GradBuckets); finish with all_reduce_grads()."""
         g, D, dev, lib = self.g, self.D, self.dev, L.lib()
-        self._acc, self._sync = accumulate, sync
+        self._acc, self._sync, self._fused = accumulate, sync, bool(_fused)
         self._param_ready("emb")       # rs_ag: the embeddings' gathered parameters leave the flat buffer before it is written again
         self._param_ready("L0")        # the embedding kernel also applies block 0's first LayerNorm
         if not accumulate:
@@ -551,10 +600,21 @@ class GPTTrainer:
 
     @torch.no_grad()
     def training_step(self, c_indices, z_indices):
-        """One optimizer step in TRAIN mode (dropout on when the model's pdrop > 0; every rank / step draws its own masks)."""
+        """One optimizer step in TRAIN mode (dropout on when the model's pdrop > 0; every rank / step draws its own masks).
+        fused_optimizer: the gradient collectives are consumed and the parameters updated bucket by bucket INSIDE the backward pass
+        (see the constructor); else loss_and_grad -> all_reduce_grads -> optimizer_step.  The result is the same bit for bit."""
         rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
         key = f"{self.dropout_seed}-{rank}-{self.step_count}" if any(self.pdrop) else None
-        loss = self.loss_and_grad(c_indices, z_indices, sync=True, dropout_key=key)
-        self.all_reduce_grads()
-        self.optimizer_step()
+        if not self.fused_optimizer:
+            loss = self.loss_and_grad(c_indices, z_indices, sync=True, dropout_key=key)
+            self.all_reduce_grads()
+            self.optimizer_step()
+            return loss
+        self.step_count += 1
+        try:
+            loss = self.loss_and_grad(c_indices, z_indices, sync=True, dropout_key=key, _fused=True)
+        finally:
+            self._fused = False
+        self.buckets.end_step()
+        self.g.mark_decode_weights_stale()
         return loss
