@@ -49,8 +49,9 @@ def main():
     slo, shi = tr2.buckets.shard("L1")
     lo, hi = tr2.buckets.ranges["L1"]
     out["rsag_shard_frac"] = np.float64((shi - slo) / (hi - lo))
-    out["rsag_table_chunks"] = np.int64(tr2._adam_tab_shard["n"])
-    out["ring_table_chunks"] = np.int64(tr2._adam_tab["n"])
+    # update work per rank: chunks of the per-bucket AdamW tables (fused step), sharded mode against the ring trainer's whole buckets
+    out["rsag_table_chunks"] = np.int64(sum(tb["n"] for tb in tr2._opt_tabs.values()))
+    out["ring_table_chunks"] = np.int64(sum(tb["n"] for tb in tr._opt_tabs.values()))
     tr2.training_step(c, z)
     # the parameter all-gathers of the step were launched, not waited for: the next forward (or finish_param_gather) consumes them
     out["rsag_gathers_in_flight"] = np.int64(len(tr2.buckets.params_in_flight()))
