@@ -24,6 +24,37 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
+def _concurrent_streams(dev, n, candidates=8):
+    """n HIP streams that run concurrently WITH THE CURRENT STREAM and with each other.  The runtime multiplexes streams onto a few
+    hardware queues; two streams on one queue run back to back.  Candidates are probed as gpt.CondTupleGPT._chain_streams probes them:
+    one 200 us single-wavefront spin per stream, all at once - ~0.2 ms when every stream has a queue of its own, >= 0.4 ms otherwise.
+    Falls back to unprobed streams when no set passes (correct either way: overlap is an optimisation)."""
+    if n <= 0:
+        return []
+    cur = torch.cuda.current_stream(dev)
+    ticks = 20000      # x 10 ns
+
+    def overlap(ss):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        L.check(L.lib().sfmi_stream_spin(ticks, cur.cuda_stream), "sfmi_stream_spin")
+        for st in ss:
+            st.wait_event(e0)
+            L.check(L.lib().sfmi_stream_spin(ticks, st.cuda_stream), "sfmi_stream_spin")
+        for st in ss:
+            cur.wait_stream(st)
+        e1.record(cur)
+        e1.synchronize()
+        return e0.elapsed_time(e1) < 1.5 * ticks * 1e-5
+    chosen, pool = [], [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+    for st in pool:
+        if len(chosen) == n:
+            break
+        if overlap(chosen + [st]) or overlap(chosen + [st]):
+            chosen.append(st)
+    return (chosen + [st for st in pool if st not in chosen])[:n]
+
+
 class GPTTrainer:
     def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0,
                  single_rank_collectives=False, grad_sync="ring", profile_waits=False, gemm="sk", overlap_param_gather=True, side_stream=True, fused_optimizer=True):
@@ -42,10 +73,11 @@ class GPTTrainer:
         assert gemm in ("sk", "tile")
         self.gemm_algo, self.overlap_param_gather, self.fused_optimizer = gemm, bool(overlap_param_gather), bool(fused_optimizer)
         self._fused = False
-        self._side = torch.cuda.Stream(device=gpt.dev) if side_stream else None
         # the per-bucket optimizer of the fused step gets a stream of its own: it has to wait for the bucket's gradient collective, and
         # the weight-gradient GEMMs of the blocks below must not queue behind that wait
-        self._opt_stream = torch.cuda.Stream(device=gpt.dev) if (side_stream and fused_optimizer) else None
+        extra = _concurrent_streams(gpt.dev, (1 if side_stream else 0) + (1 if (side_stream and fused_optimizer) else 0))
+        self._side = extra[0] if side_stream else None
+        self._opt_stream = extra[1] if (side_stream and fused_optimizer) else None
         self._on_side, self._keep = False, []
         self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
         # (embd_pdrop, resid_pdrop, attn_pdrop): the model's (CondTupleGPT ctor kwargs / YAML) unless given
