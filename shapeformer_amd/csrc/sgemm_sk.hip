@@ -402,21 +402,46 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
           for (int j = 0; j < TM; ++j)
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
-        for (int w = v_first; w <= v_last; ++w) {
-          // workgroup w's slot for this tile: 0 when the tile is where w's range starts, else 1 (its last segment)
+        // workgroup w's slot for this tile: 0 when the tile is where w's range starts, else 1 (its last segment)
+        auto slot_rsrc = [&](int w) {
           const int wslot = (int)(sk_first_unit(w, U, G) / C) == tile ? 0 : 1;
-          const __amdgpu_buffer_rsrc_t rs = sk_rsrc(a.slab + (((long long)w * 2 + wslot) * 4 + wave) * (64 * NACC), 64 * NACC * 4);
-          u32x4 t[TM * TM * 4];
+          return sk_rsrc(a.slab + (((long long)w * 2 + wslot) * 4 + wave) * (64 * NACC), 64 * NACC * 4);
+        };
+        if constexpr (TM == 1) {
+          // the slices of up to four contributors are requested together (16 registers each would be 64 for the 128 x 128 form: that one
+          // stays at one contributor per round trip): a serial round trip per contributor was most of a cut tile's tail
+          for (int w0 = v_first; w0 <= v_last; w0 += 4) {
+            u32x4 t[4][4];
 #pragma unroll
-          for (int x = 0; x < TM * TM * 4; ++x) t[x] = __builtin_amdgcn_raw_buffer_load_b128(rs, (x * 64 + lane) * 16, 0, /*sc1*/ 16);
+            for (int k = 0; k < 4; ++k) {
+              const __amdgpu_buffer_rsrc_t rs = slot_rsrc(min(w0 + k, v_last));
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+              for (int x = 0; x < 4; ++x) t[k][x] = __builtin_amdgcn_raw_buffer_load_b128(rs, (x * 64 + lane) * 16, 0, /*sc1*/ 16);
+            }
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
+            for (int k = 0; k < 4; ++k) {
+              if (w0 + k > v_last) break;        // added in k order (deterministic)
 #pragma unroll
               for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][4 * gg + e] += __uint_as_float(t[(i * TM + j) * 4 + gg][e]);
+                for (int e = 0; e < 4; ++e) acc[0][0][4 * gg + e] += __uint_as_float(t[k][gg][e]);
+            }
+          }
+        } else {
+          for (int w = v_first; w <= v_last; ++w) {
+            const __amdgpu_buffer_rsrc_t rs = slot_rsrc(w);
+            u32x4 t[TM * TM * 4];
+#pragma unroll
+            for (int x = 0; x < TM * TM * 4; ++x) t[x] = __builtin_amdgcn_raw_buffer_load_b128(rs, (x * 64 + lane) * 16, 0, /*sc1*/ 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc[i][j][4 * gg + e] += __uint_as_float(t[(i * TM + j) * 4 + gg][e]);
+          }
         }
         finished = true;
       }

@@ -472,9 +472,12 @@ class GPTTrainer:
             dlgT, xnhT = self._T(dlg, M, g.Vpad, Rpad=Mp), self._T(xnh, M, D, Rpad=Mp)
             gh = self.grad[f"head{s}.w"]                                  # rows >= V of dlg^T are zero: write (V,D) directly
             self._gemm(dlgT, xnhT, None, gh if accumulate else None, gh, g.V, D, Mp)
-            whT = self._T(g.head_w_pad[s], g.Vpad, D, Rpad=g.Vpad)      # (D, Vpad)
             dxnh = self._f(M, D)
-            self._gemm(dlg, whT, None, None, dxnh, M, D, g.Vpad)
+            if self.gemm_algo == "sk":      # dX = dlg W_h with W_h (Vpad, D) read in place as the (k, n)-stored operand: no 16 MB transpose per head
+                self._sgemm(0, 0, M, D, g.Vpad, dlg, g.Vpad, g.head_w_pad[s], D, dxnh, D)
+            else:
+                whT = self._T(g.head_w_pad[s], g.Vpad, D, Rpad=g.Vpad)      # (D, Vpad)
+                self._gemm(dlg, whT, None, None, dxnh, M, D, g.Vpad)
             d_head[s], hst, _ = self._ln_rows(dxnh, head_in[s], g.head_ln[s][0], None, M)
             head_jobs.append(("ln", dxnh, head_in[s], hst, f"head{s}.ln.w", f"head{s}.ln.b"))
         self._col_reduce(head_jobs, M)
