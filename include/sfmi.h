@@ -230,6 +230,11 @@ int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* 
                       int B, int L, int D, int H, float attn_drop_p, unsigned attn_drop_seed /* the forward's mask */, void* stream);
 /* the same gradients from the forward's row log-sum-exps (sfmi_gpt_attn_prefill_lse_f32): a row-sum launch (delta = sum_d dO O, (B,H,L)
  * scratch) + ONE launch that runs the dQ blocks and the dK/dV blocks side by side (2 x the workgroups: fills the chip at batch 1) */
+/* training forward of the same attention for launches too small to fill the chip with 64-row tiles (B * H * ceil(L / 64) <= 128; batch 1
+ * of the YAML): 32-row tiles x two key-block groups per workgroup, merged online-softmax states; writes y (B*L, D) and the (B,H,L) row
+ * log-sum-exps.  SFMI_EINVAL for larger launches (use sfmi_gpt_attn_prefill_lse_f32) */
+int sfmi_attn_train_fwd_small_f32(const float* qkv, float* y, float* lse, int B, int L, int D, int H, float attn_drop_p,
+                                  unsigned attn_drop_seed, void* stream);
 int sfmi_attn_bwd_lse_f32(const float* qkv, const float* y, const float* dy, const float* lse, float* delta /*B*H*L floats scratch*/,
                           float* dqkv, int B, int L, int D, int H, float attn_drop_p, unsigned attn_drop_seed, void* stream);
 /* nn.Dropout(p) forward == backward on a flat tensor: y = x * mask / (1-p), mask_i = hash(seed, i) >= p (mingpt.py:90,105,218,292) */

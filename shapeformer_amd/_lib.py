@@ -124,6 +124,7 @@ PROTOTYPES = {
     "sfmi_col_reduce_f32": (i32, [i32] + [c_ptr] * 8 + [i32, i32, c_ptr, i64, c_ptr, i64, c_ptr]),
     "sfmi_ce_fwd_bwd_f32": (i32, [c_ptr] * 4 + [i32] * 5 + [C.c_float, c_ptr]),
     "sfmi_attn_bwd_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [f32, C.c_uint, c_ptr]),
+    "sfmi_attn_train_fwd_small_f32": (i32, [c_ptr] * 3 + [i32] * 4 + [f32, C.c_uint, c_ptr]),
     "sfmi_attn_bwd_lse_f32": (i32, [c_ptr] * 6 + [i32] * 4 + [f32, C.c_uint, c_ptr]),
     "sfmi_dropout_f32": (i32, [c_ptr, c_ptr, i64, f32, C.c_uint, c_ptr]),
     "sfmi_embed_scatter_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, c_ptr]),

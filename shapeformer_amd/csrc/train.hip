@@ -405,45 +405,48 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 
 // one 64-row tile of a (b, h) slice: global -> registers (4 float4 per thread) -> stride-68 LDS tile.  The loads of block i+1 are
 // issued right after block i has been handed to LDS, so their latency runs under the block's 192 / 256 MFMAs per wave.
-__device__ __forceinline__ void ab_load(f32x4 (&r)[4], const float* __restrict__ src, long long row_base, int r0, int L, int ld, int tid) {
+template <int GT>      // GT threads of a wave group move one 64 x 64 tile: 1024 / GT float4 each
+__device__ __forceinline__ void ab_load(f32x4 (&r)[1024 / GT], const float* __restrict__ src, long long row_base, int r0, int L, int ld, int tid) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int i = tid + 256 * it, rr = i >> 4, c = i & 15;
+  for (int it = 0; it < 1024 / GT; ++it) {
+    const int i = tid + GT * it, rr = i >> 4, c = i & 15;
     const int t = min(r0 + rr, L - 1);
     r[it] = *reinterpret_cast<const f32x4*>(src + (row_base + t) * ld + 4 * c);
   }
 }
-__device__ __forceinline__ void ab_store(float* __restrict__ dst, const f32x4 (&r)[4], int tid) {
+template <int GT>
+__device__ __forceinline__ void ab_store(float* __restrict__ dst, const f32x4 (&r)[1024 / GT], int tid) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int i = tid + 256 * it, rr = i >> 4, c = i & 15;
+  for (int it = 0; it < 1024 / GT; ++it) {
+    const int i = tid + GT * it, rr = i >> 4, c = i & 15;
     *reinterpret_cast<f32x4*>(&dst[rr * AB_S + 4 * c]) = r[it];
   }
 }
 
 // dQ of query block qb (the former attn_bwd_dq_mfma_kernel: same arithmetic, same order).
-// NG wave groups (NG = 2: 512-thread workgroups at small batch): group g walks the key blocks g, g + NG, ... with its own LDS tiles, the
-// partial dQ's are added through LDS at the end - half the dependent blocks per workgroup (the loop of the last query block is the launch's
-// critical path when B * H * blocks <= the CU count).  NG = 1 is bit-identical to rounds 1-4.
-template <int NG>
+// Tiling: a workgroup owns 16 * RW query rows (RW row waves) and NG wave groups; group g walks the key blocks g, g + NG, ... with its own
+// LDS tiles and the partial dQ's are added through LDS at the end.  <RW 4, NG 1> is the form of rounds 1-4 (bit-identical).  Small
+// launches (batch 1: everything resident at once, the launch lasts as long as its heaviest WAVE - the last query rows walk every key
+// block) use <RW 2, NG 2>: the same rows' work spread over twice the SIMDs, twice the workgroups to balance the causal triangle.
+template <int RW, int NG>
 __device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem_all, const float* __restrict__ qkv, const float* __restrict__ dy,
                                                  const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                  int b, int h, int H, int qb, int L, int D, float scale, float drop_p, unsigned drop_seed) {
-  constexpr int GROUP_FLOATS = 2 * 64 * AB_S + 8 * 16 * AB_S;
-  const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
+  constexpr int GT = 64 * RW, GROUP_FLOATS = 2 * 64 * AB_S + 2 * RW * 16 * AB_S;
+  const int grp = NG == 1 ? 0 : (int)(threadIdx.x / GT);
   float* smem = smem_all + grp * GROUP_FLOATS;
   float* Ks = smem;
   float* Vs = smem + 64 * AB_S;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;
   float* Tw = smem + 2 * 64 * AB_S + wave * 16 * AB_S;
-  const int lr = lane & 15, lq = lane >> 4, q0 = qb * 64;
+  const int lr = lane & 15, lq = lane >> 4, q0 = qb * 16 * RW;
   const long long rb = (long long)b * L, sb = ((long long)b * H + h) * L;
   const int trow = min(q0 + 16 * wave + lr, L - 1);
-  const int kend = min(L, q0 + 64), nblk = (kend + 63) / 64, rounds = (nblk + NG - 1) / NG;
-  f32x4 pk[4], pv[4];
+  const int kend = min(L, q0 + 16 * RW), nblk = (kend + 63) / 64, rounds = (nblk + NG - 1) / NG;
+  f32x4 pk[1024 / GT], pv[1024 / GT];
   if (grp < nblk) {
-    ab_load(pk, qkv + D + h * 64, rb, 64 * grp, L, 3 * D, tid);
-    ab_load(pv, qkv + 2 * D + h * 64, rb, 64 * grp, L, 3 * D, tid);
+    ab_load<GT>(pk, qkv + D + h * 64, rb, 64 * grp, L, 3 * D, tid);
+    ab_load<GT>(pv, qkv + 2 * D + h * 64, rb, 64 * grp, L, 3 * D, tid);
   }
   float qf[16], dof[16];
   {
@@ -466,14 +469,14 @@ __device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem_all, c
     const bool active = k0 < kend;           // group-uniform; the barriers below are executed by every wave of the workgroup
     __syncthreads();
     if (active) {
-      ab_store(Ks, pk, tid);
-      ab_store(Vs, pv, tid);
+      ab_store<GT>(Ks, pk, tid);
+      ab_store<GT>(Vs, pv, tid);
     }
     __syncthreads();
     if (!active) continue;
     if (k0 + 64 * NG < kend) {
-      ab_load(pk, qkv + D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
-      ab_load(pv, qkv + 2 * D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
+      ab_load<GT>(pk, qkv + D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
+      ab_load<GT>(pv, qkv + 2 * D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -505,15 +508,16 @@ __device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem_all, c
   }
   if (NG > 1) {      // group 1's partial sums -> LDS (its own tiles are free after the barrier) -> group 0 adds them, in group order
     __syncthreads();
-    float* xch = smem_all + GROUP_FLOATS;        // 256 threads x 16 floats
+    static_assert(NG <= 2, "the exchange below adds ONE other group");
+    float* xch = smem_all + GROUP_FLOATS;        // GT threads x 16 floats
     if (grp == 1) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&xch[(dt * 256 + tid) * 4]) = dq[dt];
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&xch[(dt * GT + tid) * 4]) = dq[dt];
     }
     __syncthreads();
     if (grp != 0) return;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = dq[dt] + *reinterpret_cast<const f32x4*>(&xch[(dt * 256 + tid) * 4]);
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = dq[dt] + *reinterpret_cast<const f32x4*>(&xch[(dt * GT + tid) * 4]);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -526,26 +530,27 @@ __device__ __forceinline__ void attn_bwd_dq_role(float* __restrict__ smem_all, c
 }
 
 // dK / dV of key block kb_ (the former attn_bwd_dkv_mfma_kernel: same arithmetic, same order); NG wave groups as above, over the query blocks
-template <int NG>
+template <int RW, int NG>
 __device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem_all, const float* __restrict__ qkv, const float* __restrict__ dy,
                                                   const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                   int b, int h, int H, int kb_, int L, int D, float scale, float drop_p, unsigned drop_seed) {
-  constexpr int GROUP_FLOATS = 2 * 64 * AB_S + 8 * 16 * AB_S;
-  const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
+  constexpr int GT = 64 * RW, GROUP_FLOATS = 2 * 64 * AB_S + 2 * RW * 16 * AB_S;
+  const int grp = NG == 1 ? 0 : (int)(threadIdx.x / GT);
   float* smem = smem_all + grp * GROUP_FLOATS;
   float* Qs = smem;
   float* Os = smem + 64 * AB_S;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;
   float* Pw = smem + 2 * 64 * AB_S + wave * 16 * AB_S;
-  float* Sw = smem + 2 * 64 * AB_S + 4 * 16 * AB_S + wave * 16 * AB_S;
-  const int lr = lane & 15, lq = lane >> 4, k0 = kb_ * 64;
+  float* Sw = smem + 2 * 64 * AB_S + RW * 16 * AB_S + wave * 16 * AB_S;
+  const int lr = lane & 15, lq = lane >> 4, k0 = kb_ * 16 * RW;
+  const int qs = (k0 >> 6) << 6;      // the 64-aligned query block that holds the first query row >= k0
   const long long rb = (long long)b * L, sb = ((long long)b * H + h) * L;
   const int krow = min(k0 + 16 * wave + lr, L - 1);
-  const int nblk = (L - k0 + 63) / 64, rounds = (nblk + NG - 1) / NG;
-  f32x4 pq[4], po[4];
+  const int nblk = (L - qs + 63) / 64, rounds = (nblk + NG - 1) / NG;
+  f32x4 pq[1024 / GT], po[1024 / GT];
   if (grp < nblk) {
-    ab_load(pq, qkv + h * 64, rb, k0 + 64 * grp, L, 3 * D, tid);
-    ab_load(po, dy + h * 64, rb, k0 + 64 * grp, L, D, tid);
+    ab_load<GT>(pq, qkv + h * 64, rb, qs + 64 * grp, L, 3 * D, tid);
+    ab_load<GT>(po, dy + h * 64, rb, qs + 64 * grp, L, D, tid);
   }
   float kf[16], vf[16];
   {
@@ -557,18 +562,18 @@ __device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem_all, 
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
   for (int r = 0; r < rounds; ++r) {
-    const int q0 = k0 + 64 * (r * NG + grp);
+    const int q0 = qs + 64 * (r * NG + grp);
     const bool active = q0 < L;
     __syncthreads();
     if (active) {
-      ab_store(Qs, pq, tid);
-      ab_store(Os, po, tid);
+      ab_store<GT>(Qs, pq, tid);
+      ab_store<GT>(Os, po, tid);
     }
     __syncthreads();
     if (!active) continue;
     if (q0 + 64 * NG < L) {
-      ab_load(pq, qkv + h * 64, rb, q0 + 64 * NG, L, 3 * D, tid);
-      ab_load(po, dy + h * 64, rb, q0 + 64 * NG, L, D, tid);
+      ab_load<GT>(pq, qkv + h * 64, rb, q0 + 64 * NG, L, 3 * D, tid);
+      ab_load<GT>(po, dy + h * 64, rb, q0 + 64 * NG, L, D, tid);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -605,20 +610,21 @@ __device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem_all, 
   }
   if (NG > 1) {
     __syncthreads();
-    float* xch = smem_all + GROUP_FLOATS;        // 256 threads x 32 floats
+    static_assert(NG <= 2, "the exchange below adds ONE other group");
+    float* xch = smem_all + GROUP_FLOATS;        // GT threads x 32 floats
     if (grp == 1) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        *reinterpret_cast<f32x4*>(&xch[(dt * 256 + tid) * 4]) = dk[dt];
-        *reinterpret_cast<f32x4*>(&xch[((4 + dt) * 256 + tid) * 4]) = dv[dt];
+        *reinterpret_cast<f32x4*>(&xch[(dt * GT + tid) * 4]) = dk[dt];
+        *reinterpret_cast<f32x4*>(&xch[((4 + dt) * GT + tid) * 4]) = dv[dt];
       }
     }
     __syncthreads();
     if (grp != 0) return;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      dk[dt] = dk[dt] + *reinterpret_cast<const f32x4*>(&xch[(dt * 256 + tid) * 4]);
-      dv[dt] = dv[dt] + *reinterpret_cast<const f32x4*>(&xch[((4 + dt) * 256 + tid) * 4]);
+      dk[dt] = dk[dt] + *reinterpret_cast<const f32x4*>(&xch[(dt * GT + tid) * 4]);
+      dv[dt] = dv[dt] + *reinterpret_cast<const f32x4*>(&xch[((4 + dt) * GT + tid) * 4]);
     }
   }
 #pragma unroll
@@ -636,26 +642,180 @@ __device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem_all, 
 // block nqb - 1 - z / 2, z odd: dK / dV of key block z / 2 - the longest loops of either kind are dispatched first.  The two kinds are
 // independent given lse and delta, so the launch has twice the workgroups of either (256 at batch 1: every CU gets one), and the
 // causal imbalance of one kind (1 .. nqb blocks per workgroup) is filled by the other.
-template <int NG>
-__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
-                                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                                   float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
-                                                                                   unsigned drop_seed) {
-  __shared__ __attribute__((aligned(16))) float smem[NG * (2 * 64 * AB_S + 8 * 16 * AB_S)];
-  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, z = blockIdx.z, nqb = gridDim.z >> 1;
-  if (z & 1) attn_bwd_dkv_role<NG>(smem, qkv, dy, lse, delta, dqkv, b, h, H, z >> 1, L, D, scale, drop_p, drop_seed);
-  else attn_bwd_dq_role<NG>(smem, qkv, dy, lse, delta, dqkv, b, h, H, nqb - 1 - (z >> 1), L, D, scale, drop_p, drop_seed);
+// ------------------------------------------------------------------------------------------------
+// Training forward of the causal attention for SMALL launches (round 5; batch 1 = 16 heads x 8 query blocks = 128 workgroups of the
+// prefill kernel for 256 CUs, and the last query block walks 8 key blocks one after the other with one wave per SIMD: 43 us per layer
+// for 0.26 GFLOP).  A workgroup owns 16 * RW query rows; NG wave groups walk the key blocks g, g + NG, ... with their own K / V tiles and
+// their own online-softmax state (m, l, O); the groups' states are merged through LDS at the end:
+//   m = max_g m_g ;  l = sum_g l_g exp(m_g - m) ;  O = sum_g O_g exp(m_g - m) ;  y = O / l ;  lse = m + log l
+// Same MFMA shapes and LDS conventions as the backward kernels below (16x16x4 f32, stride-68 tiles, C/D register j = row 4 (lane>>4) + j).
+// Attention dropout as in csrc/gpt.hip:attn_prefill_mfma_kernel (mask of element (b, h, query, key), applied to P after the row sum).
+// ------------------------------------------------------------------------------------------------
+template <int RW, int NG>
+__global__ __launch_bounds__(64 * RW * NG) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ y,
+                                                                      float* __restrict__ lse, int L, int D, float scale, float drop_p,
+                                                                      unsigned drop_seed) {
+  constexpr int GT = 64 * RW, NIT = 1024 / GT, GROUP_FLOATS = 2 * 64 * AB_S + RW * 16 * AB_S;
+  __shared__ __attribute__((aligned(16))) float smem_all[NG * GROUP_FLOATS];
+  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, qb = blockIdx.z;
+  const int grp = NG == 1 ? 0 : (int)(threadIdx.x / GT), tid = threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;
+  float* Ks = smem_all + grp * GROUP_FLOATS;
+  float* Vs = Ks + 64 * AB_S;
+  float* Pw = Vs + 64 * AB_S + wave * 16 * AB_S;
+  const int lr = lane & 15, lq = lane >> 4, q0 = qb * 16 * RW;
+  const long long rb = (long long)b * L;
+  float qf[16];
+  {
+    const int tq = min(q0 + 16 * wave + lr, L - 1);
+    const float* qp = qkv + (rb + tq) * 3 * D + h * 64 + lq;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) qf[kk] = qp[4 * kk] * scale;
+  }
+  float mrun[4], lrun[4];
+  f32x4 o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kend = min(L, q0 + 16 * RW), nblk = (kend + 63) / 64, rounds = (nblk + NG - 1) / NG;
+  f32x4 pk[NIT], pv[NIT];
+  if (grp < nblk) {
+    ab_load<GT>(pk, qkv + D + h * 64, rb, 64 * grp, L, 3 * D, tid);
+    ab_load<GT>(pv, qkv + 2 * D + h * 64, rb, 64 * grp, L, 3 * D, tid);
+  }
+  const int qlast = min(q0 + 16 * wave + 15, L - 1);      // the last query row of this wave
+  for (int r = 0; r < rounds; ++r) {
+    const int k0 = 64 * (r * NG + grp);
+    const bool active = k0 < kend;            // group-uniform; every wave of the workgroup executes the two barriers
+    __syncthreads();
+    if (active) {
+      ab_store<GT>(Ks, pk, tid);
+      ab_store<GT>(Vs, pv, tid);
+    }
+    __syncthreads();
+    if (!active) continue;
+    if (k0 + 64 * NG < kend) {
+      ab_load<GT>(pk, qkv + D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
+      ab_load<GT>(pv, qkv + 2 * D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
+    }
+    // key tiles with at least one key <= the wave's last query row (later tiles are fully masked: p == 0 exactly)
+    const int tmax = min(3, (qlast - k0) >> 4);
+    if (tmax < 0) continue;                   // (only wave-level synchronisation below)
+    f32x4 sacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t > tmax) continue;
+      const float* kp = &Ks[(16 * t + lr) * AB_S + lq];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) sacc[t] = AB_MFMA(qf[kk], kp[4 * kk], sacc[t]);
+    }
+    float corr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qrow = q0 + 16 * wave + 4 * lq + j;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t > tmax) continue;
+        const int key = k0 + 16 * t + lr;
+        if (key > qrow || key >= L) sacc[t][j] = -INFINITY;
+        mx = fmaxf(mx, sacc[t][j]);
+      }
+      mx = row16_max(mx);
+      const float mnew = fmaxf(mrun[j], mx), ms = mnew == -INFINITY ? 0.f : mnew;
+      corr[j] = __expf(mrun[j] - ms);
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float pe = 0.f;
+        if (t <= tmax) {
+          pe = __expf(sacc[t][j] - ms);
+          ps += pe;                      // the softmax denominator is the undropped sum (mingpt.py:84-85)
+          if (drop_p > 0.f)
+            pe *= sfmi_dropout_mul(drop_seed, (unsigned)(((b * H + h) * L + qrow) * L + k0 + 16 * t + lr), drop_p, 1.0f / (1.0f - drop_p));
+        }
+        Pw[(4 * lq + j) * AB_S + 16 * t + lr] = pe;
+      }
+      ps = row16_sum(ps);
+      lrun[j] = lrun[j] * corr[j] + ps;
+      mrun[j] = mnew;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] *= corr[j];
+    __builtin_amdgcn_wave_barrier();
+    const float* pp = &Pw[lr * AB_S + lq];
+    for (int kk = 0; kk < 4 * (tmax + 1); ++kk) {      // keys 4 kk + lq of the tiles in use
+      const float pa = pp[4 * kk];
+      const float* vb = &Vs[(4 * kk + lq) * AB_S + lr];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = AB_MFMA(pa, vb[16 * dt], o[dt]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (NG > 1) {      // merge the groups' (m, l, O) states: group g > 0 publishes, group 0 folds them in, in group order
+    __syncthreads();
+    float* xch = smem_all + GROUP_FLOATS;        // (NG - 1) x 24 x GT floats: inside the other groups' (now free) tiles
+    if (grp > 0) {
+      float* x = xch + (grp - 1) * 24 * GT;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x[j * GT + tid] = mrun[j]; x[(4 + j) * GT + tid] = lrun[j]; }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[(8 + 4 * dt + j) * GT + tid] = o[dt][j];
+    }
+    __syncthreads();
+    if (grp != 0) return;
+    for (int g = 1; g < NG; ++g) {
+      const float* x = xch + (g - 1) * 24 * GT;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float mg = x[j * GT + tid], lg = x[(4 + j) * GT + tid];
+        const float mnew = fmaxf(mrun[j], mg), ms = mnew == -INFINITY ? 0.f : mnew;
+        const float ca = __expf(mrun[j] - ms), cb = __expf(mg - ms);      // exp(-inf) = 0: an empty state contributes nothing
+        lrun[j] = lrun[j] * ca + lg * cb;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt][j] = o[dt][j] * ca + x[(8 + 4 * dt + j) * GT + tid] * cb;
+        mrun[j] = mnew;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tq = q0 + 16 * wave + 4 * lq + j;
+    if (tq >= L) continue;
+    const float inv = 1.0f / lrun[j];
+    float* yp = y + (rb + tq) * D + h * 64 + lr;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) yp[16 * dt] = o[dt][j] * inv;
+    if (lr == 0) lse[((long long)b * H + h) * L + tq] = mrun[j] + __logf(lrun[j]);
+  }
 }
 
-// small launches (every workgroup resident at once: the longest block loop is the launch's duration) run two wave groups per workgroup
+template <int RW, int NG>
+__global__ __launch_bounds__(64 * RW * NG) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
+                                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                      float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
+                                                                      unsigned drop_seed) {
+  __shared__ __attribute__((aligned(16))) float smem[NG * (2 * 64 * AB_S + 2 * RW * 16 * AB_S)];
+  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, z = blockIdx.z, nqb = gridDim.z >> 1;
+  if (z & 1) attn_bwd_dkv_role<RW, NG>(smem, qkv, dy, lse, delta, dqkv, b, h, H, z >> 1, L, D, scale, drop_p, drop_seed);
+  else attn_bwd_dq_role<RW, NG>(smem, qkv, dy, lse, delta, dqkv, b, h, H, nqb - 1 - (z >> 1), L, D, scale, drop_p, drop_seed);
+}
+
+// small launches (every workgroup resident at once: the heaviest wave is the launch's duration) run 32-row tiles x two wave groups
 static void attn_bwd_fused_launch(hipStream_t st, const float* qkv, const float* dy, const float* lse, const float* delta, float* dqkv, int B,
                                   int L, int D, int H, float drop_p, unsigned drop_seed) {
   const int nqb = (L + 63) / 64;
-  const dim3 grid(B, H, 2 * nqb);
-  if ((long long)B * H * 2 * nqb <= 256 && nqb > 1)
-    hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, grid, dim3(512), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
-  else
-    hipLaunchKernelGGL(attn_bwd_fused_kernel<1>, grid, dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  if ((long long)B * H * 2 * nqb <= 256 && nqb > 1) {
+    const int n32 = (L + 31) / 32;
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<2, 2>), dim3(B, H, 2 * n32), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<4, 1>), dim3(B, H, 2 * nqb), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+  }
 }
 
 // softmax cross-entropy: loss_row[m] = lse - logit[target] ; dlogits = (softmax - onehot) * scale for rows with
@@ -949,6 +1109,18 @@ int sfmi_attn_bwd_lse_f32(const float* qkv, const float* y, const float* dy, con
   const int nqb = (L + 63) / 64;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long long)B * L + 3) / 4)), dim3(256), 0, st, y, dy, delta, B, L, D, H);
   attn_bwd_fused_launch(st, qkv, dy, lse, delta, dqkv, B, L, D, H, drop_p, drop_seed);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+// Training forward of CausalSelfAttention (mingpt.py:73-91) for launches too small to fill the chip with the 64-row prefill tiles
+// (B * H * ceil(L / 64) <= 128, head dim 64): 32-row tiles x two key-block groups per workgroup, (B,H,L) log-sum-exps for the backward
+// pass.  Larger launches use sfmi_gpt_attn_prefill_lse_f32.  Returns SFMI_EINVAL when the launch is not "small".
+int sfmi_attn_train_fwd_small_f32(const float* qkv, float* y, float* lse, int B, int L, int D, int H, float drop_p, unsigned drop_seed,
+                                  void* stream) {
+  if (!qkv || !y || !lse || B <= 0 || L <= 0 || H <= 0 || D != 64 * H || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
+  if ((long long)B * H * ((L + 63) / 64) > 128) return SFMI_EINVAL;
+  hipLaunchKernelGGL((attn_train_fwd_kernel<2, 2>), dim3(B, H, (L + 31) / 32), dim3(256), 0, (hipStream_t)stream, qkv, y, lse, L, D, 0.125f, drop_p,
+                     drop_seed);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

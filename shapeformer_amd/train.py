@@ -420,8 +420,13 @@ class GPTTrainer:
             self._gemm(xn, ly.wqkv, ly.bqkv, None, qkv, M, 3 * D, D)
             y = self._f(M, D)
             lse_l = self._f(B, g.H, Lq)        # row log-sum-exps of the scaled scores: the attention backward starts from them
-            L.check(lib.sfmi_gpt_attn_prefill_lse_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
-                                                      g.H, g.Lmax + 1, None, *site(p_attn, f"L{li}.attn"), L.ptr(lse_l), L.stream_ptr()), "attn")
+            if D == 64 * g.H and B * g.H * ((Lq + 63) // 64) <= 128:
+                # too few 64-row tiles for 256 CUs (the YAML's batch 1): 32-row tiles x two key-block groups per workgroup
+                L.check(lib.sfmi_attn_train_fwd_small_f32(L.ptr(qkv), L.ptr(y), L.ptr(lse_l), B, Lq, D, g.H, *site(p_attn, f"L{li}.attn"),
+                                                          L.stream_ptr()), "attn")
+            else:
+                L.check(lib.sfmi_gpt_attn_prefill_lse_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
+                                                          g.H, g.Lmax + 1, None, *site(p_attn, f"L{li}.attn"), L.ptr(lse_l), L.stream_ptr()), "attn")
             r1 = self._f(M, D)
             self._gemm(y, ly.wproj, ly.bproj, resid, r1, M, D, D, drop=site(p_resid, f"L{li}.proj"))
             xn2 = self._f(M, D)

@@ -190,7 +190,7 @@ def test_library_gemm_binding_and_large_row_training_path(dev, monkeypatch):
             assert err < 2e-3, (name, use_lib, err)
 
 
-@pytest.mark.parametrize("B,L,H", [(1, 499, 16), (2, 150, 2), (3, 64, 4)])
+@pytest.mark.parametrize("B,L,H", [(1, 499, 16), (2, 150, 2), (3, 64, 4), (1, 33, 2), (4, 300, 16)])
 def test_attention_backward_fused_launch_from_the_forward_lse(dev, B, L, H):
     """Round 5: the training forward keeps the rows' log-sum-exps (sfmi_gpt_attn_prefill_lse_f32) and the backward is a row-sum launch
     + ONE launch that runs the dQ and the dK / dV blocks side by side (sfmi_attn_bwd_lse_f32).  Against torch autograd of the same
@@ -219,6 +219,19 @@ def test_attention_backward_fused_launch_from_the_forward_lse(dev, B, L, H):
                                                L_.ptr(lse), L_.stream_ptr()), "attn fwd")
     assert float((y.cpu().double() - yref.detach()).abs().max()) < 2e-5
     assert float((lse.cpu().double() - lse_ref.detach()).abs().max()) < 2e-5
+    # the small-launch forward (32-row tiles x two key-block groups, merged online-softmax states): same y / lse; with attention
+    # dropout the same mask as the prefill kernel
+    if B * H * ((L + 63) // 64) <= 128:
+        y2, lse2 = torch.full_like(y, float("nan")), torch.full_like(lse, float("nan"))
+        L_.check(lib.sfmi_attn_train_fwd_small_f32(L_.ptr(qd), L_.ptr(y2), L_.ptr(lse2), B, L, D, H, 0.0, 0, L_.stream_ptr()), "attn fwd small")
+        assert float((y2.cpu().double() - yref.detach()).abs().max()) < 2e-5 and float((lse2 - lse).abs().max()) < 1e-5
+        y3, y4 = torch.empty_like(y), torch.empty_like(y)
+        L_.check(lib.sfmi_attn_train_fwd_small_f32(L_.ptr(qd), L_.ptr(y3), L_.ptr(lse2), B, L, D, H, 0.2, 7, L_.stream_ptr()), "attn fwd small")
+        L_.check(lib.sfmi_gpt_attn_prefill_lse_f32(L_.ptr(qd), L_.ptr(kv[0]), L_.ptr(kv[1]), L_.ptr(nval), L_.ptr(y4), B, L, D, H, Lmax, None, 0.2, 7,
+                                                   None, L_.stream_ptr()), "attn fwd")
+        assert float((y3 - y4).abs().max()) < 2e-5 and float((y3 - y).abs().max()) > 1e-3      # the masks are live and equal
+    else:
+        assert lib.sfmi_attn_train_fwd_small_f32(L_.ptr(qd), L_.ptr(y), L_.ptr(lse), B, L, D, H, 0.0, 0, L_.stream_ptr()) == -1
     delta, dq1 = torch.empty(B, H, L, device=dev), torch.full((B * L, 3 * D), float("nan"), device=dev)
     L_.check(lib.sfmi_attn_bwd_lse_f32(L_.ptr(qd), L_.ptr(y), L_.ptr(dyd), L_.ptr(lse), L_.ptr(delta), L_.ptr(dq1), B, L, D, H, 0.0, 0, L_.stream_ptr()), "bwd lse")
     scale = float(x.grad.abs().max())
