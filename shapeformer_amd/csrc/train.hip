@@ -683,7 +683,6 @@ __global__ __launch_bounds__(64 * RW * NG) void attn_train_fwd_kernel(const floa
     ab_load<GT>(pk, qkv + D + h * 64, rb, 64 * grp, L, 3 * D, tid);
     ab_load<GT>(pv, qkv + 2 * D + h * 64, rb, 64 * grp, L, 3 * D, tid);
   }
-  const int qlast = min(q0 + 16 * wave + 15, L - 1);      // the last query row of this wave
   for (int r = 0; r < rounds; ++r) {
     const int k0 = 64 * (r * NG + grp);
     const bool active = k0 < kend;            // group-uniform; every wave of the workgroup executes the two barriers
@@ -698,14 +697,12 @@ __global__ __launch_bounds__(64 * RW * NG) void attn_train_fwd_kernel(const floa
       ab_load<GT>(pk, qkv + D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
       ab_load<GT>(pv, qkv + 2 * D + h * 64, rb, k0 + 64 * NG, L, 3 * D, tid);
     }
-    // key tiles with at least one key <= the wave's last query row (later tiles are fully masked: p == 0 exactly)
-    const int tmax = min(3, (qlast - k0) >> 4);
-    if (tmax < 0) continue;                   // (only wave-level synchronisation below)
+    // (tiles of the diagonal block that lie wholly above the wave's rows are fully masked - p == 0 exactly - and are computed anyway:
+    //  at most three wasted tiles per wave and query tile)
     f32x4 sacc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t > tmax) continue;
       const float* kp = &Ks[(16 * t + lr) * AB_S + lq];
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) sacc[t] = AB_MFMA(qf[kk], kp[4 * kk], sacc[t]);
@@ -717,7 +714,6 @@ __global__ __launch_bounds__(64 * RW * NG) void attn_train_fwd_kernel(const floa
       float mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        if (t > tmax) continue;
         const int key = k0 + 16 * t + lr;
         if (key > qrow || key >= L) sacc[t][j] = -INFINITY;
         mx = fmaxf(mx, sacc[t][j]);
@@ -728,13 +724,10 @@ __global__ __launch_bounds__(64 * RW * NG) void attn_train_fwd_kernel(const floa
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        float pe = 0.f;
-        if (t <= tmax) {
-          pe = __expf(sacc[t][j] - ms);
-          ps += pe;                      // the softmax denominator is the undropped sum (mingpt.py:84-85)
-          if (drop_p > 0.f)
-            pe *= sfmi_dropout_mul(drop_seed, (unsigned)(((b * H + h) * L + qrow) * L + k0 + 16 * t + lr), drop_p, 1.0f / (1.0f - drop_p));
-        }
+        float pe = __expf(sacc[t][j] - ms);
+        ps += pe;                        // the softmax denominator is the undropped sum (mingpt.py:84-85)
+        if (drop_p > 0.f)
+          pe *= sfmi_dropout_mul(drop_seed, (unsigned)(((b * H + h) * L + qrow) * L + k0 + 16 * t + lr), drop_p, 1.0f / (1.0f - drop_p));
         Pw[(4 * lq + j) * AB_S + 16 * t + lr] = pe;
       }
       ps = row16_sum(ps);
@@ -747,7 +740,8 @@ __global__ __launch_bounds__(64 * RW * NG) void attn_train_fwd_kernel(const floa
       for (int j = 0; j < 4; ++j) o[dt][j] *= corr[j];
     __builtin_amdgcn_wave_barrier();
     const float* pp = &Pw[lr * AB_S + lq];
-    for (int kk = 0; kk < 4 * (tmax + 1); ++kk) {      // keys 4 kk + lq of the tiles in use
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {      // keys 4 kk + lq
       const float pa = pp[4 * kk];
       const float* vb = &Vs[(4 * kk + lq) * AB_S + lr];
 #pragma unroll
