@@ -191,3 +191,22 @@ def test_bench_rccl_path_with_one_rank(dev):
     assert len(l2) == 1 and l2[0]["config"]["grad_sync_mode"] == "rs_ag" and l2[0]["param_allgather_wait_ms"] is not None
     # same data, same seeds, one rank: the sharded update (shard = everything) must reproduce the ring mode's loss trajectory
     assert abs(l2[0]["loss_last"] - line[0]["loss_last"]) < 1e-6 and abs(l2[0]["loss_first"] - line[0]["loss_first"]) < 1e-6
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL across devices)")
+def test_rs_ag_equals_ring_over_rccl_on_two_gpus(tmp_path):
+    """the in-place reduce_scatter_tensor / all_gather_into_tensor of GradBuckets mode "rs_ag" over REAL RCCL with world size 2
+    (the 2-rank tests above run over gloo on one device; the 1-rank RCCL legs cannot see aliasing bugs): two processes, one GPU each,
+    run `bench.py --mode train` for a few steps in both modes; the final losses must agree to fp32 rounding (same weights)."""
+    import json
+    outs = {}
+    for mode in ("ring", "rs_ag"):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "3", "--warmup", "1", "--grad-sync", mode]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert abs(outs["ring"]["loss_last"] - outs["rs_ag"]["loss_last"]) < 1e-4 and outs["rs_ag"]["n_gpus"] == 2

@@ -44,11 +44,14 @@ def test_encode_quantize_vs_reference_vectors(vq, vq16_sd_t):
     assert (lat - ref_lat).abs().max().item() < 2e-5 * scale + 1e-4
     np.testing.assert_allclose(lat.reshape(2, -1, 128)[:, ::61].numpy(), z["latent_sel"], atol=2e-5 * scale + 1e-4)
     raw = enc["quant_ind"].cpu().numpy().reshape(-1)
-    nbad = _near_tie_ok(vq16_sd_t, ref_lat, raw, z["quant_ind_raw"].astype(np.int64).reshape(-1))
+    want_raw = z["quant_ind_raw"].astype(np.int64).reshape(-1)
+    nbad = _near_tie_ok(vq16_sd_t, ref_lat, raw, want_raw)
     assert nbad <= 2
-    if nbad == 0:
-        assert int(mode) == int(z["mode"])
-        assert np.array_equal(q.cpu().numpy(), z["quant_ind"].astype(np.int64))
+    # `mode` and the masked grid are checked whatever nbad is: a near-tie can move at most nbad of the 8192 cells, which cannot change
+    # the most frequent code of the batch, and every cell whose raw index agrees must agree after the mask as well
+    assert int(mode) == int(z["mode"])
+    same = (raw == want_raw).reshape(q.shape)
+    assert np.array_equal(q.cpu().numpy()[same], z["quant_ind"].astype(np.int64)[same]) and int((~same).sum()) == nbad
 
 
 def test_local_pool_stages_bit_exact_max(vq, vq16_sd_t):
