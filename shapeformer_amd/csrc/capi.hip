@@ -20,8 +20,8 @@ int sfmi_tune_set(const char* name, int value) {
   const std::string n(name);
   SfmiTune& t = g_sfmi_tune;
   if (n == "attn_blocks" && value >= 0) t.attn_blocks = value;
-  else if (n == "attn_unroll" && (value == 2 || value == 4 || value == 8)) t.attn_unroll = value;
-  else if (n == "attn_waves" && (value == 8 || value == 16)) t.attn_waves = value;
+  else if (n == "attn_unroll" && (value == 2 || value == 4 || value == 8 || value == 16)) t.attn_unroll = value;
+  else if (n == "attn_waves" && (value == 4 || value == 8 || value == 16)) t.attn_waves = value;
   else if (n == "attn_lds_pad" && value >= 0 && value <= 140 * 1024) t.attn_lds_pad = value;
   else if (n == "sdf_blocks" && value >= 1 && value <= 512) t.sdf_blocks = value;
   else if (n == "dgemm_nt2" && value >= 0 && value <= 2) t.dgemm_nt2 = value;

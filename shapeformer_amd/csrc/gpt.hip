@@ -545,7 +545,7 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
 }
 
 template <int NWV, int U>
-__global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : 4) void attn_decode_kernel(AttnArgs a) {   // U <= 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128
+__global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : U <= 8 ? 4 : 2) void attn_decode_kernel(AttnArgs a) {   // U <= 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128, U = 16: <= 256
   __shared__ AttnLds<NWV> s;
   const int nitems = a.B * a.H;
   prof_begin(a.prof, blockIdx.x);
@@ -1291,13 +1291,14 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {   // the occupancy-cap experiments ask for more dynamic LDS than the 64 KB default
 #define AT_ATTR(W_, U_) do { hipError_t e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; } while (0)
-    AT_ATTR(16, 2); AT_ATTR(16, 4); AT_ATTR(16, 8); AT_ATTR(8, 2); AT_ATTR(8, 4); AT_ATTR(8, 8);
+    AT_ATTR(16, 2); AT_ATTR(16, 4); AT_ATTR(16, 8); AT_ATTR(8, 2); AT_ATTR(8, 4); AT_ATTR(8, 8); AT_ATTR(4, 8); AT_ATTR(4, 16);
 #undef AT_ATTR
   });
   if (pad && attr_err != hipSuccess) return (int)attr_err;
   if (sem) hipLaunchKernelGGL(attn_gate_kernel, dim3(1), dim3(64), 0, st, sem, lanes);
 #define AT(W_, U_) hipLaunchKernelGGL((attn_decode_kernel<W_, U_>), dim3(grid), dim3(64 * W_), pad, st, a)
   if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else if (g_tune.attn_unroll == 2) AT(16, 2); else AT(16, 4); }
+  else if (g_tune.attn_waves == 4) { if (g_tune.attn_unroll == 16) AT(4, 16); else AT(4, 8); }      // light-occupancy experiment (round 5)
   else { if (g_tune.attn_unroll == 8) AT(8, 8); else if (g_tune.attn_unroll == 2) AT(8, 2); else AT(8, 4); }
 #undef AT
   SFMI_CHECK_LAUNCH();

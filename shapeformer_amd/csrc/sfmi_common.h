@@ -80,8 +80,9 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 // sfmi_tune_set(name, value) (csrc/capi.hip) by bench.py / tools/ar_sweep.py; read at LAUNCH time, i.e. baked into a captured
 // hipGraph (re-capture after changing one).  Defaults = the product configuration.
 //   attn_blocks : 0 = one workgroup per (row, head) item of the decode attention; n > 0 = persistent grid of n workgroups
-//   attn_unroll : float4 loads in flight per lane (2, 4 or 8)
-//   attn_waves  : 16 or 8 waves per workgroup (NOT bit-identical to each other: different summation order)
+//   attn_unroll : float4 loads in flight per lane (2, 4 or 8; 8 or 16 with attn_waves = 4)
+//   attn_waves  : 16 or 8 waves per workgroup (NOT bit-identical to each other: different summation order); 4 = the light-occupancy
+//                 experiment of round 5 (a quarter of a CU's wave slots per two workgroups, profiles/r05_stream_power.md)
 //   attn_lds_pad: extra dynamic LDS bytes per attention workgroup (caps resident workgroups per CU)
 //   sdf_blocks  : cap of the SDF-query kernel's persistent grid (default 512 = two workgroups per CU; 256 leaves half of every
 //                 CU's registers free - the background-decode experiment of profiles/r03_ar_overlap.md)
