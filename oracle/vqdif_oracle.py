@@ -235,7 +235,7 @@ def trilinear_sample(grid, p):
 
     grid (B,C,D,H,W) [z][y][x]; p (B,N,3) in [-.5,.5] -> (B,N,C).
     """
-    u = normalize_3d(p)[:, :, None, None].float()
+    u = normalize_3d(p)[:, :, None, None].to(grid.dtype)
     v = 2.0 * u - 1.0
     c = F.grid_sample(grid, v, padding_mode="border", align_corners=True, mode="bilinear")
     return c.squeeze(-1).squeeze(-1).transpose(1, 2)
@@ -254,7 +254,7 @@ def sdf_query(sd, grid, Xtg, chunk=1 << 18):
     """LocalDecoder implicit part on a precomputed (B,32,64,64,64) grid; Xtg in [-1,1]."""
     outs = []
     for s in range(0, Xtg.shape[1], chunk):
-        p = (Xtg[:, s:s + chunk] / 2.0).float()
+        p = (Xtg[:, s:s + chunk] / 2.0).to(grid.dtype)
         outs.append(sdf_mlp(sd, p, trilinear_sample(grid, p)))
     return torch.cat(outs, dim=1)
 

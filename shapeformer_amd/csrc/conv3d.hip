@@ -41,14 +41,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
   constexpr int M_T = 64 * WN;
   constexpr int W_ROWS = (N_T * 4 + 255) / 256;  // weight float4 rows per thread
   constexpr int XT = XR ? 3 : 1;                 // weight tiles per chunk (taps along x; KS <= 3)
+  // 128 output channels with x reuse: three 128-row weight tiles per buffer.  Rows of 16 floats (no padding column; the 16-byte
+  // segment of a row is XOR-ed with bits 2-3 of the row index, so 16 consecutive rows still cover all 64 banks) keep the
+  // workgroup under 80 KB and two of them resident per CU.
+  constexpr bool SWZ = XR && N_T == 128;
+  constexpr int LS = SWZ ? 16 : LDS_STRIDE;
   static_assert(!(XR && UPS), "x reuse needs the direct addressing");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // XR: an x-row of Wo voxels occupies Wo + KS - 1 LDS rows: padL zero columns, the Wo real ones, padR zero columns
   const int xr_rw = XR ? a.Wo + a.KS - 1 : 0;
   const int xr_padl = XR ? (a.sp_on ? a.padx : a.pad) : 0;
-  const int AROWS = XR ? (M_T / a.Wo) * xr_rw : M_T;   // activation rows per LDS buffer
-  float* act_lds = lds;                              // [2][AROWS][LDS_STRIDE]
-  float* wgt_lds = lds + 2 * AROWS * LDS_STRIDE;     // [2][XT][N_T][LDS_STRIDE]
+  const int AROWS = XR ? (SWZ ? ((M_T / a.Wo) * xr_rw + 15) & ~15 : (M_T / a.Wo) * xr_rw) : M_T;   // activation rows per LDS buffer
+  float* act_lds = lds;                     // [2][AROWS][LS]   (SWZ: AROWS and N_T are multiples of 16, the swizzle needs only
+  float* wgt_lds = lds + 2 * AROWS * LS;    // [2][XT][N_T][LS]  the row index inside a buffer)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, pl = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
@@ -125,12 +130,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
   }
   if (XR) {   // the frame columns of both buffers are zero for the whole launch (nothing else writes them)
     const int nxr = M_T / a.Wo, fr = a.KS - 1;
-    for (int idx = tid; idx < 2 * nxr * fr * (LDS_STRIDE / 4); idx += 256) {
-      const int q4 = idx % (LDS_STRIDE / 4), r = idx / (LDS_STRIDE / 4);
+    for (int idx = tid; idx < 2 * nxr * fr * (LS / 4); idx += 256) {
+      const int q4 = idx % (LS / 4), r = idx / (LS / 4);
       const int f = r % fr, xrow = (r / fr) % nxr, S = r / (fr * nxr);
       const int lrow = xrow * xr_rw + (f < xr_padl ? f : a.Wo + f);
-      *reinterpret_cast<f32x4*>(act_lds + (S * AROWS + lrow) * LDS_STRIDE + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(act_lds + (S * AROWS + lrow) * LS + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  }
+  // column (in floats) of the 16-byte segment a thread stages / a lane reads; the reads of tap d are one row further per tap
+  int scol_a[WN], mcol[2][XT][2], wcol[2];
+  const int scol_w = 4 * (SWZ ? seg ^ ((srow >> 2) & 3) : seg);
+#pragma unroll
+  for (int i = 0; i < WN; ++i) scol_a[i] = 4 * (SWZ ? seg ^ ((srow_l[i] >> 2) & 3) : seg);
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    wcol[sub] = 4 * (SWZ ? (hi + 2 * sub) ^ ((pl >> 2) & 3) : hi + 2 * sub);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int d = 0; d < XT; ++d) mcol[j][d][sub] = 4 * (SWZ ? (hi + 2 * sub) ^ (((mrow_l[j] + d) >> 2) & 3) : hi + 2 * sub);
   }
 
   // two register sets: the global loads of chunk c+2 are issued while chunk c is multiplied (one set gave the loads only the
@@ -195,14 +213,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
       f32x4 v = ra[S][i];
       if (a.in_scale) v = v * rs[S] + rt[S];
       if (!((rok[S] >> i) & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(act_lds + ((S * AROWS) + srow_l[i]) * LDS_STRIDE + seg * 4) = v;
+      *reinterpret_cast<f32x4*>(act_lds + ((S * AROWS) + srow_l[i]) * LS + scol_a[i]) = v;
     }
 #pragma unroll
     for (int d = 0; d < XT; ++d)
 #pragma unroll
       for (int i = 0; i < W_ROWS; ++i) {
         const int row = srow + 64 * i;
-        if (row < N_T && d < a.KS) *reinterpret_cast<f32x4*>(wgt_lds + (((S * XT + d) * N_T) + row) * LDS_STRIDE + seg * 4) = rw[S][d * W_ROWS + i];
+        if (row < N_T && d < a.KS) *reinterpret_cast<f32x4*>(wgt_lds + (((S * XT + d) * N_T) + row) * LS + scol_w) = rw[S][d * W_ROWS + i];
       }
   };
 
@@ -213,20 +231,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
+  // ACC2 (the 128 x 64 x-reuse tile: UNet3D): blocked accumulation.  An MFMA chain over all K = 27 Cin products (3 456 .. 20 736 in
+  // UNet3D) rounds once per instruction and its error grows like sqrt(K): measured 0.9e-6 .. 2.4e-6 of the output's rms per layer
+  // against 3.5e-7 for the reference's CPU convolution, and the 10-layer stack with its GroupNorms carried that to 4e-5 rms at the
+  // logits - the end-to-end gate at 0.85 .. 1.14 of its width depending on the summation order.  Folding the running tile into a
+  // second accumulator every FOLD chunks (384 products) bounds the chain: 32 adds per 384 MFMAs.
+  constexpr bool ACC2 = XR && CO_TILES == 1 && WM == 2 && WN == 2;
+  constexpr int FOLD = 8;
+  f32x16 acc2[ACC2 ? CO_TILES : 1][2];
+  int fold_n = 0;
+  if (ACC2) {
+#pragma unroll
+    for (int i = 0; i < CO_TILES; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc2[i][j][t] = 0.0f;
+  }
+  auto fold = [&]() {
+#pragma unroll
+    for (int i = 0; i < (ACC2 ? CO_TILES : 0); ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { acc2[i][j][t] += acc[i][j][t]; acc[i][j][t] = 0.0f; }
+  };
 
   auto multiply = [&](const int S) {
 #pragma unroll
     for (int d = 0; d < XT; ++d) {
       if (d >= (XR ? a.KS : 1)) break;
-      const float* ab = act_lds + (S * AROWS + d) * LDS_STRIDE + 4 * hi;
-      const float* wb = wgt_lds + ((S * XT + d) * N_T + wm * CO_TILES * 32 + pl) * LDS_STRIDE + 4 * hi;
+      const float* ab = act_lds + (S * AROWS + d) * LS;
+      const float* wb = wgt_lds + ((S * XT + d) * N_T + wm * CO_TILES * 32 + pl) * LS;
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         f32x4 bf[2], af[CO_TILES];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(ab + mrow_l[j] * LDS_STRIDE + sub * 8);
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(ab + mrow_l[j] * LS + mcol[j][d][sub]);
 #pragma unroll
-        for (int i = 0; i < CO_TILES; ++i) af[i] = *reinterpret_cast<const f32x4*>(wb + i * 32 * LDS_STRIDE + sub * 8);
+        for (int i = 0; i < CO_TILES; ++i) af[i] = *reinterpret_cast<const f32x4*>(wb + i * 32 * LS + wcol[sub]);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -235,6 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
             for (int j = 0; j < 2; ++j) acc[i][j] = MFMA(af[i][q], bf[j][q], acc[i][j]);
       }
     }
+    if (ACC2 && ++fold_n == FOLD) { fold_n = 0; fold(); }
   };
   load_chunk(0);
   if (nchunks > 1) load_chunk(1);
@@ -249,6 +293,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
       if (c + 3 < nchunks) load_chunk(1);
       multiply(1);
     }
+  }
+  if (ACC2) {   // the last (partial) block, then the epilogue reads `acc`
+    fold();
+#pragma unroll
+    for (int i = 0; i < (ACC2 ? CO_TILES : 0); ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = acc2[i][j];
   }
 
   // epilogue: lane (voxel, hi) holds couts 8g+4hi+j of each co tile -> 4 float4 stores per tile
@@ -406,19 +457,41 @@ static int conv_dispatch(const ConvArgs& a, void* stream) {
   const int Cout = a.Cout;
   const long long M = (long long)a.B * a.Do * a.Ho * a.Wo;
   hipStream_t st = (hipStream_t)stream;
-  // x reuse (see the kernel): stride-1 k2 / k3 convolutions with same-size output whose 256-voxel tile is whole x-rows, for the
-  // 32- and 64-channel output tiles (the Upsampler's four layers; the 128-channel tiles amortise the staging over 4x the MFMAs and
-  // would lose their second resident workgroup to the three weight tiles)
-  const bool xr = g_sfmi_tune.conv_xreuse && a.stride == 1 && !a.up && (a.KS == 2 || a.KS == 3) && a.Wo == a.Wi && a.Ho == a.Hi &&
-                  a.Do == a.Di && 256 % a.Wo == 0 && (a.sp_on || 2 * a.pad == a.KS - 1) && Cout % 128 != 0;
+  // x reuse (see the kernel): stride-1 k2 / k3 convolutions with same-size output whose voxel tile is whole x-rows.  conv_xreuse 1:
+  // the 32- and 64-channel output tiles (the Upsampler's four layers); 2 (default): also UNet3D's layers (output channels a multiple
+  // of 128) on the 128 x 64 tile with blocked accumulation (ACC2 in the kernel); 3: those on the 128 x 128 swizzled-row tile instead
+  // where there are >= 512 of them (5 % faster, the un-blocked MFMA chain's rounding noise).
+  const bool xr_geom = g_sfmi_tune.conv_xreuse && a.stride == 1 && !a.up && (a.KS == 2 || a.KS == 3) && a.Wo == a.Wi && a.Ho == a.Hi &&
+                       a.Do == a.Di && (a.sp_on || 2 * a.pad == a.KS - 1);
+  const bool xr = xr_geom && 256 % a.Wo == 0 && Cout % 128 != 0;
   auto lds_bytes = [&](int M_T, int N_T, bool x) {
     const int arows = x ? (M_T / a.Wo) * (a.Wo + a.KS - 1) : M_T;
+    if (x && N_T == 128) return (size_t)(2 * ((arows + 15) & ~15) + 2 * 3 * N_T) * 16 * 4;
     return (size_t)(2 * arows + 2 * (x ? 3 : 1) * N_T) * LDS_STRIDE * 4;
   };
   if (Cout % 128 == 0) {
     constexpr int M_T = 128, N_T = 128;
-    dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
-    if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, true>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
+    const long long tiles = ((M + M_T - 1) / M_T) * (Cout / N_T);
+    const bool xr128 = xr_geom && g_sfmi_tune.conv_xreuse >= 2 && 128 % a.Wo == 0;
+    if ((tiles < 512 || (xr128 && g_sfmi_tune.conv_xreuse == 2)) && !a.up && g_sfmi_tune.conv_xreuse >= 2) {
+      // 128 x 64 tiles: the blocked-accumulation form; also what a coarse grid (4^3, 8^3 x 128 channels: fewer 128 x 128 tiles than
+      // the 512 workgroups the chip holds) takes in every mode
+      constexpr int N_H = 64;
+      dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_H)));
+      static const hipError_t attrh = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<1, 2, 2, false, true>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      if (xr128 && attrh == hipSuccess && lds_bytes(M_T, N_H, true) <= 80 * 1024)
+        hipLaunchKernelGGL((conv3d_igemm_kernel<1, 2, 2, false, true>), grid, dim3(256), lds_bytes(M_T, N_H, true), st, a);
+      else hipLaunchKernelGGL((conv3d_igemm_kernel<1, 2, 2, false>), grid, dim3(256), lds_bytes(M_T, N_H, false), st, a);
+      SFMI_CHECK_LAUNCH();
+      return SFMI_OK;
+    }
+    dim3 grid((unsigned)tiles);
+    static const hipError_t attr128 = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<2, 2, 2, false, true>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (xr128 && attr128 == hipSuccess && lds_bytes(M_T, N_T, true) <= 80 * 1024)
+      hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, false, true>), grid, dim3(256), lds_bytes(M_T, N_T, true), st, a);
+    else if (a.up) hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, true>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
     else hipLaunchKernelGGL((conv3d_igemm_kernel<2, 2, 2, false>), grid, dim3(256), lds_bytes(M_T, N_T, false), st, a);
   } else if (Cout % 64 == 0) {
     constexpr int M_T = 256, N_T = 64;

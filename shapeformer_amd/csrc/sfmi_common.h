@@ -91,9 +91,11 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   dgemm_nw    : k-parts (waves) per decode-GEMM workgroup: 0 = by shape (default), 4 / 8 / 16 where the K-slice allows it
 //   dgemm_un    : cap on the k16-steps of loads in flight per wave: 0 = by shape (8 / 4 / 2 / 2 / 2 / 1 for 1 .. 6 row tiles); can only lower it
 // sfmi_tune_generation() counts successful sfmi_tune_set calls: callers that cache captured hipGraphs key them on it.
-//   conv_xreuse : 1 (default) = stride-1 k2 / k3 convolutions with 32 / 64 output channels per tile stage each input row once per
-//                 (dz, dy) and reuse it for the taps along x; 0 = re-stage per tap (round 1-3 form).  NOT bit-identical to each other
-//                 (the taps are summed in another order: fp32 rounding only)
+//   conv_xreuse : stride-1 k2 / k3 convolutions stage each input row once per (dz, dy) and reuse it for the taps along x: 1 = with 32 / 64
+//                 output channels per tile (round 4 form); 2 (default) = also UNet3D's 128-multiple layers, on 128 x 64 tiles whose MFMA
+//                 chain is folded into a second accumulator every 384 products (3 x less rounding noise per layer than the plain
+//                 chain); 3 = those layers on 128 x 128 tiles with swizzled 16-float LDS rows (5 % faster, plain chain); 0 = re-stage
+//                 per tap (round 1-3 form).  The forms are NOT bit-identical to each other (summation order: fp32 rounding only)
 //   sk_grid     : workgroups of the work-balanced training GEMM (csrc/sgemm_sk.hip): 512 (default: two per CU) / 256 / 768 / 1024.  NOT
 //                 bit-identical to each other (a tile's K range is cut at other places: fp32 rounding only)
 //   sk_tile     : its workgroup tile: 0 = by output size (default), 1 = 64 x 64, 2 = 128 x 128 (same remark)

@@ -57,6 +57,20 @@ def test_vqdif16_oracle_vs_reference_vectors(vq16_sd_t):
     np.testing.assert_allclose(lg, z["logits"], atol=1e-4, rtol=1e-5)
 
 
+def test_float64_value_of_the_decoder_fixture_brackets_the_reference_output():
+    """tests/golden/vqdif16_small_f64.npz (oracle/make_f64_truth.py: the oracle's decoder evaluated in float64 on the fixture's codes) is
+    what the GPU test gates the HIP logits against at half the end-to-end gate.  Pinned here from the other side: the reference's own
+    fp32 logits (the committed fixture) lie within half that gate of it (measured 0.35), rms 1.3e-5."""
+    z = np.load(os.path.join(G, "vqdif16_small.npz"))
+    t = np.load(os.path.join(G, "vqdif16_small_f64.npz"))
+    ref, f64 = z["logits"].astype(np.float64), t["logits_f64"]
+    assert f64.dtype == np.float64 and f64.shape == ref.shape
+    d = np.abs(ref - f64)
+    assert (d <= 0.5 * (2e-4 + 1e-4 * np.abs(f64))).all()
+    assert np.sqrt((d ** 2).mean()) < 2e-5
+    assert abs(float(t["ref_dev_rms"]) - np.sqrt((d ** 2).mean())) < 1e-9
+
+
 def test_vqdif32_oracle_vs_reference_vectors():
     sd = VO.to_torch_sd(W.make_state_dict(W.vqdif_spec(32)))
     z = np.load(os.path.join(G, "vqdif32_small.npz"))

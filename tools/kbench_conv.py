@@ -9,7 +9,7 @@ from shapeformer_amd.vqdif import VQDIF
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--xreuse", type=int, default=1, help="conv_xreuse knob (csrc/conv3d.hip): 1 = stage once per (dz,dy), 0 = the round 1-3 form")
+ap.add_argument("--xreuse", type=int, default=2, help="conv_xreuse knob (csrc/conv3d.hip): 2 = x reuse for every tile width + 128 x 64 tiles on coarse grids, 1 = round-4 form (32 / 64 channels), 0 = per-tap staging")
 a = ap.parse_args()
 from shapeformer_amd import _lib as L
 L.check(L.lib().sfmi_tune_set(b"conv_xreuse", a.xreuse), "tune")
@@ -35,11 +35,12 @@ def conv_flops(y, x, cv, name, scale=None, shift=None, up=0, relu=True, bias=Non
     return 2.0 * y.numel() // cv.cout * cv.cout * cv.cin * taps
 
 
-vq._conv = timed(vq._conv, lambda x, cv, name, *r, **k: f"conv {name:16s} {tuple(x.shape[1:4])}x{cv.cin}->{cv.cout} k{cv.ks}" + (" up2" if k.get("up") else ""), conv_flops)
-vq._gn = timed(vq._gn, lambda x, g, b, name: f"gn   {name}", lambda *r, **k: 0.0)
-vq._pool = timed(vq._pool, lambda x, name: f"pool {name}", lambda *r, **k: 0.0)
-vq._upcat = timed(vq._upcat, lambda s, l, name: f"cat  {name}", lambda *r, **k: 0.0)
-vq._affine = timed(vq._affine, lambda x, sc, sh, name: f"aff  {name}", lambda *r, **k: 0.0)
+dec = vq.decoder            # the LocalDecoder sub-module owns the grid ops since round 5
+dec._conv = timed(dec._conv, lambda x, cv, name, *r, **k: f"conv {name:16s} {tuple(x.shape[1:4])}x{cv.cin}->{cv.cout} k{cv.ks}" + (" up2" if k.get("up") else ""), conv_flops)
+dec._gn = timed(dec._gn, lambda x, g, b, name: f"gn   {name}", lambda *r, **k: 0.0)
+dec._pool = timed(dec._pool, lambda x, name: f"pool {name}", lambda *r, **k: 0.0)
+dec._upcat = timed(dec._upcat, lambda s, l, name: f"cat  {name}", lambda *r, **k: 0.0)
+dec._affine = timed(dec._affine, lambda x, sc, sh, name: f"aff  {name}", lambda *r, **k: 0.0)
 for _ in range(2 + a.reps):
     vq.decoder_grid_cl(code)
 torch.cuda.synchronize()

@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 --pmc passes over tools/kbench_conv.py (UNet3D + up-sampler at 64 shapes): MFMA busy cycles and HBM-side bytes of the
-# conv3d_igemm_kernel instances (one counter group per pass, --kernel-trace only) -> gpurun_out/r4/pmc_conv.txt (or $PMC_OUT)
+# conv3d_igemm_kernel instances (one counter group per pass, --kernel-trace only) -> gpurun_out/r5/pmc_conv.txt (or $PMC_OUT)
 export TMPDIR=/tmp
 R=$PWD
-OUT=${PMC_OUT:-$R/gpurun_out/r4/pmc_conv.txt}
+OUT=${PMC_OUT:-$R/gpurun_out/r5/pmc_conv.txt}
 mkdir -p $(dirname $OUT); : > $OUT
 pass() {
   name=$1; ctr=$2; shift 2
