@@ -35,16 +35,20 @@ struct ConvArgs {
 // framed by its zero-padding columns - and multiplies them KS times at LDS row offsets 0 .. KS-1 against KS weight tiles.  One third
 // (one half for the 2^3 sub-pixel convolutions) of the global loads, LDS writes and barriers per MFMA of the plain form, which
 // re-stages the activation tile for every tap; with 32 or 64 output channels per workgroup that staging is what bounds the kernel.
-template <int CO_TILES, int WM, int WN, bool UPS, bool XR = false>
+// J = 32-voxel tiles per wave (2; 4 for the 32-channel x-reuse tile of 512 voxels: with 32 output channels a 256-voxel tile gives a wave
+// only 48 MFMAs between barriers and a workgroup 18 chunks over which to spread its voxel decode, first loads and epilogue).
+template <int CO_TILES, int WM, int WN, bool UPS, bool XR = false, int J = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES == 1 && !XR ? 3 : 2))) void conv3d_igemm_kernel(ConvArgs a) {
   constexpr int N_T = 32 * CO_TILES * WM;
-  constexpr int M_T = 64 * WN;
+  constexpr int M_T = 32 * J * WN;
+  constexpr int AP = M_T / 64;                   // activation float4 rows per thread (64 rows per pass of the 256 threads)
+  constexpr int NS = J == 4 ? 1 : 2;             // register sets of the global loads (J = 4: a chunk is long enough for one)
   constexpr int W_ROWS = (N_T * 4 + 255) / 256;  // weight float4 rows per thread
   constexpr int XT = XR ? 3 : 1;                 // weight tiles per chunk (taps along x; KS <= 3)
   // 128 output channels with x reuse: three 128-row weight tiles per buffer.  Rows of 16 floats (no padding column; the 16-byte
   // segment of a row is XOR-ed with bits 2-3 of the row index, so 16 consecutive rows still cover all 64 banks) keep the
   // workgroup under 80 KB and two of them resident per CU.
-  constexpr bool SWZ = XR && N_T == 128;
+  constexpr bool SWZ = XR && (N_T == 128 || J == 4);
   constexpr int LS = SWZ ? 16 : LDS_STRIDE;
   static_assert(!(XR && UPS), "x reuse needs the direct addressing");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -74,10 +78,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
   const int Dv = a.Di << a.up, Hv = a.Hi << a.up, Wv = a.Wi << a.up;
 
   // decode the output voxels this thread stages
-  int vb[WN], vz[WN], vy[WN], vx[WN];
-  bool vok[WN];
+  int vb[AP], vz[AP], vy[AP], vx[AP];
+  bool vok[AP];
 #pragma unroll
-  for (int i = 0; i < WN; ++i) {
+  for (int i = 0; i < AP; ++i) {
     long long m = m0 + srow + 64 * i;
     vok[i] = m < M;
     if (!vok[i]) m = M - 1;
@@ -96,10 +100,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
   // offset and three 3-bit per-axis validity masks are computed here; inside the loop the tap walks (dz,dy,dx,chunk) as
   // wave-uniform scalars and a voxel costs a shift-and-test plus one 64-bit add.  UPS (nearest-x2 folded into the address,
   // only the direct form of an up-sampling conv) keeps the general arithmetic.
-  long long vbase[WN];
-  int vmask[WN];
+  long long vbase[AP];
+  int vmask[AP];
 #pragma unroll
-  for (int i = 0; i < WN; ++i) {
+  for (int i = 0; i < AP; ++i) {
     int mk = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -110,22 +114,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
     vmask[i] = vok[i] ? mk : 0;
     vbase[i] = ((((long long)vb[i] * a.Di + vz[i]) * a.Hi + vy[i]) * a.Wi + vx[i]) * a.Cin + seg * 4;
   }
-  const bool one_b = (vb[0] == vb[WN - 1]);   // the tile lies inside one shape: its GroupNorm affine is loaded once per chunk
+  const bool one_b = (vb[0] == vb[AP - 1]);   // the tile lies inside one shape: its GroupNorm affine is loaded once per chunk
   long long wbase[W_ROWS];
 #pragma unroll
   for (int i = 0; i < W_ROWS; ++i) wbase[i] = (long long)(n0 + srow + 64 * i) * a.Cin + seg * 4;
   int t_dz = 0, t_dy = 0, t_dx = 0, t_cc = 0, t_tap = 0;   // wave-uniform walk over (tap, channel chunk)
 
   // LDS row of the voxel this thread stages / of the voxels this lane multiplies (XR: inside its framed x-row)
-  int srow_l[WN], mrow_l[2];
+  int srow_l[AP], mrow_l[J];
 #pragma unroll
-  for (int i = 0; i < WN; ++i) {
+  for (int i = 0; i < AP; ++i) {
     const int v = srow + 64 * i;
     srow_l[i] = XR ? (v / a.Wo) * xr_rw + xr_padl + v % a.Wo : v;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int v = wn * 64 + j * 32 + pl;
+  for (int j = 0; j < J; ++j) {
+    const int v = wn * 32 * J + j * 32 + pl;
     mrow_l[j] = XR ? (v / a.Wo) * xr_rw + v % a.Wo : v;      // tap dx reads row mrow_l + dx
   }
   if (XR) {   // the frame columns of both buffers are zero for the whole launch (nothing else writes them)
@@ -138,15 +142,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
     }
   }
   // column (in floats) of the 16-byte segment a thread stages / a lane reads; the reads of tap d are one row further per tap
-  int scol_a[WN], mcol[2][XT][2], wcol[2];
+  int scol_a[AP], mcol[J == 4 ? 1 : J][XT][2], wcol[2];   // (J = 4 computes the activation column at the read: registers)
   const int scol_w = 4 * (SWZ ? seg ^ ((srow >> 2) & 3) : seg);
 #pragma unroll
-  for (int i = 0; i < WN; ++i) scol_a[i] = 4 * (SWZ ? seg ^ ((srow_l[i] >> 2) & 3) : seg);
+  for (int i = 0; i < AP; ++i) scol_a[i] = 4 * (SWZ ? seg ^ ((srow_l[i] >> 2) & 3) : seg);
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
     wcol[sub] = 4 * (SWZ ? (hi + 2 * sub) ^ ((pl >> 2) & 3) : hi + 2 * sub);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < (J == 4 ? 1 : J); ++j)
 #pragma unroll
       for (int d = 0; d < XT; ++d) mcol[j][d][sub] = 4 * (SWZ ? (hi + 2 * sub) ^ (((mrow_l[j] + d) >> 2) & 3) : hi + 2 * sub);
   }
@@ -154,16 +158,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
   // two register sets: the global loads of chunk c+2 are issued while chunk c is multiplied (one set gave the loads only the
   // ~1000 MFMA cycles of a single chunk to land).  The GroupNorm affine and the zero padding are applied when a set is
   // written to LDS (x*scale+shift needs the loaded value: done at load time it would stall on the load it was meant to hide).
-  f32x4 ra[2][WN], rw[2][XT * W_ROWS], rs[2], rt[2];
-  int rok[2];
+  f32x4 ra[NS][AP], rw[NS][XT * W_ROWS], rs[NS], rt[NS];
+  int rok[NS];
   auto load_chunk = [&](const int S) {
     const int c0 = t_cc * KC + seg * 4;
     rs[S] = f32x4{1.f, 1.f, 1.f, 1.f};
     rt[S] = f32x4{0.f, 0.f, 0.f, 0.f};
     rok[S] = 0;
-    if (UPS || !one_b) {   // general arithmetic (address-folded up-sampling, tiles that straddle shapes): affine applied here
+    if (UPS || (!one_b && J != 4)) {   // (J = 4: the host launches it only where no tile straddles two shapes)  general arithmetic (address-folded up-sampling, tiles that straddle shapes): affine applied here
 #pragma unroll
-      for (int i = 0; i < WN; ++i) {
+      for (int i = 0; i < AP; ++i) {
         const int iz = vz[i] + t_dz, iy = vy[i] + t_dy, ix = vx[i] + (XR ? xr_padl : t_dx);   // XR: the voxel's own column
         const bool ok = vok[i] && iz >= 0 && iz < Dv && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
         rt[S] = *reinterpret_cast<const f32x4*>(a.in_shift + (long long)vb[0] * a.Cin + c0);
       }
 #pragma unroll
-      for (int i = 0; i < WN; ++i) {
+      for (int i = 0; i < AP; ++i) {
         const bool ok = XR ? (((vmask[i] >> t_dz) & (vmask[i] >> (3 + t_dy)) & 1) != 0 && vok[i])     // the own column is always inside
                            : (((vmask[i] >> t_dz) & (vmask[i] >> (3 + t_dy)) & (vmask[i] >> (6 + t_dx)) & 1) != 0);
         ra[S][i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? vbase[i] + toff : (long long)(seg * 4)));   // unconditional load
@@ -207,12 +211,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
       else { ++t_tap; if (++t_dx == a.KS) { t_dx = 0; if (++t_dy == a.KS) { t_dy = 0; ++t_dz; } } }
     }
   };
-  auto store_chunk = [&](const int S) {   // register set S -> LDS buffer S
+  auto store_chunk = [&](const int R, const int S) {   // register set R -> LDS buffer S
 #pragma unroll
-    for (int i = 0; i < WN; ++i) {
-      f32x4 v = ra[S][i];
-      if (a.in_scale) v = v * rs[S] + rt[S];
-      if (!((rok[S] >> i) & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < AP; ++i) {
+      f32x4 v = ra[R][i];
+      if (a.in_scale) v = v * rs[R] + rt[R];
+      if (!((rok[R] >> i) & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(act_lds + ((S * AROWS) + srow_l[i]) * LS + scol_a[i]) = v;
     }
 #pragma unroll
@@ -220,15 +224,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
 #pragma unroll
       for (int i = 0; i < W_ROWS; ++i) {
         const int row = srow + 64 * i;
-        if (row < N_T && d < a.KS) *reinterpret_cast<f32x4*>(wgt_lds + (((S * XT + d) * N_T) + row) * LS + scol_w) = rw[S][d * W_ROWS + i];
+        if (row < N_T && d < a.KS) *reinterpret_cast<f32x4*>(wgt_lds + (((S * XT + d) * N_T) + row) * LS + scol_w) = rw[R][d * W_ROWS + i];
       }
   };
 
-  f32x16 acc[CO_TILES][2];
+  f32x16 acc[CO_TILES][J];
 #pragma unroll
   for (int i = 0; i < CO_TILES; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < J; ++j)
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
   // ACC2 (the 128 x 64 x-reuse tile: UNet3D): blocked accumulation.  An MFMA chain over all K = 27 Cin products (3 456 .. 20 736 in
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
   // against 3.5e-7 for the reference's CPU convolution, and the 10-layer stack with its GroupNorms carried that to 4e-5 rms at the
   // logits - the end-to-end gate at 0.85 .. 1.14 of its width depending on the summation order.  Folding the running tile into a
   // second accumulator every FOLD chunks (384 products) bounds the chain: 32 adds per 384 MFMAs.
-  constexpr bool ACC2 = XR && CO_TILES == 1 && WM == 2 && WN == 2;
+  constexpr bool ACC2 = XR && CO_TILES == 1 && WM == 2 && WN == 2 && J == 2;
   constexpr int FOLD = 8;
   f32x16 acc2[ACC2 ? CO_TILES : 1][2];
   int fold_n = 0;
@@ -265,9 +269,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
       const float* wb = wgt_lds + ((S * XT + d) * N_T + wm * CO_TILES * 32 + pl) * LS;
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        f32x4 bf[2], af[CO_TILES];
+        f32x4 bf[J], af[CO_TILES];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(ab + mrow_l[j] * LS + mcol[j][d][sub]);
+        for (int j = 0; j < J; ++j) bf[j] = *reinterpret_cast<const f32x4*>(ab + mrow_l[j] * LS + (J == 4 ? 4 * ((hi + 2 * sub) ^ (((mrow_l[j] + d) >> 2) & 3)) : mcol[j][d][sub]));
 #pragma unroll
         for (int i = 0; i < CO_TILES; ++i) af[i] = *reinterpret_cast<const f32x4*>(wb + i * 32 * LS + wcol[sub]);
 #pragma unroll
@@ -275,22 +279,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
 #pragma unroll
           for (int i = 0; i < CO_TILES; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = MFMA(af[i][q], bf[j][q], acc[i][j]);
+            for (int j = 0; j < J; ++j) acc[i][j] = MFMA(af[i][q], bf[j][q], acc[i][j]);
       }
     }
     if (ACC2 && ++fold_n == FOLD) { fold_n = 0; fold(); }
   };
   load_chunk(0);
-  if (nchunks > 1) load_chunk(1);
+  if (NS == 2 && nchunks > 1) load_chunk(NS - 1);
   for (int c = 0; c < nchunks; c += 2) {
-    store_chunk(0);
+    store_chunk(0, 0);
     __syncthreads();
-    if (c + 2 < nchunks) load_chunk(0);
+    if (c + NS < nchunks) load_chunk(0);
     multiply(0);
     if (c + 1 < nchunks) {
-      store_chunk(1);
+      store_chunk(NS - 1, 1);
       __syncthreads();
-      if (c + 3 < nchunks) load_chunk(1);
+      if (c + 1 + NS < nchunks) load_chunk(NS - 1);
       multiply(1);
     }
   }
@@ -304,8 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
 
   // epilogue: lane (voxel, hi) holds couts 8g+4hi+j of each co tile -> 4 float4 stores per tile
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long long m_in = m0 + wn * 64 + j * 32 + pl;
+  for (int j = 0; j < J; ++j) {
+    const long long m_in = m0 + wn * 32 * J + j * 32 + pl;
     if (m_in >= M) continue;
     long long m = a.out_group ? (m_in / a.out_group) * a.out_group_stride + m_in % a.out_group : m_in;
     if (a.sp_on) {
@@ -466,7 +470,7 @@ static int conv_dispatch(const ConvArgs& a, void* stream) {
   const bool xr = xr_geom && 256 % a.Wo == 0 && Cout % 128 != 0;
   auto lds_bytes = [&](int M_T, int N_T, bool x) {
     const int arows = x ? (M_T / a.Wo) * (a.Wo + a.KS - 1) : M_T;
-    if (x && N_T == 128) return (size_t)(2 * ((arows + 15) & ~15) + 2 * 3 * N_T) * 16 * 4;
+    if (x && (N_T == 128 || M_T == 512)) return (size_t)(2 * ((arows + 15) & ~15) + 2 * 3 * N_T) * 16 * 4;   // the swizzled-row instances
     return (size_t)(2 * arows + 2 * (x ? 3 : 1) * N_T) * LDS_STRIDE * 4;
   };
   if (Cout % 128 == 0) {
@@ -507,6 +511,17 @@ static int conv_dispatch(const ConvArgs& a, void* stream) {
   } else {
     constexpr int M_T = 256, N_T = 32;
     dim3 grid((unsigned)(((M + M_T - 1) / M_T) * (Cout / N_T)));
+    // 512-voxel tiles (four 32-voxel tiles per wave) where the grid is wide enough for their framed rows to fit twice per CU
+    // (Wo >= 32) and there are enough of them to fill the chip; conv_xreuse 1 keeps the round-4 256-voxel tile
+    static const hipError_t attr32w = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<1, 1, 4, false, true, 4>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (xr && g_sfmi_tune.conv_xreuse >= 2 && attr32w == hipSuccess && 512 % a.Wo == 0 && lds_bytes(512, N_T, true) <= 80 * 1024 &&
+        ((long long)a.Do * a.Ho * a.Wo) % 512 == 0 && (M / 512) * (Cout / N_T) >= 1024) {
+      dim3 gridw((unsigned)(((M + 511) / 512) * (Cout / N_T)));
+      hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, false, true, 4>), gridw, dim3(256), lds_bytes(512, N_T, true), st, a);
+      SFMI_CHECK_LAUNCH();
+      return SFMI_OK;
+    }
     static const hipError_t attr32 = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<1, 1, 4, false, true>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (xr && attr32 == hipSuccess && lds_bytes(M_T, N_T, true) <= 96 * 1024)      // Wo == 1 needs 138 KB: per-tap form

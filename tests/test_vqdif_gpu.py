@@ -243,7 +243,9 @@ def test_conv_x_reuse_form_and_subpixel_upsampling_conv_vs_torch(dev):
     # 128 / 256 / 512 output channels: >= 512 tiles of 128 x 128 take the swizzled x-reuse instance (Wo = 16 inside a shape, Wo = 4 with
     # two shapes per tile), fewer take the 128 x 64 tile (a last tile half full, Wo = 2 frames)
     for (Cin, Cout, D, B) in [(32, 32, 16, 2), (64, 64, 8, 3), (32, 64, 4, 5), (16, 32, 64, 1), (64, 32, 32, 1), (32, 64, 2, 3), (32, 32, 1, 4),
-                              (16, 128, 16, 17), (16, 512, 4, 257), (32, 128, 8, 3), (16, 256, 4, 5), (16, 128, 2, 3)]:
+                              (16, 128, 16, 17), (16, 512, 4, 257), (32, 128, 8, 3), (16, 256, 4, 5), (16, 128, 2, 3),
+                              # >= 1024 tiles of 512 voxels x 32 channels (Wo = 64 and 32): the four-tiles-per-wave instance
+                              (16, 32, 64, 2), (16, 32, 32, 16)]:
         x = torch.randn(B, Cin, D, D, D, generator=g)
         w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5
         bias = torch.randn(Cout, generator=g)
@@ -265,7 +267,7 @@ def test_conv_x_reuse_form_and_subpixel_upsampling_conv_vs_torch(dev):
         torch.testing.assert_close(yx, y0, atol=2e-5, rtol=1e-5)
         torch.testing.assert_close(y3, y0, atol=2e-5, rtol=1e-5)
         # the up-sampling convolution of the same tensors: conv3(nearest_x2(affine(x))) by the sub-pixel decomposition
-        if D <= 16:
+        if D <= 16 or (D == 32 and B == 16):
             refu = F.relu(F.conv3d(F.interpolate(xin, scale_factor=2, mode="nearest"), w, bias, stride=1, padding=1))
             ws = np.empty(64 * Cout * Cin, np.float32)
             L.check(lib.sfmi_conv_pack_weight_subpixel(np.ascontiguousarray(w.numpy()).ctypes.data, Cout, Cin, ws.ctypes.data), "pack_subpixel")
