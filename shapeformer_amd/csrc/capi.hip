@@ -2,7 +2,7 @@
 #include "sfmi_common.h"
 #include <string>
 
-SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512, 1, 0, 0, 2, 512, 0, 0, 0};
+SfmiTune g_sfmi_tune = {0, 4, 16, 0, 512, 1, 0, 0, 2, 512, 0, 0, 0, 1};
 static int g_sfmi_tune_generation = 0;
 
 // One wavefront that waits `ticks` of the constant 100 MHz wall clock: the probe `shapeformer_amd/gpt.py:_chain_streams` uses to
@@ -28,6 +28,7 @@ int sfmi_tune_set(const char* name, int value) {
   else if (n == "dgemm_nw" && (value == 0 || value == 4 || value == 8 || value == 16)) t.dgemm_nw = value;
   else if (n == "dgemm_un" && value >= 0 && value <= 8) t.dgemm_un = value;
   else if (n == "conv_xreuse" && value >= 0 && value <= 3) t.conv_xreuse = value;
+  else if (n == "enc_fused" && (value == 0 || value == 1)) t.enc_fused = value;
   else if (n == "sk_grid" && value >= 256 && value <= 1024 && value % 256 == 0) t.sk_grid = value;
   else if (n == "sk_tile" && value >= 0 && value <= 2) t.sk_tile = value;
   else if (n == "sk_loop" && value >= 0 && value <= 1) t.sk_loop = value;
@@ -49,6 +50,7 @@ int sfmi_tune_get(const char* name) {
   if (n == "dgemm_nw") return t.dgemm_nw;
   if (n == "dgemm_un") return t.dgemm_un;
   if (n == "conv_xreuse") return t.conv_xreuse;
+  if (n == "enc_fused") return t.enc_fused;
   if (n == "sk_grid") return t.sk_grid;
   if (n == "sk_tile") return t.sk_tile;
   if (n == "sk_loop") return t.sk_loop;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void enc_scan_sums_kernel(const int* __restri
   }
 }
 __global__ __launch_bounds__(1024) void enc_scan_apply_kernel(int* __restrict__ start /*in: counts*/, int* __restrict__ cursor,
-                                                              const int* __restrict__ chunk_sum) {
+                                                              const int* __restrict__ chunk_sum, int* __restrict__ flag, int limit) {
   __shared__ int wsum[16];
   __shared__ int s_base;
   const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(1024) void enc_scan_apply_kernel(int* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane == 0) s_base = c;
   }
+  // a cell with more points than the fused stage kernel's workgroups can hold: the staged kernels take the call (see enc_fused_kernel)
+  if (__any(max(max(v.x, v.y), max(v.z, v.w)) > limit) && lane == 0) { atomicOr(flag, 1); atomicOr(flag + 1 + b, 1); }
   const int tot = (v.x + v.y) + (v.z + v.w);
   int incl = tot;
 #pragma unroll
@@ -164,7 +166,9 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
     int* __restrict__ segmax_out,         // (B,T,32) pre-filled 0x80808080
     long long* __restrict__ csum,         // (B,T,32) pre-zeroed   (STAGE 4)
     int* __restrict__ ccount,             // (B,T)    pre-zeroed   (STAGE 4)
-    const float* __restrict__ wpack, int B, int T) {
+    const float* __restrict__ wpack, int B, int T,
+    const int* __restrict__ run_flag) {   // optional: [0] any shape, [1 + b] shape b was declined by the fused kernel - only those run
+  if (run_flag && !run_flag[0]) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // stage weights: block STAGE (+ fc_pos for 0, + fc_c for 4)
   {
@@ -192,9 +196,10 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
 
   for (long long tile = wave_gid; tile < ntiles; tile += nwaves) {
     long long i = tile * 32 + pl;
-    const bool valid = i < total;
+    bool valid = i < total;
     if (!valid) i = total - 1;
     const int b = (int)(i / T);
+    if (run_flag && !run_flag[1 + b]) valid = false;
     // segment = sorted position of the cell's first point (b*T + start[cell] < 2^31); for the run tests a lane that is not
     // valid gets a segment of its own
     const int segi = (int)((long long)b * T) + rep[(long long)b * ENC_G * ENC_G * ENC_G + cell[i]];
@@ -319,6 +324,209 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// E1..E5 in ONE launch (round 5): run-aligned workgroups.
+// The only dependency between the five stages is the local max pool, and a pool never leaves its cell.  A workgroup that owns
+// WHOLE cells can therefore walk all five stages by itself: the running features of its points stay in registers (two 32-point
+// tiles per wave, eight waves), the pooled maxima of its cells live in 64 KB of LDS (one row per sorted position, named like the global
+// segments: the cell's first point), a stage's weights are staged per stage, and three workgroup barriers per stage replace the
+// launch boundary.  Nothing but the cloud is read from HBM and nothing but the per-cell sums written: the four (B,T,32) feature
+// round trips, the four pooled-maxima buffers and their 0x80 fills of the staged form are gone.
+// Ownership: workgroup w of a shape takes the runs that START in sorted positions [w * EF_NOM, (w + 1) * EF_NOM) - it skips the
+// tail of a run begun before and finishes the run that straddles its end - which holds at most EF_NOM + EF_LIMIT - 1 <= EF_CAP
+// points if no cell has more than EF_LIMIT = 128 of them (the bench's synthetic partial clouds: 34 .. 52).  The scan kernel raises
+// flag[1 + shape] (and flag[0]) when one does: this kernel then skips the shape and the staged kernels, launched behind it with the
+// opposite test, take it - no host round trip either way.  Per point the arithmetic is the staged form's, instruction for instruction (an MFMA column depends on its
+// own point only), the pool is an integer max and the mean a fixed-point sum: the two forms are BIT-IDENTICAL.
+// ---------------------------------------------------------------------------------------------
+constexpr int EF_CAP = 512, EF_LIMIT = 128, EF_NOM = EF_CAP - EF_LIMIT, EF_NT = 2, EF_THREADS = EF_CAP / (32 * EF_NT) * 64;
+constexpr int EF_W_FLOATS = ENC_BLK_FLOATS + 1056;      // stage weights (+ fc_pos or fc_c)
+// row stride of the pooled maxima (ints) and of the fixed-point sums (64-bit words): 32 channels + 4 of padding.  With 32 the points of
+// a tile - a handful of different cells - fell on two banks per channel and every LDS atomic was a 16-way bank conflict.
+constexpr int EF_ROW = 36;
+
+struct EfTile {
+  int i;          // global sorted position b * T + pos (clamped for invalid lanes)
+  int seg_l;      // sorted position of the cell's first point relative to the workgroup's first point: row of the LDS pooled maxima
+  bool valid;
+};
+
+// The pools are LDS atomics, one per point and channel (ds_max_i32 on the cell's row; the points of a cell collide and are
+// serialised by the LDS - a few cycles): the first version carried the staged kernels' segmented wavefront scans over, 80
+// ds_bpermute per tile and stage each waited for on its own, and spent more time in them than in its MFMAs.
+template <int STAGE>
+__device__ __forceinline__ void ef_stage(float* __restrict__ lds, int* __restrict__ lsm, const float* __restrict__ wpack,
+                                         const float* __restrict__ cloud, const int* __restrict__ order, long long bT,
+                                         f32x16 (&net)[EF_NT], const EfTile (&ts)[EF_NT]) {
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  __syncthreads();                      // every wave is done with the previous stage: its weights, its pooled maxima are final
+  f32x16 xhi[EF_NT];
+  if (STAGE > 0) {
+#pragma unroll
+    for (int k = 0; k < EF_NT; ++k) {
+      const int4* sp = reinterpret_cast<const int4*>(lsm + ts[k].seg_l * EF_ROW + 4 * hi);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int4 q = sp[2 * g];
+        xhi[k][4 * g + 0] = fkey_inv(q.x); xhi[k][4 * g + 1] = fkey_inv(q.y);
+        xhi[k][4 * g + 2] = fkey_inv(q.z); xhi[k][4 * g + 3] = fkey_inv(q.w);
+      }
+    }
+  }
+  {
+    const f32x4* s = reinterpret_cast<const f32x4*>(wpack + ENC_OFF_BLK(STAGE));
+    f32x4* d = reinterpret_cast<f32x4*>(lds);
+    for (int i = tid; i < ENC_BLK_FLOATS / 4; i += EF_THREADS) d[i] = s[i];
+    if (STAGE == 0 || STAGE == 4) {
+      const f32x4* s2 = reinterpret_cast<const f32x4*>(wpack + (STAGE == 0 ? ENC_OFF_FCPOS : ENC_OFF_FCC));
+      f32x4* d2 = reinterpret_cast<f32x4*>(lds + ENC_BLK_FLOATS);
+      for (int i = tid; i < (STAGE == 0 ? 256 : 1056) / 4; i += EF_THREADS) d2[i] = s2[i];
+    }
+  }
+  __syncthreads();                      // the pooled maxima of the previous stage are in registers: their rows can be re-armed
+  if (STAGE < 4) {
+    int4* r = reinterpret_cast<int4*>(lsm + tid * EF_ROW);    // EF_CAP rows, one per thread
+    const int e = (int)0x80808080;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) r[g] = int4{e, e, e, e};
+    __syncthreads();
+  }
+  const f32x4* L = reinterpret_cast<const f32x4*>(lds) + lane;
+#pragma unroll
+  for (int k = 0; k < EF_NT; ++k) {
+    const EfTile& t = ts[k];
+    f32x16 xlo, xh;
+    if (STAGE == 0) {
+      const float* p = cloud + (bT + order[t.i]) * 3;
+      const float hx = p[0] * 0.5f, hy = p[1] * 0.5f, hz = p[2] * 0.5f;  // vqdif.py:36 Xbd/2
+      const float* fp = lds + ENC_BLK_FLOATS;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { xlo[q] = 0.0f; xh[q] = 0.0f; }
+      xlo = MFMA(fp[lane], hi ? hy : hx, xlo);
+      xlo = MFMA(fp[64 + lane], hi ? 1.0f : hz, xlo);
+      xh = MFMA(fp[128 + lane], hi ? hy : hx, xh);
+      xh = MFMA(fp[192 + lane], hi ? 1.0f : hz, xh);
+    } else {
+      xlo = net[k]; xh = xhi[k];
+    }
+    f32x16 h, o;
+    bias_init(lds + 5 * 1024, hi, h);
+    layer32<true>(L + 0 * 256, xlo, h);
+    layer32<true>(L + 1 * 256, xh, h);
+    bias_init(lds + 5 * 1024 + 32, hi, o);
+    layer32<false>(L + 2 * 256, xlo, o);
+    layer32<false>(L + 3 * 256, xh, o);
+    layer32<true>(L + 4 * 256, h, o);
+    if (STAGE < 4) {
+      net[k] = o;
+      if (t.valid) {           // local max pool (enc.py:95-112)
+        int* sm = lsm + t.seg_l * EF_ROW + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicMax(sm + 8 * g + j, fkey(o[4 * g + j]));
+      }
+    } else {
+      // c = fc_c(net) (enc.py:133), kept for the mean below
+      f32x16 c;
+      bias_init(lds + ENC_BLK_FLOATS + 1024, hi, c);
+      layer32<false>(reinterpret_cast<const f32x4*>(lds + ENC_BLK_FLOATS) + lane, o, c);
+      net[k] = c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(EF_THREADS) void enc_fused_kernel(const float* __restrict__ cloud, const int* __restrict__ scell,
+                                                               const int* __restrict__ start, const int* __restrict__ cend,
+                                                               const int* __restrict__ order, long long* __restrict__ csum,
+                                                               int* __restrict__ ccount, const float* __restrict__ wpack,
+                                                               const int* __restrict__ flag, int T) {
+  if (flag[1 + blockIdx.y]) return;     // a cell of this shape holds more than EF_LIMIT points: the staged kernels take the shape
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* lsm = reinterpret_cast<int*>(lds + EF_W_FLOATS);       // [EF_CAP][EF_ROW] pooled maxima (ordered-int keys)
+  __shared__ int s_rng[2];
+  __shared__ int s_cnt[EF_CAP / 2];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pl = lane & 31, hi = lane >> 5;
+  constexpr long long NC = (long long)ENC_G * ENC_G * ENC_G;
+  const int* sc = scell + (long long)b * T;
+  const int* st = start + b * NC;
+  if (tid == 0) {
+    int p0 = blockIdx.x * EF_NOM, p1 = min(T, p0 + EF_NOM);
+    if (p0 < T && p0 > 0) { const int c = sc[p0]; if (st[c] < p0) p0 = cend[b * NC + c]; }   // the tail of a run begun before: its owner's
+    if (p1 < T) { const int c = sc[p1]; if (st[c] < p1) p1 = cend[b * NC + c]; }             // the run that straddles the end: finished here
+    s_rng[0] = p0; s_rng[1] = max(p0, p1);
+  }
+  __syncthreads();
+  const int p0 = s_rng[0], n = s_rng[1] - p0;
+  if (n <= 0) return;
+  EfTile ts[EF_NT];
+#pragma unroll
+  for (int k = 0; k < EF_NT; ++k) {
+    const int tl = (wave * EF_NT + k) * 32;       // the tile's first point, relative to p0
+    EfTile& t = ts[k];
+    t.valid = tl + pl < n;
+    const int pos = p0 + (t.valid ? tl + pl : n - 1);
+    t.i = b * T + pos;
+    t.seg_l = st[sc[pos]] - p0;                   // sorted position of the cell's first point
+  }
+  f32x16 net[EF_NT];
+  const long long bT = (long long)b * T;
+  ef_stage<0>(lds, lsm, wpack, cloud, order, bT, net, ts);
+  ef_stage<1>(lds, lsm, wpack, cloud, order, bT, net, ts);
+  ef_stage<2>(lds, lsm, wpack, cloud, order, bT, net, ts);
+  ef_stage<3>(lds, lsm, wpack, cloud, order, bT, net, ts);
+  ef_stage<4>(lds, lsm, wpack, cloud, order, bT, net, ts);     // net = c = fc_c(net)
+  // scatter_mean numerator (enc.py:70-74): per-cell sums in 2^-32 fixed point (associative: any order gives the same bits) and
+  // point counts, accumulated with LDS atomics in the pooled-maxima region - as 64-bit words it holds half of the rows, so the
+  // cells that start in the first and in the second 256 positions take turns - and written out as whole rows: the fused form
+  // needs neither global atomics nor zeroed sums.
+  unsigned long long* lsum = reinterpret_cast<unsigned long long*>(lsm);      // [EF_CAP / 2][EF_ROW]
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (half * (EF_CAP / 2) >= n) break;
+    __syncthreads();                    // the region's previous users are done (pooled maxima read at the top of stage 4; the other half's rows written out)
+    {
+      int4* r = reinterpret_cast<int4*>(lsm + tid * EF_ROW);     // as ints: the whole region, i.e. all EF_CAP / 2 rows of 64-bit words
+#pragma unroll
+      for (int g = 0; g < EF_ROW / 4; ++g) r[g] = int4{0, 0, 0, 0};
+      if (tid < EF_CAP / 2) s_cnt[tid] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EF_NT; ++k) {
+      const EfTile& t = ts[k];
+      if (t.valid && (t.seg_l >> 8) == half) {
+        const int row = t.seg_l & (EF_CAP / 2 - 1);
+        unsigned long long* sp = lsum + row * EF_ROW + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(sp + 8 * g + j, (unsigned long long)__double2ll_rn((double)net[k][4 * g + j] * 4294967296.0));
+        if (hi == 0) atomicAdd(s_cnt + row, 1);
+      }
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 1, part = tid & 1, cnt = s_cnt[row];
+      if (cnt > 0) {                    // a cell starts at this position
+        const long long seg = bT + p0 + half * (EF_CAP / 2) + row;
+        const longlong2* src = reinterpret_cast<const longlong2*>(lsum + row * EF_ROW + part * 16);
+        longlong2* dst = reinterpret_cast<longlong2*>(csum + seg * 32 + part * 16);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) dst[g] = src[g];
+        if (part == 0) ccount[seg] = cnt;
+      }
+    }
+  }
+}
+
+// fill of a staged-form buffer (0x80808080: pooled maxima; 0: the per-cell sums its atomics add into), skipped when the fused kernel
+// took every shape of the call
+__global__ void enc_fill_kernel(int4* __restrict__ p, long long n4, const int* __restrict__ flag, int e) {
+  if (flag && !*flag) return;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) p[i] = int4{e, e, e, e};
 }
 
 // E6: write the per-cell means into the dense channels-last (B,G,G,G,32) grid (pre-zeroed).
@@ -467,7 +675,7 @@ int sfmi_enc_pack_weights(const float* fc_pos_w /*64x3*/, const float* fc_pos_b 
 size_t sfmi_enc_workspace_bytes(int B, int T) {
   size_t bt = (size_t)B * T;
   // cell + order + sorted cell (3 x 4) + start map + cursor map + 2 net buffers + 2 segmax buffers + csum + ccount + scan chunk sums
-  return bt * 12 + 2 * (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + (size_t)B * 64 * 4 + 65536 + 1024;
+  return bt * 12 + 2 * (size_t)B * ENC_G * ENC_G * ENC_G * 4 + 2 * bt * 128 + 2 * bt * 128 + bt * 256 + bt * 4 + 256 + (((size_t)B + 1) * 4 + 255) + 256 + (size_t)B * 64 * 4 + 65536 + 1024;
 }
 
 static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, unsigned char* mask, int* cell_out, void* workspace, int B, int T,
@@ -508,40 +716,61 @@ static int enc_pipeline(const float* cloud, const float* wpack, float* grid_cl, 
   float* net[2]; net[0] = (float*)w; w += bt * 128; net[1] = (float*)w; w += bt * 128;
   int* sm[2]; sm[0] = (int*)w; w += bt * 128; sm[1] = (int*)w; w += bt * 128;
   long long* csum = (long long*)w; w += bt * 256;
-  int* ccount = (int*)w; w += bt * 4;
+  const size_t cc_bytes = (bt * 4 + 255) & ~(size_t)255;
+  int* ccount = (int*)w; w += cc_bytes;
+  const size_t flag_bytes = (((size_t)B + 1) * 4 + 255) & ~(size_t)255;
+  int* flag = (int*)w; w += flag_bytes;                  // [0] any shape / [1 + b] shape b: a cell holds more than EF_LIMIT points (zeroed with csum / ccount)
   int* chunk_sum = (int*)w; w += (size_t)B * 64 * 4;     // (B, 64) chunk totals of the cell-count scan
   w = (char*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
   float* down_wt = (float*)w;    // [8][32][64] transposed copy of the first Downsampler convolution's weights (64 KB)
   hipMemsetAsync(start, 0, nc * 4, st);
   hipMemsetAsync(mask, 0, (size_t)B * R * R * R, st);
-  hipMemsetAsync(csum, 0, bt * 256 + bt * 4, st);
+  // per-cell sums and counts: the fused kernel writes whole rows, only the staged kernels' atomics need them zeroed (conditional fill below)
+  hipMemsetAsync(flag, 0, flag_bytes, st);
   if (grid_cl) hipMemsetAsync(grid_cl, 0, nc * 32 * 4, st);
   int nb = (int)((bt + 255) / 256);
+  // the five stages in one launch (enc_fused_kernel) unless a debug tap wants the per-stage buffers or the knob says otherwise;
+  // limit < 0 makes the scan raise the flag unconditionally
+  const bool fused = g_sfmi_tune.enc_fused && !tap_stage1 && !tap_stage4c;
   // group the points of every shape by cell: histogram -> exclusive scan -> scatter (2 integer atomics per point)
   hipLaunchKernelGGL(enc_cells_kernel, dim3(nb), dim3(256), 0, st, cloud, cell, start, mask, B, T, R);
   hipLaunchKernelGGL(enc_scan_sums_kernel, dim3(ENC_NCH, B), dim3(1024), 0, st, start, chunk_sum);
-  hipLaunchKernelGGL(enc_scan_apply_kernel, dim3(ENC_NCH, B), dim3(1024), 0, st, start, cursor, chunk_sum);
+  hipLaunchKernelGGL(enc_scan_apply_kernel, dim3(ENC_NCH, B), dim3(1024), 0, st, start, cursor, chunk_sum, flag, fused ? EF_LIMIT : -1);
   hipLaunchKernelGGL(enc_scatter_kernel, dim3(nb), dim3(256), 0, st, cell, cursor, order, scell, B, T);
+  // (before the fused kernel: it writes rows of the shapes it takes)
+  hipLaunchKernelGGL(enc_fill_kernel, dim3(2048), dim3(256), 0, st, (int4*)csum, (long long)((bt * 256 + cc_bytes) / 16), fused ? flag : nullptr, 0);
+  if (fused) {
+    constexpr size_t ef_lds = (size_t)(EF_W_FLOATS + EF_CAP * EF_ROW) * 4;   // 98.7 KB: one workgroup of eight waves per CU
+    static const hipError_t attr = hipFuncSetAttribute((const void*)enc_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ef_lds);
+    if (attr != hipSuccess) return SFMI_ELDS;
+    hipLaunchKernelGGL(enc_fused_kernel, dim3((T + EF_NOM - 1) / EF_NOM, B), dim3(EF_THREADS), ef_lds, st, cloud, scell, start, cursor, order,
+                       csum, ccount, wpack, flag, T);
+  }
+  // the staged form: one launch per stage (the pool between stages as a global dependency).  With the fused kernel ahead of them
+  // these launches test the flag and return (4.5 us each, measured) unless it declined a shape.
+  const int* rf = fused ? flag : nullptr;
   const long long tiles = (long long)(bt + 31) / 32;
   int grid = (int)((tiles + 3) / 4);
   if (grid > 2048) grid = 2048;
   const size_t lds0 = (ENC_BLK_FLOATS + 256) * 4, ldsk = ENC_BLK_FLOATS * 4, lds4 = (ENC_BLK_FLOATS + 1056) * 4;
-  hipMemsetAsync(sm[0], 0x80, bt * 128, st);
+  const long long n4 = (long long)bt * 8;       // int4s of a (B,T,32) pooled-maxima buffer
+  const int e80 = (int)0x80808080;
+  hipLaunchKernelGGL(enc_fill_kernel, dim3(2048), dim3(256), 0, st, (int4*)sm[0], n4, rf, e80);
   hipLaunchKernelGGL(enc_block_kernel<0>, dim3(grid), dim3(256), lds0, st, cloud, scell, start, order, nullptr, nullptr, net[0],
-                     sm[0], nullptr, nullptr, wpack, B, T);
-  hipMemsetAsync(sm[1], 0x80, bt * 128, st);
+                     sm[0], nullptr, nullptr, wpack, B, T, rf);
+  hipLaunchKernelGGL(enc_fill_kernel, dim3(2048), dim3(256), 0, st, (int4*)sm[1], n4, rf, e80);
   hipLaunchKernelGGL(enc_block_kernel<1>, dim3(grid), dim3(256), ldsk, st, cloud, scell, start, order, net[0], sm[0], net[1],
-                     sm[1], nullptr, nullptr, wpack, B, T);
+                     sm[1], nullptr, nullptr, wpack, B, T, rf);
   if (tap_stage1)
     hipLaunchKernelGGL(enc_unsort_kernel, dim3((unsigned)((bt * 32 + 255) / 256)), dim3(256), 0, st, net[1], order, tap_stage1, B, T, 32);
-  hipMemsetAsync(sm[0], 0x80, bt * 128, st);
+  hipLaunchKernelGGL(enc_fill_kernel, dim3(2048), dim3(256), 0, st, (int4*)sm[0], n4, rf, e80);
   hipLaunchKernelGGL(enc_block_kernel<2>, dim3(grid), dim3(256), ldsk, st, cloud, scell, start, order, net[1], sm[1], net[0],
-                     sm[0], nullptr, nullptr, wpack, B, T);
-  hipMemsetAsync(sm[1], 0x80, bt * 128, st);
+                     sm[0], nullptr, nullptr, wpack, B, T, rf);
+  hipLaunchKernelGGL(enc_fill_kernel, dim3(2048), dim3(256), 0, st, (int4*)sm[1], n4, rf, e80);
   hipLaunchKernelGGL(enc_block_kernel<3>, dim3(grid), dim3(256), ldsk, st, cloud, scell, start, order, net[0], sm[0], net[1],
-                     sm[1], nullptr, nullptr, wpack, B, T);
+                     sm[1], nullptr, nullptr, wpack, B, T, rf);
   hipLaunchKernelGGL(enc_block_kernel<4>, dim3(grid), dim3(256), lds4, st, cloud, scell, start, order, net[1], sm[1], tap_stage4c,
-                     nullptr, csum, ccount, wpack, B, T);
+                     nullptr, csum, ccount, wpack, B, T, rf);
   long long nthr = (long long)bt * 32;
   if (grid_cl)
     hipLaunchKernelGGL(enc_grid_mean_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, scell, start, csum,

@@ -101,5 +101,7 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   sk_tile     : its workgroup tile: 0 = by output size (default), 1 = 64 x 64, 2 = 128 x 128 (same remark)
 //   sk_loop     : chunk loop of its 64 x 64 form: 0 = store / barrier / load / read / MFMA (default), 1 = pipelined + interleaved (bit-identical)
 //   sk_stagger  : experiment: the second resident workgroup of a CU starts `sk_stagger` x 256 cycles late (0 = off; bit-identical)
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse, sk_grid, sk_tile, sk_loop, sk_stagger; };
+//   enc_fused   : 1 (default) = the five per-point stages of the local-pool encoder in one launch (run-aligned workgroups, csrc/encoder.hip
+//                 enc_fused_kernel); 0 = one launch per stage (round 1-4 form).  Bit-identical to each other.
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse, sk_grid, sk_tile, sk_loop, sk_stagger, enc_fused; };
 extern SfmiTune g_sfmi_tune;

@@ -5,9 +5,15 @@ import torch
 from shapeformer_amd import _lib as L, synthetic
 from shapeformer_amd.vqdif import VQDIF
 from bench import ev_time
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--fused", type=int, default=1, help="enc_fused knob (csrc/encoder.hip): 1 = the five stages in one launch, 0 = one launch per stage")
+a = ap.parse_args()
 dev = torch.device("cuda:0")
 vq = VQDIF(res=16, device=dev)
 lib = L.lib()
+L.check(lib.sfmi_tune_set(b"enc_fused", a.fused), "tune")
+print(f"enc_fused = {a.fused}")
 for B, T in ((64, 16384), (32, 32768), (8, 16384)):
     X = torch.from_numpy(synthetic.make_batch(99, B, n_partial=T, n_full=T)["Xct" if T == 16384 else "Xbd"]).to(dev)
     ws = torch.empty(lib.sfmi_enc_workspace_bytes(B, T), device=dev, dtype=torch.uint8)
