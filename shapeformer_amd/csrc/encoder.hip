@@ -329,19 +329,24 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
 // ---------------------------------------------------------------------------------------------
 // E1..E5 in ONE launch (round 5): run-aligned workgroups.
 // The only dependency between the five stages is the local max pool, and a pool never leaves its cell.  A workgroup that owns
-// WHOLE cells can therefore walk all five stages by itself: the running features of its points stay in registers (two 32-point
-// tiles per wave, eight waves), the pooled maxima of its cells live in 64 KB of LDS (one row per sorted position, named like the global
-// segments: the cell's first point), a stage's weights are staged per stage, and three workgroup barriers per stage replace the
-// launch boundary.  Nothing but the cloud is read from HBM and nothing but the per-cell sums written: the four (B,T,32) feature
-// round trips, the four pooled-maxima buffers and their 0x80 fills of the staged form are gone.
+// WHOLE cells can therefore walk all five stages by itself: the running features of its points stay in registers (one 32-point
+// tile per wave, sixteen waves), the pooled maxima of its cells live in 72 KB of LDS (one row per sorted position, named like the
+// global segments: the cell's first point), a stage's weights are staged per stage (fetched into registers one stage ahead), and
+// three workgroup barriers per stage replace the launch boundary.  Nothing but the cloud is read from HBM and nothing but the
+// per-cell sums written: the four (B,T,32) feature round trips, the four pooled-maxima buffers and their 0x80 fills of the staged
+// form are gone.
 // Ownership: workgroup w of a shape takes the runs that START in sorted positions [w * EF_NOM, (w + 1) * EF_NOM) - it skips the
 // tail of a run begun before and finishes the run that straddles its end - which holds at most EF_NOM + EF_LIMIT - 1 <= EF_CAP
 // points if no cell has more than EF_LIMIT = 128 of them (the bench's synthetic partial clouds: 34 .. 52).  The scan kernel raises
 // flag[1 + shape] (and flag[0]) when one does: this kernel then skips the shape and the staged kernels, launched behind it with the
-// opposite test, take it - no host round trip either way.  Per point the arithmetic is the staged form's, instruction for instruction (an MFMA column depends on its
-// own point only), the pool is an integer max and the mean a fixed-point sum: the two forms are BIT-IDENTICAL.
+// opposite test, take it - no host round trip either way.  Per point the arithmetic is the staged form's, instruction for
+// instruction (an MFMA column depends on its own point only), the pool is an integer max and the mean a fixed-point sum: the two
+// forms are BIT-IDENTICAL.
+// Measured (profiles/r05_kbench_enc.txt): 0.9 ms per 64 x 16 384 points = 62 TFLOP/s of f32 MFMA against 0.42 ms x 5 for the staged
+// kernels.  Tried without effect on that figure: eight waves x two tiles (254 VGPRs), 256-point workgroups (two per CU), segmented
+// wavefront scans instead of the LDS atomics, weights fetched between the barriers.
 // ---------------------------------------------------------------------------------------------
-constexpr int EF_CAP = 512, EF_LIMIT = 128, EF_NOM = EF_CAP - EF_LIMIT, EF_NT = 2, EF_THREADS = EF_CAP / (32 * EF_NT) * 64;
+constexpr int EF_CAP = 512, EF_LIMIT = 128, EF_NOM = EF_CAP - EF_LIMIT, EF_NT = 1, EF_THREADS = EF_CAP / (32 * EF_NT) * 64;
 constexpr int EF_W_FLOATS = ENC_BLK_FLOATS + 1056;      // stage weights (+ fc_pos or fc_c)
 // row stride of the pooled maxima (ints) and of the fixed-point sums (64-bit words): 32 channels + 4 of padding.  With 32 the points of
 // a tile - a handful of different cells - fell on two banks per channel and every LDS atomic was a 16-way bank conflict.
@@ -351,21 +356,39 @@ struct EfTile {
   int i;          // global sorted position b * T + pos (clamped for invalid lanes)
   int seg_l;      // sorted position of the cell's first point relative to the workgroup's first point: row of the LDS pooled maxima
   bool valid;
+  bool any;       // wave-uniform: the tile holds a point at all (a workgroup's last tiles are usually empty: n is 384 .. 511 of 512)
 };
 
 // The pools are LDS atomics, one per point and channel (ds_max_i32 on the cell's row; the points of a cell collide and are
 // serialised by the LDS - a few cycles): the first version carried the staged kernels' segmented wavefront scans over, 80
 // ds_bpermute per tile and stage each waited for on its own, and spent more time in them than in its MFMAs.
+// a stage's weights travel global -> registers during the stage before, registers -> LDS between the barriers (the first version
+// loaded them between the barriers: eight waves idle for an L2 round trip, five times per workgroup)
+template <int STAGE>
+__device__ __forceinline__ void ef_fetch(const float* __restrict__ wpack, f32x4 (&wr)[4]) {
+  const int tid = threadIdx.x;
+  const f32x4* s = reinterpret_cast<const f32x4*>(wpack + ENC_OFF_BLK(STAGE));
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (tid + q * EF_THREADS < ENC_BLK_FLOATS / 4) wr[q] = s[tid + q * EF_THREADS];
+  if (STAGE == 0 || STAGE == 4) {
+    const f32x4* s2 = reinterpret_cast<const f32x4*>(wpack + (STAGE == 0 ? ENC_OFF_FCPOS : ENC_OFF_FCC));
+    if (tid < (STAGE == 0 ? 256 : 1056) / 4) wr[3] = s2[tid];
+  }
+}
+static_assert(3 * EF_THREADS >= ENC_BLK_FLOATS / 4 && EF_THREADS >= 1056 / 4 && EF_THREADS >= EF_CAP, "ef_fetch covers a stage's weights with 3 + 1 registers per thread");
+
 template <int STAGE>
 __device__ __forceinline__ void ef_stage(float* __restrict__ lds, int* __restrict__ lsm, const float* __restrict__ wpack,
                                          const float* __restrict__ cloud, const int* __restrict__ order, long long bT,
-                                         f32x16 (&net)[EF_NT], const EfTile (&ts)[EF_NT]) {
+                                         f32x16 (&net)[EF_NT], const EfTile (&ts)[EF_NT], f32x4 (&wr)[4]) {
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
   __syncthreads();                      // every wave is done with the previous stage: its weights, its pooled maxima are final
   f32x16 xhi[EF_NT];
   if (STAGE > 0) {
 #pragma unroll
     for (int k = 0; k < EF_NT; ++k) {
+      if (!ts[k].any) continue;
       const int4* sp = reinterpret_cast<const int4*>(lsm + ts[k].seg_l * EF_ROW + 4 * hi);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -376,27 +399,28 @@ __device__ __forceinline__ void ef_stage(float* __restrict__ lds, int* __restric
     }
   }
   {
-    const f32x4* s = reinterpret_cast<const f32x4*>(wpack + ENC_OFF_BLK(STAGE));
     f32x4* d = reinterpret_cast<f32x4*>(lds);
-    for (int i = tid; i < ENC_BLK_FLOATS / 4; i += EF_THREADS) d[i] = s[i];
-    if (STAGE == 0 || STAGE == 4) {
-      const f32x4* s2 = reinterpret_cast<const f32x4*>(wpack + (STAGE == 0 ? ENC_OFF_FCPOS : ENC_OFF_FCC));
-      f32x4* d2 = reinterpret_cast<f32x4*>(lds + ENC_BLK_FLOATS);
-      for (int i = tid; i < (STAGE == 0 ? 256 : 1056) / 4; i += EF_THREADS) d2[i] = s2[i];
-    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (tid + q * EF_THREADS < ENC_BLK_FLOATS / 4) d[tid + q * EF_THREADS] = wr[q];
+    if ((STAGE == 0 || STAGE == 4) && tid < (STAGE == 0 ? 256 : 1056) / 4) reinterpret_cast<f32x4*>(lds + ENC_BLK_FLOATS)[tid] = wr[3];
   }
   __syncthreads();                      // the pooled maxima of the previous stage are in registers: their rows can be re-armed
+  if (STAGE < 4) ef_fetch<STAGE < 4 ? STAGE + 1 : 4>(wpack, wr);
   if (STAGE < 4) {
-    int4* r = reinterpret_cast<int4*>(lsm + tid * EF_ROW);    // EF_CAP rows, one per thread
+    int4* r = reinterpret_cast<int4*>(lsm + tid * EF_ROW);    // EF_CAP rows, one per thread (of the first EF_CAP)
     const int e = (int)0x80808080;
+    if (tid < EF_CAP) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) r[g] = int4{e, e, e, e};
+      for (int g = 0; g < 8; ++g) r[g] = int4{e, e, e, e};
+    }
     __syncthreads();
   }
   const f32x4* L = reinterpret_cast<const f32x4*>(lds) + lane;
 #pragma unroll
   for (int k = 0; k < EF_NT; ++k) {
     const EfTile& t = ts[k];
+    if (!t.any) continue;               // an empty tile only keeps the barriers
     f32x16 xlo, xh;
     if (STAGE == 0) {
       const float* p = cloud + (bT + order[t.i]) * 3;
@@ -444,6 +468,8 @@ __global__ __launch_bounds__(EF_THREADS) void enc_fused_kernel(const float* __re
                                                                int* __restrict__ ccount, const float* __restrict__ wpack,
                                                                const int* __restrict__ flag, int T) {
   if (flag[1 + blockIdx.y]) return;     // a cell of this shape holds more than EF_LIMIT points: the staged kernels take the shape
+  f32x4 wr[4];
+  ef_fetch<0>(wpack, wr);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int* lsm = reinterpret_cast<int*>(lds + EF_W_FLOATS);       // [EF_CAP][EF_ROW] pooled maxima (ordered-int keys)
   __shared__ int s_rng[2];
@@ -467,17 +493,18 @@ __global__ __launch_bounds__(EF_THREADS) void enc_fused_kernel(const float* __re
     const int tl = (wave * EF_NT + k) * 32;       // the tile's first point, relative to p0
     EfTile& t = ts[k];
     t.valid = tl + pl < n;
+    t.any = __builtin_amdgcn_readfirstlane(tl) < n;
     const int pos = p0 + (t.valid ? tl + pl : n - 1);
     t.i = b * T + pos;
     t.seg_l = st[sc[pos]] - p0;                   // sorted position of the cell's first point
   }
   f32x16 net[EF_NT];
   const long long bT = (long long)b * T;
-  ef_stage<0>(lds, lsm, wpack, cloud, order, bT, net, ts);
-  ef_stage<1>(lds, lsm, wpack, cloud, order, bT, net, ts);
-  ef_stage<2>(lds, lsm, wpack, cloud, order, bT, net, ts);
-  ef_stage<3>(lds, lsm, wpack, cloud, order, bT, net, ts);
-  ef_stage<4>(lds, lsm, wpack, cloud, order, bT, net, ts);     // net = c = fc_c(net)
+  ef_stage<0>(lds, lsm, wpack, cloud, order, bT, net, ts, wr);
+  ef_stage<1>(lds, lsm, wpack, cloud, order, bT, net, ts, wr);
+  ef_stage<2>(lds, lsm, wpack, cloud, order, bT, net, ts, wr);
+  ef_stage<3>(lds, lsm, wpack, cloud, order, bT, net, ts, wr);
+  ef_stage<4>(lds, lsm, wpack, cloud, order, bT, net, ts, wr);     // net = c = fc_c(net)
   // scatter_mean numerator (enc.py:70-74): per-cell sums in 2^-32 fixed point (associative: any order gives the same bits) and
   // point counts, accumulated with LDS atomics in the pooled-maxima region - as 64-bit words it holds half of the rows, so the
   // cells that start in the first and in the second 256 positions take turns - and written out as whole rows: the fused form
@@ -489,15 +516,17 @@ __global__ __launch_bounds__(EF_THREADS) void enc_fused_kernel(const float* __re
     __syncthreads();                    // the region's previous users are done (pooled maxima read at the top of stage 4; the other half's rows written out)
     {
       int4* r = reinterpret_cast<int4*>(lsm + tid * EF_ROW);     // as ints: the whole region, i.e. all EF_CAP / 2 rows of 64-bit words
+      if (tid < EF_CAP) {
 #pragma unroll
-      for (int g = 0; g < EF_ROW / 4; ++g) r[g] = int4{0, 0, 0, 0};
+        for (int g = 0; g < EF_ROW / 4; ++g) r[g] = int4{0, 0, 0, 0};
+      }
       if (tid < EF_CAP / 2) s_cnt[tid] = 0;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < EF_NT; ++k) {
       const EfTile& t = ts[k];
-      if (t.valid && (t.seg_l >> 8) == half) {
+      if (t.valid && t.seg_l / (EF_CAP / 2) == half) {
         const int row = t.seg_l & (EF_CAP / 2 - 1);
         unsigned long long* sp = lsum + row * EF_ROW + 4 * hi;
 #pragma unroll
@@ -509,7 +538,7 @@ __global__ __launch_bounds__(EF_THREADS) void enc_fused_kernel(const float* __re
     }
     __syncthreads();
     {
-      const int row = tid >> 1, part = tid & 1, cnt = s_cnt[row];
+      const int row = (tid >> 1) & (EF_CAP / 2 - 1), part = tid & 1, cnt = tid < EF_CAP ? s_cnt[row] : 0;
       if (cnt > 0) {                    // a cell starts at this position
         const long long seg = bT + p0 + half * (EF_CAP / 2) + row;
         const longlong2* src = reinterpret_cast<const longlong2*>(lsum + row * EF_ROW + part * 16);
