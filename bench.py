@@ -373,6 +373,10 @@ def config3_record(pipe, gpt, Xct, a):
                      "roofline": {"bound": "hbm", "achieved": round((w_one + kv) / ms_step / 1e6, 1), "peak": HBM, "unit": "GB/s",
                                   "frac": round((w_one + kv) / ms_step / 1e6 / HBM, 4),
                                   "note": "algorithmic bytes per step = one weight pass (1.24 GB) + f32 K/V of the rows at the mean cached length"}}
+    auto_shared = S * Lc1 >= gpt.SHARED_PREFIX_MIN_ROW_TOKENS
+    rec["sample_n16_auto"] = {"takes": "sample_n16_shared_prefix" if auto_shared else "sample_n16_expanded",
+                              "rule": f"shared_prefix='auto' (what the sample_n callers pass): shared from rows x L_c >= {gpt.SHARED_PREFIX_MIN_ROW_TOKENS} "
+                                      f"(here 16 x {Lc1}); the two forms are bit-identical (tests/test_gpt_gpu.py), crossover measured with tools/bench_shared_prefix.py"}
     X16 = Xct[:16].contiguous()
     ts = []
     for it in range(3):

@@ -181,7 +181,7 @@ class VisShapeFormer(VisCallback):
                        max_steps=self.sample_max_step, top_k=self.top_k, top_p=self.top_p, temperature=self.temperature,
                        best_in_first=True, mask_invalid=self.mask_invalid, mask_invalid_completion=self.mask_invalid_completion,
                        seed=self.seed, return_logits=self.keep_logits_history,
-                       shared_prefix=True)       # the S rows are copies of ONE condition: prefill + condition K/V once
+                       shared_prefix="auto")     # the S rows are copies of ONE condition: prefill + condition K/V once where it pays
         computed = dict(batch=batch, samples=res["samples"], origin_samples=res["samples"],
                         logits_history=res.get("logits_history"), c_ind=c_ind,
                         z_ind=z_ind if z_ind is not None else c_ind[:, :0], empty_index=enc["empty_index"].long()[0])

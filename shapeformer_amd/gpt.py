@@ -429,6 +429,11 @@ class CondTupleGPT:
     # profiles/r03_ar_overlap.md).
     ATTN_LANES = 2
     MAX_CHAIN_ROWS = 192   # rows per decode chain: row groups of up to 6 row tiles (96 rows) per decode-GEMM workgroup; larger batches = several chains
+    # shared_prefix="auto" (the sample_n copies of one condition, shapeformer.py:222-260): one prefill and one copy of the condition's
+    # keys / values for all rows, bit-identical to expanded rows, but its decode attention walks two caches per row.  Whole-call
+    # times of 512 steps (tools/bench_shared_prefix.py, round 5): 16 rows: expanded wins below L_c = 175 (1.020 vs 1.040 ms/step at
+    # L_c = 84), shared above (1.153 vs 1.116 at 300); 64 rows: shared wins from L_c = 84 on (2.037 vs 1.965; 2.569 vs 2.168 at 300).
+    SHARED_PREFIX_MIN_ROW_TOKENS = 2800      # rows x condition length from which the shared form is taken
     SINGLE_CHAIN_ROWS = 96  # `sample` keeps a batch in ONE chain up to here and interleaves chains above (a lone chain cannot overlap anything)
 
     def decode_step(self, st, B, sp):
@@ -487,6 +492,8 @@ class CondTupleGPT:
             self.refresh_decode_weights()
         Lc_host = Lc.cpu().tolist()
         Lc_max = max(Lc_host)
+        if shared_prefix == "auto":      # the caller vouches for identical condition rows; shared only where it pays
+            shared_prefix = B * Lc_max >= self.SHARED_PREFIX_MIN_ROW_TOKENS
         steps = min(max_steps, self.Lmax - Lc_max - Lz)   # never exceed block_size (stop, don't crop)
         st = self._alloc(B, max_steps, slot)
         st["seq"].zero_()

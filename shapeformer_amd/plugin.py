@@ -378,7 +378,7 @@ class ShapeFormerModel:
                                       top_p=top_p, temperature=temperature, best_in_first=best_in_first, mask_invalid=rep.mask_invalid,
                                       mask_invalid_completion=rep.mask_invalid_completion, seed=seed, stop_early=True, check_every=8,
                                       return_logits=True, z_tokens=z.to(torch.int32) if L_z else None,
-                                      shared_prefix=bool(B > 1 and L_z == 0 and (c == c[:1]).all()))   # sample_n copies
+                                      shared_prefix="auto" if (B > 1 and L_z == 0 and bool((c == c[:1]).all())) else False)   # sample_n copies
         x = res["samples"]                                             # (B, L_z + steps, 2): the z prefix comes first (shapeformer.py:121)
         end = torch.tensor(self.end_tokens)
         ended = (x[:, L_z:] == end[None, None, :]).any(-1).all(0)      # NEW step j: no row without a stop token (shapeformer.py:110-115)

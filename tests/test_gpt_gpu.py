@@ -278,6 +278,19 @@ def test_shared_prefix_sampling_is_bit_identical_to_expanded_rows(dev):
         assert torch.equal(a["samples"], b["samples"]) and torch.equal(a["log_prob"], b["log_prob"])
         assert all(torch.equal(x, y) for x, y in zip(a["logits_history"], b["logits_history"]))
         assert len(set(map(tuple, a["samples"][1:, :, 0].tolist()))) > 1          # the stochastic rows do differ from each other
+        # "auto" (what the sample_n callers pass): the shared form from SHARED_PREFIX_MIN_ROW_TOKENS rows x condition tokens on
+        taken = []
+        orig = g.prefill
+        g.prefill = lambda st, rows, P, _o=orig: (taken.append(rows), _o(st, rows, P))[1]
+        try:
+            for thr in (1, 10 ** 9):
+                g.SHARED_PREFIX_MIN_ROW_TOKENS = thr
+                d = g.sample(c, Lc, max_steps=30, seed=4, stop_early=False, shared_prefix="auto")
+                assert torch.equal(a["samples"], d["samples"]) and torch.equal(a["log_prob"], d["log_prob"])
+        finally:
+            g.prefill = orig
+            del g.SHARED_PREFIX_MIN_ROW_TOKENS
+        assert taken[0] == 1 and taken[1] == S, taken      # one prefilled row when shared, S when expanded
     with pytest.raises(AssertionError):
         g.sample(torch.from_numpy(c3), torch.from_numpy(Lc3), max_steps=4, shared_prefix=True)   # different rows: refused
 

@@ -7,7 +7,7 @@ from shapeformer_amd.gpt import CondTupleGPT
 dev = torch.device("cuda:0")
 g = CondTupleGPT(device=dev)
 rs = np.random.RandomState(0)
-for S, Lc in ((16, 150), (16, 300), (64, 150)):
+for S, Lc in ((16, 40), (16, 84), (16, 120), (16, 150), (16, 200), (16, 300), (16, 400), (64, 84), (64, 150), (64, 300)):
     c = np.full((1, Lc, 2), 4096, np.int64)
     c[0, :Lc - 1, 0] = np.sort(rs.choice(4096, Lc - 1, replace=False)); c[0, :Lc - 1, 1] = rs.randint(0, 4096, Lc - 1)
     ct = torch.from_numpy(c).expand(S, -1, -1).contiguous().to(dev, torch.int32)
