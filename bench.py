@@ -230,7 +230,7 @@ def pmc_traffic(kernel, B):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r0N_pmc_traffic_B<rows>.json, newest round first: FETCH_SIZE
     doubled per the gfx950 correction + WRITE_SIZE); only valid for the configuration it was collected on."""
     f = None
-    for r in ("r04", "r03", "r02", "r01"):                               # newest collection for this launch shape (tools/pmc_run.sh)
+    for r in ("r05", "r04", "r03", "r02", "r01"):                        # newest collection for this launch shape (tools/pmc_run.sh)
         c = os.path.join(ROOT, "profiles", f"{r}_pmc_traffic_B{B}.json")
         if os.path.exists(c):
             f = c
@@ -246,11 +246,12 @@ def pmc_traffic(kernel, B):
 
 def kernel_trace_avg(kernel_prefix):
     """Average launch duration (us) of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/r04_bench_kernel_trace.txt), or None.  NOT a measurement of this run: the profiler's per-dispatch completion
-    signals serialise the decode chains' queues, so its average is a launch that has the chip to itself."""
-    f = os.path.join(ROOT, "profiles", "r04_bench_kernel_trace.txt")
-    if not os.path.exists(f):
+    (profiles/r0N_bench_kernel_trace.txt, newest round first), or None.  NOT a measurement of this run: the profiler's per-dispatch
+    completion signals serialise the decode chains' queues, so its average is a launch that has the chip to itself."""
+    f = kernel_trace_file()
+    if f is None:
         return None
+    f = os.path.join(ROOT, f)
     for ln in open(f):
         if kernel_prefix in ln and not ln.startswith(("#", "{")):
             parts = ln.split()
@@ -261,9 +262,17 @@ def kernel_trace_avg(kernel_prefix):
     return None
 
 
+def kernel_trace_file():
+    for r in ("r05", "r04"):
+        f = os.path.join("profiles", f"{r}_bench_kernel_trace.txt")
+        if os.path.exists(os.path.join(ROOT, f)):
+            return f
+    return None
+
+
 def pmc_traffic_source(B):
     """Where `roofline.traffic` comes from: it is NOT measured in this run (PMC passes need rocprofv3 around the process)."""
-    for r in ("r04", "r03", "r02", "r01"):
+    for r in ("r05", "r04", "r03", "r02", "r01"):
         f = os.path.join("profiles", f"{r}_pmc_traffic_B{B}.json")
         if os.path.exists(os.path.join(ROOT, f)):
             return (f"{f}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled per the gfx950 correction) of "
@@ -726,7 +735,8 @@ def main():
                 line["ar_loop"]["gemm_only_TFLOPs"] = round(flops_step / split["attn"] / 1e9, 1)
                 line["ar_loop"]["split_note"] = ("all chains interleaved, one kernel family disabled at a time (each still runs the head GEMMs + samplers): "
                                                  "the KV stream alone runs at the achievable HBM rate; the two families time-share the chip "
-                                                 "(sum ~ real: the loop is bound by energy at the socket's power cap, profiles/r04_gemm_experiments.md)")
+                                                 "(sum ~ real: one attention launch owns all 32 wave slots of every CU, GEMM workgroups of the other chains enter only in its tail - "
+                                                 "serialisation by wave-slot exhaustion, not the power cap: profiles/r05_stream_power.md)")
             nm = a.micro or default_chains(B)
             Bk = -(-B // nm)     # rows per decode launch (micro-batch)
         if not a.no_roofline:
@@ -756,7 +766,7 @@ def main():
                                 "avg_us": dom["avg_us"],
                                 "timing": ("IN SITU: average over every launch of the timed region, measured by the kernel itself - last workgroup's "
                                            "end minus earliest workgroup's start on the 100 MHz device clock (what a kernel trace reports minus the "
-                                           "dispatch ramp; rocprofv3 --kernel-trace --stats of this command: profiles/r04_bench_kernel_trace.txt)"),
+                                           f"dispatch ramp; rocprofv3 --kernel-trace --stats of this command: {kernel_trace_file()})"),
                                 "dgemm_in_situ": gem if dom_is_attn else None, "attn_in_situ": None if dom_is_attn else att}
             # how many launches of the dominant kernel are in flight on average (the chains run on separate hardware queues: with the
             # two-lane turnstile two attention launches share the HBM stream), and the rate all of them reach together
@@ -774,7 +784,7 @@ def main():
                 sc, pk = (1e9, HBM) if dom_is_attn else (1e12, F32)
                 line["roofline"]["kernel_trace"] = {
                     "avg_us": ta, "achieved": round(alg / (ta * 1e-6) / sc, 1), "frac": round(alg / (ta * 1e-6) / sc / pk, 4),
-                    "source": "profiles/r04_bench_kernel_trace.txt (committed; rocprofv3 --kernel-trace --stats of this command)",
+                    "source": f"{kernel_trace_file()} (committed; rocprofv3 --kernel-trace --stats of this command)",
                     "note": ("under the profiler every dispatch carries a completion signal and the chains' queues drain one kernel at a time: "
                              "its average is the launch ALONE on the chip (the in-situ average of that profiled run, printed in the same "
                              "file, agrees with it), not the launch as it runs in the timed region")}

@@ -177,6 +177,19 @@ def ptr(t):
     return t.ctypes.data
 
 
+_raw_stream = None
+
+
 def stream_ptr():
-    import torch
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device.  Called once per kernel launch (~900 times per training step):
+    torch.cuda.current_stream() builds a Stream object per call; the raw-stream binding the compiler back ends use returns the
+    same handle as a plain int."""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        get, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get is not None and dev is not None:
+            _raw_stream = lambda: get(dev())
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return _raw_stream()

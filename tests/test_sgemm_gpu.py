@@ -55,3 +55,14 @@ def test_fused_epilogue_and_accumulate(dev):
     assert _run(dev, 1, 0, 1024, 256, 3992, accumulate=True, use_ws=False) < 4e-6     # same without scratch (one slice)
     assert _run(dev, 0, 1, 256, 256, 4096, bias=True, act=2, resid=True) < 4e-6       # split-K with the full epilogue
     assert _run(dev, 0, 0, 3992, 1024, 512, accumulate=False) < 2e-6                  # dX = dY W
+
+
+def test_stream_ptr_is_torchs_current_stream(dev):
+    """_lib.stream_ptr() (one call per kernel launch) takes the raw-stream binding instead of building a Stream object: it must name
+    the same hipStream_t as torch.cuda.current_stream(), also inside a stream context and after leaving it."""
+    from shapeformer_amd import _lib as L
+    assert L.stream_ptr() == torch.cuda.current_stream().cuda_stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        assert L.stream_ptr() == s.cuda_stream == torch.cuda.current_stream().cuda_stream
+    assert L.stream_ptr() == torch.cuda.current_stream().cuda_stream != s.cuda_stream
