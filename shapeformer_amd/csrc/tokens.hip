@@ -7,11 +7,26 @@
 #include "sfmi_common.h"
 
 // rows > 1: one histogram per row of n/rows elements (per-shape mode, the reference's batch-1 inference)
+// Wave-aggregated: the lanes of a wavefront that hold the same (row, value) send ONE atomic with their count.  The mode of a code
+// grid is the "empty" code of 97 % of its cells - with one atomic per element they all hit one address and the launch took 1.3 ms
+// for 131 072 elements (9 % of BASELINE config 2's batch); the counts are integers, so the result is the same bit for bit.
 __global__ void hist_kernel(const int* __restrict__ idx, int* __restrict__ hist, long long n, int K, long long per_row) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int bin = -1;                                  // rows * K < 2^31 (host-checked)
   if (i < n) {
-    int v = idx[i];
-    if (v >= 0 && v < K) atomicAdd(&hist[(i / per_row) * K + v], 1);
+    const int v = idx[i];
+    if (v >= 0 && v < K) bin = (int)(i / per_row) * K + v;
+  }
+  bool todo = bin >= 0;
+  unsigned long long m;
+  while ((m = __ballot(todo)) != 0ull) {
+    const int leader = __ffsll((long long)m) - 1;
+    const int lb = __shfl(bin, leader, 64);
+    const bool mine = todo && bin == lb;
+    const unsigned long long mm = __ballot(mine);
+    if (lane == leader) atomicAdd(&hist[lb], __popcll(mm));
+    if (mine) todo = false;
   }
 }
 
@@ -130,7 +145,7 @@ extern "C" {
 // rows == 1: whole-tensor mode (vqdif.py:53 / common.py:155); rows > 1: one mode per row of n/rows elements.
 // hist: rows*K ints of workspace; mode_out: rows ints.
 int sfmi_mode_i32(const int* idx, long long n, int K, int rows, int* hist, int* mode_out, void* stream) {
-  if (!idx || !hist || !mode_out || n <= 0 || K <= 0 || rows <= 0 || n % rows) return SFMI_EINVAL;
+  if (!idx || !hist || !mode_out || n <= 0 || K <= 0 || rows <= 0 || n % rows || (long long)rows * K >= (1ll << 31)) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(hist, 0, (size_t)K * rows * 4, st);
   hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, hist, n, K, n / rows);

@@ -282,3 +282,31 @@ def test_conv_x_reuse_form_and_subpixel_upsampling_conv_vs_torch(dev):
             torch.testing.assert_close(ux.cpu().permute(0, 4, 1, 2, 3), refu, atol=3e-4, rtol=1e-4)
             torch.testing.assert_close(ux, u0, atol=2e-5, rtol=1e-5)
             torch.testing.assert_close(u3, u0, atol=2e-5, rtol=1e-5)
+
+
+def test_mode_histogram_wave_aggregated(dev):
+    """sfmi_mode_i32 (models/common.py:20-23: most frequent value, smallest on ties): the histogram sends one atomic per (row, value)
+    group of a wavefront.  Rows that are no multiple of 64 elements (a wavefront straddles rows), one dominant value, all-distinct
+    values, ties, and out-of-range values (ignored) against numpy."""
+    from shapeformer_amd import tokens as T
+    rs = np.random.RandomState(3)
+    for rows, per_row, K, kind in [(1, 4096 * 5, 4096, "dominant"), (3, 100, 16, "ties"), (7, 333, 4096, "distinct"), (32, 4096, 4096, "dominant"),
+                                   (2, 1000, 50, "range")]:
+        if kind == "dominant":
+            a = np.where(rs.rand(rows, per_row) < 0.97, 1234 % K, rs.randint(0, K, (rows, per_row)))
+        elif kind == "ties":
+            a = np.tile(np.arange(per_row) % 10, (rows, 1)); a[1] = a[1][::-1]           # ten values ten times each: the smallest wins
+        elif kind == "distinct":
+            a = np.stack([rs.permutation(K)[:per_row] for _ in range(rows)]); a[:, -1] = a[:, 0]   # exactly one value twice per row
+        else:
+            a = rs.randint(-5, K + 5, (rows, per_row))
+        want = []
+        for r in range(rows):
+            v = a[r][(a[r] >= 0) & (a[r] < K)]
+            c = np.bincount(v, minlength=K)
+            want.append(int(np.argmax(c)))          # argmax returns the smallest index among ties
+        got = T.mode_i32(torch.from_numpy(a.astype(np.int32)).to(dev), K, rows=rows).cpu().numpy().ravel()
+        assert np.array_equal(got, np.array(want)), (kind, got, want)
+        if rows > 1:      # whole-tensor mode of the same data
+            v = a[(a >= 0) & (a < K)]
+            assert int(T.mode_i32(torch.from_numpy(a.astype(np.int32)).to(dev), K)) == int(np.argmax(np.bincount(v, minlength=K)))
