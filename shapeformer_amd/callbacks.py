@@ -155,8 +155,11 @@ class VisShapeFormer(VisCallback):
     def __init__(self, temperature=1, sample_n=10, top_k=300, top_p=.9, depth=5, decode_res=128, sample_max_step=512,
                  render_samples=64, end_tokens=None, mask_invalid=True, mask_invalid_completion=False,
                  force_keep_c_indices=False, sort_prob=True, partial_radius=0.02, camPos=(2, 2, 2), resolution=(512, 512),
-                 thresh=0.5, keep_logits_history=False, seed=0, **kw):
+                 thresh=0.5, keep_logits_history=False, seed=0, shard_sample_n=None, **kw):
         super().__init__(**kw)
+        # shard_sample_n: a torch.distributed module / process group holder -> the sample_n sequences of the ONE shape are split over
+        # its ranks (single-shape option; dist.sample_n_sharded) instead of every rank completing whole shapes
+        self.shard_sample_n = shard_sample_n
         self.temperature, self.sample_n, self.top_k, self.top_p, self.depth, self.decode_res = temperature, sample_n, top_k, top_p, depth, decode_res
         self.sample_max_step, self.end_tokens = sample_max_step, tuple(end_tokens)
         self.mask_invalid, self.mask_invalid_completion = mask_invalid, mask_invalid_completion
@@ -177,11 +180,15 @@ class VisShapeFormer(VisCallback):
             z = pipe.encode_cloud(batch["Xbd"].to(g.dev, torch.float32))
             z_ind = z["c_tokens"][:, :int(z["Lc"][0])].long()
         S = self.sample_n
-        res = g.sample(enc["c_tokens"].expand(S, -1, -1).contiguous(), enc["Lc"].expand(S).contiguous(),
-                       max_steps=self.sample_max_step, top_k=self.top_k, top_p=self.top_p, temperature=self.temperature,
-                       best_in_first=True, mask_invalid=self.mask_invalid, mask_invalid_completion=self.mask_invalid_completion,
-                       seed=self.seed, return_logits=self.keep_logits_history,
-                       shared_prefix="auto")     # the S rows are copies of ONE condition: prefill + condition K/V once where it pays
+        skw = dict(max_steps=self.sample_max_step, top_k=self.top_k, top_p=self.top_p, temperature=self.temperature,
+                   best_in_first=True, mask_invalid=self.mask_invalid, mask_invalid_completion=self.mask_invalid_completion, seed=self.seed)
+        if self.shard_sample_n is not None and not self.keep_logits_history:
+            from .dist import sample_n_sharded
+            res = sample_n_sharded(g, enc["c_tokens"], enc["Lc"], S, self.shard_sample_n, **skw)     # identical tokens, S / world rows per rank
+        else:
+            res = g.sample(enc["c_tokens"].expand(S, -1, -1).contiguous(), enc["Lc"].expand(S).contiguous(),
+                           return_logits=self.keep_logits_history,
+                           shared_prefix="auto", **skw)     # the S rows are copies of ONE condition: prefill + condition K/V once where it pays
         computed = dict(batch=batch, samples=res["samples"], origin_samples=res["samples"],
                         logits_history=res.get("logits_history"), c_ind=c_ind,
                         z_ind=z_ind if z_ind is not None else c_ind[:, :0], empty_index=enc["empty_index"].long()[0])

@@ -4,6 +4,8 @@ Mirrors the reference's inference sharding (xgutils/plutil.py:123-139 `get_effec
 items r, r+G, r+2G, ...).  There is NO data-path collective: every rank holds a full weight replica (1.3 GB +
 72 MB) and completes its own shapes; the only exchange is the optional final gather of the (B,L,2) token tensors /
 timing scalars over torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in CPU tests).
+The single-shape option of SURVEY 8(e) - the sample_n sequences of ONE shape split over the ranks - is `sample_n_sharded`
+below: its one exchange is the early-stop vote (one int per `check_every` steps) and the final gather of the tokens.
 """
 from __future__ import annotations
 
@@ -299,3 +301,43 @@ class GradBuckets:
         if reset:
             self._gather_events, self._gather_steps = [], 0
         return ms
+
+
+def sample_n_sharded(gpt, c_tokens, Lc, sample_n, dist=None, **sample_kw):
+    """SURVEY section 8(e), the single-shape option: the `sample_n` sequences of ONE condition (VisShapeFormer.compute_batch,
+    shapeformer.py:222-260) split over the ranks.  c_tokens (1,Lpad,2) / Lc (1,) hold the condition once; rank r samples rows
+    [S r / W, S (r + 1) / W) of the S copies with their GLOBAL row index (uniform stream, greedy row 0), the early stop is decided
+    by an all-reduce of "all my rows have ended" at every check (the one exchange step this path has: one int per `check_every`
+    steps), and the (rows, steps, 2) tokens + log-probabilities are gathered on every rank in global row order.  The result is the
+    one `gpt.sample` of all S rows returns in a single process, bit for bit (tests/test_ddp_gpu.py)."""
+    S = int(sample_n)
+    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
+    rank = 0 if world == 1 else dist.get_rank()
+    lo, hi = S * rank // world, S * (rank + 1) // world
+    if hi - lo > 4 * gpt.MAX_CHAIN_ROWS:
+        raise ValueError(f"sample_n_sharded: {hi - lo} rows on one rank (at most {4 * gpt.MAX_CHAIN_ROWS}: successive rounds stop independently)")
+    sample_kw = dict(sample_kw)
+    sample_kw.setdefault("shared_prefix", "auto")
+    res = None
+    if hi > lo:
+        rows = c_tokens[:1].expand(hi - lo, -1, -1).contiguous()
+        lens = torch.as_tensor(Lc).reshape(-1)[:1].expand(hi - lo).contiguous()
+
+        def ended_reduce(e):
+            if world == 1:
+                return e
+            t = torch.tensor([1 if e else 0], dtype=torch.int32, device=gpt.dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        res = gpt.sample(rows, lens, row_offset=lo, rows_total=S, ended_reduce=ended_reduce, to_host=True, **sample_kw)
+        res = {k: v for k, v in res.items() if k in ("samples", "log_prob", "steps")}
+    elif world > 1 and sample_kw.get("stop_early", True):
+        raise ValueError("sample_n_sharded: fewer sequences than ranks with the early stop on (a rank without rows cannot follow the stop checks)")
+    if world == 1:
+        return res
+    parts = [None] * world
+    dist.all_gather_object(parts, res)
+    parts = [p for p in parts if p is not None]
+    steps = parts[0]["steps"]
+    assert all(p["steps"] == steps for p in parts), [p["steps"] for p in parts]
+    return dict(samples=torch.cat([p["samples"] for p in parts], 0), log_prob=torch.cat([p["log_prob"] for p in parts], 0), steps=steps)

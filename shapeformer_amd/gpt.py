@@ -580,10 +580,15 @@ class CondTupleGPT:
     def sample(self, c_tokens, Lc, max_steps=512, top_k=100, top_p=0.4, temperature=1.0, best_in_first=True,
                mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True, use_graph=True,
                return_logits=False, check_every=32, force_tokens=None, to_host=True, after_prefill=None, shared_prefix=False,
-               z_tokens=None):
+               z_tokens=None, row_offset=0, rows_total=None, ended_reduce=None):
         """c_tokens (B,Lpad,2) int32 (row b valid for Lc[b] tokens, last = end-token pair), Lc (B,) int32; z_tokens (B,L_z,2):
         optional tokens already generated (sampling continues after them; `samples` then starts with them, as the reference's
         x = sampled[:, L_c:] does, shapeformer.py:121, while log_prob / logits_history cover the NEW steps only).
+
+        row_offset / rows_total: these B rows are rows [row_offset, row_offset + B) of a batch of rows_total (another process holds
+        the others, dist.sample_n_sharded): the uniform stream and the greedy row are indexed by the GLOBAL row, so the tokens
+        are those of the whole batch in one process.  ended_reduce(bool) -> bool: combines this process's "all my rows have ended"
+        with the other processes' at every early-stop check (the reference stops when ALL rows have ended, shapeformer.py:110-115).
 
         Returns dict(samples (B,L_z+steps,2) int64, log_prob (B,steps,2), steps, [logits_history]).
         Mirrors ShapeFormer.sample_indices (shapeformer.py:54-123); torch.multinomial is replaced by an
@@ -597,14 +602,17 @@ class CondTupleGPT:
                                          best_in_first=best_in_first, mask_invalid=mask_invalid, mask_invalid_completion=mask_invalid_completion,
                                          seed=seed, stop_early=stop_early, check_every=check_every, after_prefill=after_prefill,
                                          return_logits=return_logits, force_tokens=force_tokens, shared_prefix=shared_prefix,
-                                         z_tokens=z_tokens, use_graph=use_graph)
+                                         z_tokens=z_tokens, use_graph=use_graph, _row0=int(row_offset), _rows_total=rows_total,
+                                         ended_reduce=ended_reduce)
             if not to_host:
                 return r
             Lz = 0 if z_tokens is None else int(z_tokens.shape[1])
             return self._host_result(r["state"], Lc.cpu().tolist(), Lz, r.get("logits_history"))
         sp_kw = self._sp(top_k, top_p, temperature, best_in_first, mask_invalid, mask_invalid_completion, seed)
         ctx = self._prepare(c_tokens, Lc, max_steps, sp_kw, return_logits=return_logits, force_tokens=force_tokens,
-                            use_graph=use_graph, shared_prefix=shared_prefix, z_tokens=z_tokens)
+                            use_graph=use_graph, shared_prefix=shared_prefix, z_tokens=z_tokens, row_offset=int(row_offset),
+                            rows_total=rows_total)
+        ended = (lambda: self._all_ended(st, B)) if ended_reduce is None else (lambda: bool(ended_reduce(self._all_ended(st, B))))
         st, sp, B, steps, g, hist, Lc_host = (ctx[k] for k in ("st", "sp", "B", "steps", "graph", "hist", "Lc_host"))
         if after_prefill is not None:
             after_prefill()
@@ -615,13 +623,13 @@ class CondTupleGPT:
                 for _ in range(n):
                     g.replay()
                 done += n
-                if stop_early and self._all_ended(st, B):
+                if stop_early and ended():
                     break
         else:
             while done < steps:
                 self.decode_step(st, B, sp)
                 done += 1
-                if stop_early and done % check_every == 0 and self._all_ended(st, B):
+                if stop_early and done % check_every == 0 and ended():
                     break
         if not to_host:   # device-resident result for the completion pipeline (no D2H of tokens)
             return dict(state=st, steps=done)
@@ -710,7 +718,7 @@ class CondTupleGPT:
     def sample_microbatched(self, c_tokens, Lc, n_micro=2, max_steps=512, top_k=100, top_p=0.4, temperature=1.0,
                             best_in_first=True, mask_invalid=True, mask_invalid_completion=True, seed=0, stop_early=True,
                             check_every=32, after_prefill=None, return_logits=False, force_tokens=None, shared_prefix=False,
-                            z_tokens=None, use_graph=True, _row0=0, _rows_total=None):
+                            z_tokens=None, use_graph=True, _row0=0, _rows_total=None, ended_reduce=None):
         """Same result as `sample(..., to_host=False)` (identical tokens: the uniform stream and the greedy row are
         indexed by GLOBAL row), but the rows are split into `n_micro` independent micro-batches whose decode steps are
         separate hipGraphs replayed on separate HIP streams: one micro-batch's HBM-bound attention overlaps the other's
@@ -809,7 +817,8 @@ class CondTupleGPT:
             if stop_early:
                 for s in streams:
                     cur.wait_stream(s)
-                if all(self._all_ended(c["st"], c["B"]) for c in ctxs):
+                e_ = all(self._all_ended(c["st"], c["B"]) for c in ctxs)
+                if (e_ if ended_reduce is None else bool(ended_reduce(e_))):
                     break
         for s in streams:
             cur.wait_stream(s)

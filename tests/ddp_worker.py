@@ -68,6 +68,14 @@ def main():
     out["rsag_blocking_in_flight"] = np.int64(len(tr3.buckets.params_in_flight()))
     out["gpt_w_rsag_blocking"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p, _ in tr3.params])
     out["gpt_m_ring"] = tr.flat_m.detach().cpu().numpy().copy()
+    # ---- SURVEY 8(e), single-shape option: the sample_n = 7 sequences of ONE condition split over the ranks (3 + 4 rows), early stop on
+    from shapeformer_amd.dist import sample_n_sharded
+    g4 = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    tk = np.load(os.path.join(G, "vqdif16_small.npz"))["tokens"].astype(np.int64)[0, :23]       # 23 real tokens + the end pair
+    c1 = torch.from_numpy(np.concatenate([tk, np.full((1, 2), 4096, np.int64)])[None]).to(torch.int32)
+    for name, skw in (("sn", dict(max_steps=40, seed=9, check_every=4)), ("sn_full", dict(max_steps=24, seed=9, stop_early=False, mask_invalid=False))):
+        r = sample_n_sharded(g4, c1, torch.tensor([c1.shape[1]], dtype=torch.int32), 7, dist, **skw)
+        out[name + "_samples"], out[name + "_logp"], out[name + "_steps"] = r["samples"].numpy(), r["log_prob"].numpy(), np.int64(r["steps"])
     # ---- VQDIF autoencoder: item r of a 2-item batch; gradients averaged, EMA statistics summed over ranks ------
     T = np.load(os.path.join(G, "vqdif_train.npz"))
     Xbd = np.concatenate([T["Xbd"], T["Xbd"][:, ::-1] * np.float32(0.9)], 0)      # two different clouds

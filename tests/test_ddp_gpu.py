@@ -210,3 +210,23 @@ def test_rs_ag_equals_ring_over_rccl_on_two_gpus(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert abs(outs["ring"]["loss_last"] - outs["rs_ag"]["loss_last"]) < 1e-4 and outs["rs_ag"]["n_gpus"] == 2
+
+
+def test_sample_n_of_one_shape_split_over_two_ranks(dev, ranks):
+    """SURVEY section 8(e), single-shape option (dist.sample_n_sharded): 7 sequences of ONE condition, 3 on rank 0 and 4 on rank 1 with
+    their global row indices and a collective early stop, gathered on both ranks == the 7 rows sampled by ONE process, bit for
+    bit (tokens, log-probabilities, number of steps), with the early stop on and with all steps forced."""
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    kw = dict(n_embd=128, n_layers=(2, 1), block_size=96)
+    g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+    tk = np.load(os.path.join(G, "vqdif16_small.npz"))["tokens"].astype(np.int64)[0, :23]       # 23 real tokens + the end pair
+    c1 = torch.from_numpy(np.concatenate([tk, np.full((1, 2), 4096, np.int64)])[None]).to(torch.int32)
+    c7, L7 = c1.expand(7, -1, -1).contiguous(), torch.full((7,), c1.shape[1], dtype=torch.int32)
+    for name, skw in (("sn", dict(max_steps=40, seed=9, check_every=4)), ("sn_full", dict(max_steps=24, seed=9, stop_early=False, mask_invalid=False))):
+        one = g.sample(c7, L7, **skw)
+        for r in ranks:
+            assert int(r[name + "_steps"]) == int(one["steps"]), (name, int(r[name + "_steps"]), int(one["steps"]))
+            assert np.array_equal(r[name + "_samples"], one["samples"].numpy()), name
+            assert np.array_equal(r[name + "_logp"], one["log_prob"].numpy()), name
+    assert len(set(map(tuple, one["samples"][1:, :, 0].tolist()))) > 1       # the stochastic rows differ from each other
