@@ -343,8 +343,10 @@ __global__ __launch_bounds__(256) void enc_block_kernel(
 // instruction (an MFMA column depends on its own point only), the pool is an integer max and the mean a fixed-point sum: the two
 // forms are BIT-IDENTICAL.
 // Measured (profiles/r05_kbench_enc.txt): 0.9 ms per 64 x 16 384 points = 62 TFLOP/s of f32 MFMA against 0.42 ms x 5 for the staged
-// kernels.  Tried without effect on that figure: eight waves x two tiles (254 VGPRs), 256-point workgroups (two per CU), segmented
-// wavefront scans instead of the LDS atomics, weights fetched between the barriers.
+// kernels.  PMC (round 5): MFMA busy 0.40, 45 % of the wave cycles waiting on an instruction dependency, 13 % on LDS.  Tried without
+// effect on that figure: eight waves x two tiles (254 VGPRs), 256-point workgroups (two per CU), segmented wavefront scans instead
+// of the LDS atomics, weights fetched between the barriers, the operand ReLUs hoisted out of the MFMA chains (1.46 -> 1.44 ms for
+// the call, the staged kernels 2.51 -> 2.57: not kept).
 // ---------------------------------------------------------------------------------------------
 constexpr int EF_CAP = 512, EF_LIMIT = 128, EF_NOM = EF_CAP - EF_LIMIT, EF_NT = 1, EF_THREADS = EF_CAP / (32 * EF_NT) * 64;
 constexpr int EF_W_FLOATS = ENC_BLK_FLOATS + 1056;      // stage weights (+ fc_pos or fc_c)
