@@ -179,12 +179,6 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_packed, const float* unused, float
 int sfmi_gpt_attn_decode_gated_f32(const float* qkv_packed, float* Kc, float* Vc, const int* len, float* y_packed, int B, int D, int H,
                                    int Lmax, const int* shared_len, int* sem, int* blk, int lanes, unsigned long long* prof,
                                    void* stream);
-/* the same with a row order (B ints, a permutation of 0 .. B-1, normally the rows by descending cached length): workgroup index i
- * names head i % H of row order[i / H], so that a launch over ragged rows ends on its short ones.  Scheduling only - results are
- * those of sfmi_gpt_attn_decode_f32; order == NULL: batch order (no reference counterpart). */
-int sfmi_gpt_attn_decode_ordered_f32(const float* qkv_packed, float* Kc, float* Vc, const int* len, float* y_packed, int B, int D, int H,
-                                     int Lmax, const int* shared_len, int* sem, int* blk, int lanes, unsigned long long* prof,
-                                     const int* order, void* stream);
 /* one tuple element of one sampling step per row: sampling_masker (representers.py:120-155) + filter_sampling_logits /
  * sample_logits (models/common.py:260-299: temperature, top-k with ties, top-p) + inverse-CDF draw from counter-hash uniforms
  * indexed (step, tuple, row_offset + b) + best_in_first greedy row + log-prob + optional masked-logit history; writes the

@@ -421,7 +421,6 @@ struct AttnArgs {
   int* sem;      // optional turnstile words {next ticket, finished launches, gate time-outs}: the LAST workgroup of a launch bumps sem[1]
   int* blk;      // this chain's finished-workgroup counter (re-armed by the last workgroup)
   unsigned long long* prof;   // optional in-situ launch timing sink of this chain (prof_begin / prof_end_last; needs blk)
-  const int* order;   // optional (B): item it is head it % H of row order[it / H] (longest rows first; scheduling only); NULL: head-major, batch order
 };
 template <int NWV>
 struct AttnLds {
@@ -551,18 +550,8 @@ __global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : U <= 8 ? 4 : 2) void attn_de
   const int nitems = a.B * a.H;
   prof_begin(a.prof, blockIdx.x);
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
-    int ib, ih;
-    if (a.order) {
-      // longest-processing-time-first: the rows of a chain are ragged (cached lengths differ by up to 2 x) and workgroups are handed
-      // out in index order - with the caller's order (rows by descending length; the lengths grow in lock step, it never changes)
-      // the launch ends on its short rows
-      const int r = it / a.H;
-      ih = it - r * a.H; ib = a.order[r];
-    } else {
-      ih = it / a.B; ib = it - ih * a.B;
-    }
-    // wave-uniform: keeps the cache bases in scalar registers
-    attn_decode_item<NWV, U>(s, a, __builtin_amdgcn_readfirstlane(ib), __builtin_amdgcn_readfirstlane(ih));
+    const int h = __builtin_amdgcn_readfirstlane(it / a.B);   // wave-uniform: keeps the cache bases in scalar registers
+    attn_decode_item<NWV, U>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
     if (it + (int)gridDim.x < nitems) __syncthreads();   // the next item rewrites the hand-off tiles
   }
   if ((a.sem || a.prof) && threadIdx.x == 0) {     // turnstile release: the launch's last workgroup to finish admits the next KV stream
@@ -1285,24 +1274,15 @@ int sfmi_gpt_rowprep_f32(const float* resid_in, const float* part, const float* 
 // replaces CausalSelfAttention.forward for ONE new position per row with a KV cache (mingpt.py:73-91).
 // sem (optional, 3 device ints zeroed by the caller while no launch is in flight) + blk (1 device int, zero; one per chain):
 // the launch passes the attention turnstile first (at most `lanes` gated launches stream at a time, FIFO).
-int sfmi_gpt_attn_decode_ordered_f32(const float* qkv_part, float* Kc, float* Vc, const int* len, float* y, int B, int D, int H, int Lmax,
-                                     const int* shared_len, int* sem, int* blk, int lanes, unsigned long long* prof, const int* order, void* stream);
 int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, const int* len, float* y, int B, int D, int H,
                                    int Lmax, const int* shared_len, int* sem, int* blk, int lanes, unsigned long long* prof, void* stream) {
-  return sfmi_gpt_attn_decode_ordered_f32(qkv_part, Kc, Vc, len, y, B, D, H, Lmax, shared_len, sem, blk, lanes, prof, nullptr, stream);
-}
-// the same with the caller's row order (B ints, a permutation of 0 .. B-1: rows by descending cached length) - workgroup index it
-// names head it % H of row order[it / H], so that the launch ends on its short rows.  Scheduling only; order == NULL: batch order.
-int sfmi_gpt_attn_decode_ordered_f32(const float* qkv_part, float* Kc, float* Vc, const int* len, float* y, int B, int D, int H,
-                                     int Lmax, const int* shared_len, int* sem, int* blk, int lanes, unsigned long long* prof,
-                                     const int* order, void* stream) {
   if (!qkv_part || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
   if (sem && (!blk || lanes <= 0)) return SFMI_EINVAL;
   if (prof && !blk) return SFMI_EINVAL;
   AttnArgs a;
   a.qkv = qkv_part; a.Kc = Kc; a.Vc = Vc; a.len = len; a.y = y; a.shared_len = shared_len;
   a.B = B; a.H = H; a.D = D; a.Lmax = Lmax; a.HD = D / H; a.scale = 1.0f / sqrtf((float)a.HD);
-  a.sem = sem; a.blk = blk; a.prof = prof; a.order = order;
+  a.sem = sem; a.blk = blk; a.prof = prof;
   const int nitems = B * H;
   const int grid = g_tune.attn_blocks > 0 ? min(g_tune.attn_blocks, nitems) : nitems;
   const size_t pad = (size_t)g_tune.attn_lds_pad;

@@ -203,7 +203,6 @@ class CondTupleGPT:
                   pblk=torch.zeros(1, device=dev, dtype=torch.int32),     # in-situ launch timing: finished workgroups of the decode-GEMM launch
                   prof=self._prof_zero(dev),                              # in-situ launch timing sinks {t0, sum, launches, -} x {attn, gemm}
                   shared=torch.zeros(1, device=dev, dtype=torch.int32),  # shared-prefix length of the sample_n mode (device-resident)
-                  order=torch.arange(B, device=dev, dtype=torch.int32),  # decode attention's row order (ATTN_LPT), refilled by _prepare
                   seed=torch.zeros(1, device=dev, dtype=torch.int32))   # sampler seed (device-resident: graphs are seed-independent)
         self._state = st
         self._states[slot] = st
@@ -435,7 +434,6 @@ class CondTupleGPT:
     # times of 512 steps (tools/bench_shared_prefix.py, round 5): 16 rows: expanded wins below L_c = 175 (1.020 vs 1.040 ms/step at
     # L_c = 84), shared above (1.153 vs 1.116 at 300); 64 rows: shared wins from L_c = 84 on (2.037 vs 1.965; 2.569 vs 2.168 at 300).
     SHARED_PREFIX_MIN_ROW_TOKENS = 2800      # rows x condition length from which the shared form is taken
-    ATTN_LPT = False        # decode attention: longest rows first (sfmi_gpt_attn_decode_ordered_f32); scheduling only, see DESIGN 5.1
     SINGLE_CHAIN_ROWS = 96  # `sample` keeps a batch in ONE chain up to here and interleaves chains above (a lone chain cannot overlap anything)
 
     def decode_step(self, st, B, sp):
@@ -456,12 +454,11 @@ class CondTupleGPT:
             if "gemm" not in skip:
                 self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st, prof=pg)
             if "attn" not in skip:
-                L.check(lib.sfmi_gpt_attn_decode_ordered_f32(L.ptr(st["qkv"]), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
-                                                             L.ptr(st["len"]), L.ptr(st["y"]), B, D, self.H, self.Lmax + 1,
-                                                             L.ptr(st["shared"]) if sp.get("shared_prefix") else None,
-                                                             L.ptr(self._sem) if lanes else None, L.ptr(st["blk"]) if (lanes or pa) else None, lanes,
-                                                             L.ptr(st["prof"]) if pa else None, L.ptr(st.get("order")) if sp.get("lpt") else None,
-                                                             L.stream_ptr()), "sfmi_gpt_attn_decode_ordered_f32")
+                L.check(lib.sfmi_gpt_attn_decode_gated_f32(L.ptr(st["qkv"]), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
+                                                           L.ptr(st["len"]), L.ptr(st["y"]), B, D, self.H, self.Lmax + 1,
+                                                           L.ptr(st["shared"]) if sp.get("shared_prefix") else None,
+                                                           L.ptr(self._sem) if lanes else None, L.ptr(st["blk"]) if (lanes or pa) else None, lanes,
+                                                           L.ptr(st["prof"]) if pa else None, L.stream_ptr()), "sfmi_gpt_attn_decode_gated_f32")
             if "gemm" not in skip:
                 self._dgemm(st["y"], ly.pproj, None, ly.bproj, r, r, B, D, D, D, 0, 0, S=Sproj, st=st, prof=pg)
                 self._dgemm(r, ly.pfc1, ly.c1fc1, ly.c2fc1, None, st["h"], B, 4 * D, D, 4 * D, 1, 1, S=Sfc1, st=st, prof=pg)
@@ -515,9 +512,7 @@ class CondTupleGPT:
             hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
         sp = dict(sp_kw, max_steps=int(max_steps), hist=hist, row_offset=int(row_offset),
                   rows_total=int(rows_total if rows_total is not None else B), chain=int(slot - 100 if slot >= 100 else 0),
-                  shared_prefix=bool(shared_prefix), step_offset=Lz, gate_lanes=int(gate_lanes), lpt=bool(self.ATTN_LPT))
-        # decode attention hands out the heads of the LONGEST rows first (ATTN_LPT): the lengths grow in lock step, the order is fixed here
-        st["order"].copy_(torch.argsort(st["len"], descending=True, stable=True))
+                  shared_prefix=bool(shared_prefix), step_offset=Lz, gate_lanes=int(gate_lanes))
         if force_tokens is not None:   # (B,max_steps,2) teacher forcing for stepwise parity tests
             ft = torch.zeros(B, max_steps, 2, dtype=torch.int32)
             ft[:, :force_tokens.shape[1]] = torch.as_tensor(force_tokens).to(torch.int32)

@@ -455,24 +455,3 @@ def test_decode_gemm_two_n_tile_form_and_row_groups_are_bit_identical(dev, M):
             assert torch.equal(a, b), (M, N, K, float((a - b).abs().max()))
     finally:
         L.check(lib.sfmi_tune_set(b"dgemm_nt2", 1), "tune")
-
-
-def test_attention_longest_rows_first_is_scheduling_only(dev):
-    """ATTN_LPT (sfmi_gpt_attn_decode_ordered_f32): the decode attention hands out the heads of the longest rows first - the same
-    (row, head) items in another workgroup order.  Ragged rows, single chain and interleaved chains, hipGraph replay: tokens,
-    log-probabilities and masked logits are BIT-identical to the batch-order launch."""
-    from shapeformer_amd.gpt import CondTupleGPT
-    sd, sd_t, cfg = _tiny()
-    g = CondTupleGPT(sd, n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
-    c3, Lc3 = _cond_rows()
-    rep = 40
-    c = torch.from_numpy(np.concatenate([c3] * rep)); Lc = torch.from_numpy(np.concatenate([Lc3] * rep))    # 120 ragged rows -> two chains
-    for rows in (3, 120):
-        outs = []
-        for lpt in (False, True):
-            g.ATTN_LPT = lpt
-            outs.append(g.sample(c[:rows], Lc[:rows], max_steps=20, seed=5, stop_early=False, return_logits=True))
-        g.ATTN_LPT = False
-        a, b = outs
-        assert torch.equal(a["samples"], b["samples"]) and torch.equal(a["log_prob"], b["log_prob"])
-        assert all(torch.equal(x, y) for x, y in zip(a["logits_history"], b["logits_history"]))

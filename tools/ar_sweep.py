@@ -6,7 +6,7 @@ with HIP events, optionally with one kernel family disabled (timing-only ablatio
     python tools/ar_sweep.py --out gpurun_out/r3/ar_sweep.txt [--rows 320 --chains 4] < configs
 
 A configuration line is `name key=value ...`; keys: the sfmi_tune_set knobs (attn_blocks, attn_unroll, attn_waves,
-attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `lpt=` (gpt.ATTN_LPT), `lanes=` (gpt.ATTN_LANES: attention turnstile, at most that many
+attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `lanes=` (gpt.ATTN_LANES: attention turnstile, at most that many
 chains stream their KV cache at a time), `prefetch=` (gpt.PREFETCH_BLOCKS: Infinity-Cache weight prefetch branch of a single chain),
 `profile=attn,gemm` (in-situ launch timing: prints launches and mean us per family).  Lines starting with # are skipped.
 Condition lengths are uniform in [100, 216] (mean 158 = the bench's synthetic clouds); positions ascending, end-token closed.
@@ -160,7 +160,6 @@ def main():
         lclo, lchi = int(kv.pop("lclo", 100)), int(kv.pop("lchi", 216))     # condition lengths (short traces: start near the mid-run length)
         gpt._ablate = kv.pop("ablate", "")
         gpt.ATTN_LANES = int(kv.pop("lanes", "0"))
-        gpt.ATTN_LPT = bool(int(kv.pop("lpt", "0")))            # decode attention: longest rows first
         gpt.S_PROJ_M, gpt.S_FC2 = int(kv.pop("sproj", "1")), int(kv.pop("sfc2", "4"))      # in-kernel split-K of proj / fc2 (part of the graph key)
         gpt._profile = kv.pop("profile", "")
         bg = kv.pop("bgsdf", None)
