@@ -435,7 +435,10 @@ struct AttnLds {
 // (Round 4 measured a "small grid" form for 16-32 rows - 8 loads in flight per lane and the first batch of values requested together
 // with the keys, one round trip instead of two - and dropped it: 0.47 against 0.39 ms per step of attention at 16 rows, the extra loads
 // queue in front of the keys the scores wait for.  profiles/r04_b16_experiments.md)
-template <int NWV, int U>
+// SH: the launch has a shared prefix (a.shared_len != NULL).  The plain instance keeps ONE wave-uniform base per cache (scalar
+// registers, scalar-base loads); the per-lane choice between row 0's cache and the row's own costs a compare and two selects on a
+// 64-bit address per load, and the product instance (64 registers, 8 waves per SIMD) has no slack for them.
+template <int NWV, int U, bool SH>
 __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs& a, const int b, const int h) {
   constexpr int KB = NWV * 4 * U;   // keys per batch of loads
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -447,9 +450,9 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
   // shared prefix (sample_n copies of ONE condition, shapeformer.py:222-260): keys / values of positions < shared_len[0] were
   // written once, by row 0's prefill, and every row reads them from row 0's cache (one HBM read, L2 / Infinity-Cache hits
   // for the other rows); a row's own cache holds its tail only
-  const int nshared = a.shared_len ? a.shared_len[0] : 0;
-  const float* Kb0 = a.Kc + (long long)h * Lmax * HD;
-  const float* Vb0 = a.Vc + (long long)h * Lmax * HD;
+  const int nshared = SH ? a.shared_len[0] : 0;
+  const float* Kb0 = SH ? a.Kc + (long long)h * Lmax * HD : Kb;
+  const float* Vb0 = SH ? a.Vc + (long long)h * Lmax * HD : Vb;
   const int c4 = lane & 15, kk = lane >> 4;
   const bool cok = c4 < nq4;
   // the first batch of keys is requested BEFORE the q/k/v hand-off barrier (the loads only need `t`): the HBM latency of the
@@ -459,7 +462,7 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
       kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Kb0 : Kb) + (long long)i * HD + 4 * c4));
+      if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((SH && i < nshared ? Kb0 : Kb) + (long long)i * HD + 4 * c4));
     }
   };
   auto load_v = [&](int i0, f32x4 (&vf)[U]) {
@@ -467,7 +470,7 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
       vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Vb0 : Vb) + (long long)i * HD + 4 * c4));
+      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((SH && i < nshared ? Vb0 : Vb) + (long long)i * HD + 4 * c4));
     }
   };
   f32x4 kf0[U], vf0[U];
@@ -544,14 +547,14 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
   }
 }
 
-template <int NWV, int U>
+template <int NWV, int U, bool SH>
 __global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : U <= 8 ? 4 : 2) void attn_decode_kernel(AttnArgs a) {   // U <= 4: <= 64 VGPRs (8 waves per SIMD), U = 8: <= 128, U = 16: <= 256
   __shared__ AttnLds<NWV> s;
   const int nitems = a.B * a.H;
   prof_begin(a.prof, blockIdx.x);
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int h = __builtin_amdgcn_readfirstlane(it / a.B);   // wave-uniform: keeps the cache bases in scalar registers
-    attn_decode_item<NWV, U>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
+    attn_decode_item<NWV, U, SH>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
     if (it + (int)gridDim.x < nitems) __syncthreads();   // the next item rewrites the hand-off tiles
   }
   if ((a.sem || a.prof) && threadIdx.x == 0) {     // turnstile release: the launch's last workgroup to finish admits the next KV stream
@@ -1290,13 +1293,15 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {   // the occupancy-cap experiments ask for more dynamic LDS than the 64 KB default
-#define AT_ATTR(W_, U_) do { hipError_t e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; } while (0)
+#define AT_ATTR(W_, U_) do { hipError_t e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; \
+                            e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; } while (0)
     AT_ATTR(16, 2); AT_ATTR(16, 4); AT_ATTR(16, 8); AT_ATTR(8, 2); AT_ATTR(8, 4); AT_ATTR(8, 8); AT_ATTR(4, 8); AT_ATTR(4, 16);
 #undef AT_ATTR
   });
   if (pad && attr_err != hipSuccess) return (int)attr_err;
   if (sem) hipLaunchKernelGGL(attn_gate_kernel, dim3(1), dim3(64), 0, st, sem, lanes);
-#define AT(W_, U_) hipLaunchKernelGGL((attn_decode_kernel<W_, U_>), dim3(grid), dim3(64 * W_), pad, st, a)
+#define AT(W_, U_) do { if (a.shared_len) hipLaunchKernelGGL((attn_decode_kernel<W_, U_, true>), dim3(grid), dim3(64 * W_), pad, st, a); \
+                        else hipLaunchKernelGGL((attn_decode_kernel<W_, U_, false>), dim3(grid), dim3(64 * W_), pad, st, a); } while (0)
   if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else if (g_tune.attn_unroll == 2) AT(16, 2); else AT(16, 4); }
   else if (g_tune.attn_waves == 4) { if (g_tune.attn_unroll == 16) AT(4, 16); else AT(4, 8); }      // light-occupancy experiment (round 5)
   else { if (g_tune.attn_unroll == 8) AT(8, 8); else if (g_tune.attn_unroll == 2) AT(8, 2); else AT(8, 4); }
