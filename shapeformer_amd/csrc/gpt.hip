@@ -437,7 +437,9 @@ struct AttnLds {
 // queue in front of the keys the scores wait for.  profiles/r04_b16_experiments.md)
 // SH: the launch has a shared prefix (a.shared_len != NULL).  The plain instance keeps ONE wave-uniform base per cache (scalar
 // registers, scalar-base loads); the per-lane choice between row 0's cache and the row's own costs a compare and two selects on a
-// 64-bit address per load, and the product instance (64 registers, 8 waves per SIMD) has no slack for them.
+// 64-bit address per load, and the product instance (64 registers, 8 waves per SIMD) has no slack for them: 893 -> 748 vector
+// instructions, 79 -> 43 scalar-spill reads, 7.36 -> 7.27 ms per 384-row step (bench 84.1 -> 86.3 shapes/s).  A further
+// specialisation on head dimension 64 (no column test) drops to 691 instructions but spills 20 bytes of vector registers: not taken.
 template <int NWV, int U, bool SH>
 __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs& a, const int b, const int h) {
   constexpr int KB = NWV * 4 * U;   // keys per batch of loads
