@@ -452,7 +452,7 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
   // shared prefix (sample_n copies of ONE condition, shapeformer.py:222-260): keys / values of positions < shared_len[0] were
   // written once, by row 0's prefill, and every row reads them from row 0's cache (one HBM read, L2 / Infinity-Cache hits
   // for the other rows); a row's own cache holds its tail only
-  const int nshared = SH ? a.shared_len[0] : 0;
+  const int nshared = (SH && a.shared_len) ? a.shared_len[0] : 0;
   const float* Kb0 = SH ? a.Kc + (long long)h * Lmax * HD : Kb;
   const float* Vb0 = SH ? a.Vc + (long long)h * Lmax * HD : Vb;
   const int c4 = lane & 15, kk = lane >> 4;
@@ -1295,15 +1295,17 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {   // the occupancy-cap experiments ask for more dynamic LDS than the 64 KB default
-#define AT_ATTR(W_, U_) do { hipError_t e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; \
+#define AT_ATTR(W_, U_) do { hipError_t e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_, W_ != 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; \
                             e_ = hipFuncSetAttribute((const void*)attn_decode_kernel<W_, U_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); if (e_ != hipSuccess) attr_err = e_; } while (0)
     AT_ATTR(16, 2); AT_ATTR(16, 4); AT_ATTR(16, 8); AT_ATTR(8, 2); AT_ATTR(8, 4); AT_ATTR(8, 8); AT_ATTR(4, 8); AT_ATTR(4, 16);
 #undef AT_ATTR
   });
   if (pad && attr_err != hipSuccess) return (int)attr_err;
   if (sem) hipLaunchKernelGGL(attn_gate_kernel, dim3(1), dim3(64), 0, st, sem, lanes);
-#define AT(W_, U_) do { if (a.shared_len) hipLaunchKernelGGL((attn_decode_kernel<W_, U_, true>), dim3(grid), dim3(64 * W_), pad, st, a); \
-                        else hipLaunchKernelGGL((attn_decode_kernel<W_, U_, false>), dim3(grid), dim3(64 * W_), pad, st, a); } while (0)
+  // the plain instance exists for the 16-wave shapes (the product's); the 8- / 4-wave experiment shapes keep the general one (the
+  // 8-wave plain instance spilled 12 bytes)
+#define AT(W_, U_) do { if (a.shared_len || W_ != 16) hipLaunchKernelGGL((attn_decode_kernel<W_, U_, true>), dim3(grid), dim3(64 * W_), pad, st, a); \
+                        else hipLaunchKernelGGL((attn_decode_kernel<W_, U_, W_ != 16>), dim3(grid), dim3(64 * W_), pad, st, a); } while (0)
   if (g_tune.attn_waves == 16) { if (g_tune.attn_unroll == 8) AT(16, 8); else if (g_tune.attn_unroll == 2) AT(16, 2); else AT(16, 4); }
   else if (g_tune.attn_waves == 4) { if (g_tune.attn_unroll == 16) AT(4, 16); else AT(4, 8); }      // light-occupancy experiment (round 5)
   else { if (g_tune.attn_unroll == 8) AT(8, 8); else if (g_tune.attn_unroll == 2) AT(8, 2); else AT(8, 4); }
