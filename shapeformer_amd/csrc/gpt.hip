@@ -438,7 +438,8 @@ struct AttnLds {
 // SH: the launch has a shared prefix (a.shared_len != NULL).  The plain instance keeps ONE wave-uniform base per cache (scalar
 // registers, scalar-base loads); the per-lane choice between row 0's cache and the row's own costs a compare and two selects on a
 // 64-bit address per load, and the product instance (64 registers, 8 waves per SIMD) has no slack for them: 893 -> 748 vector
-// instructions, 79 -> 43 scalar-spill reads, 7.36 -> 7.27 ms per 384-row step (bench 84.1 -> 86.3 shapes/s).  A further
+// instructions, 79 -> 43 scalar-spill reads, 7.36 -> 7.27 ms per 384-row step (bench 84.1 -> 86.3 shapes/s); with the unconditional
+// loads below 653 instructions and 7.08 ms (87.8).  A further
 // specialisation on head dimension 64 (no column test) drops to 691 instructions but spills 20 bytes of vector registers: not taken.
 template <int NWV, int U, bool SH>
 __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs& a, const int b, const int h) {
@@ -457,22 +458,36 @@ __device__ __forceinline__ void attn_decode_item(AttnLds<NWV>& s, const AttnArgs
   const float* Vb0 = SH ? a.Vc + (long long)h * Lmax * HD : Vb;
   const int c4 = lane & 15, kk = lane >> 4;
   const bool cok = c4 < nq4;
+  const float* safe = a.qkv + pk_off(b, 0, 3 * D);      // 16-byte aligned, finite: this row's packed q of the current step
   // the first batch of keys is requested BEFORE the q/k/v hand-off barrier (the loads only need `t`): the HBM latency of the
   // first batch overlaps the LDS round trip instead of following it
   auto load_k = [&](int i0, f32x4 (&kf)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
-      kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((SH && i < nshared ? Kb0 : Kb) + (long long)i * HD + 4 * c4));
+      if (SH) {
+        kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < t && cok) kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Kb0 : Kb) + (long long)i * HD + 4 * c4));
+      } else {
+        // plain instance: an UNCONDITIONAL load (no exec-mask region, no zero fill per load).  A lane without a cached key (i >= t,
+        // or a column beyond the head) reads the step's own q row instead - always finite - and its score is discarded below
+        const float* p = (i < t && cok) ? Kb + (i * HD + 4 * c4) : safe;
+        kf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+      }
     }
   };
   auto load_v = [&](int i0, f32x4 (&vf)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * (NWV * 4) + wave * 4 + kk;
-      vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((SH && i < nshared ? Vb0 : Vb) + (long long)i * HD + 4 * c4));
+      if (SH) {
+        vf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < t && cok) vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((i < nshared ? Vb0 : Vb) + (long long)i * HD + 4 * c4));
+      } else {
+        // (a finite stand-in value times a probability of exactly 0 adds +-0 to the accumulator: the sums are unchanged bit for bit)
+        const float* p = (i < t && cok) ? Vb + (i * HD + 4 * c4) : safe;
+        vf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+      }
     }
   };
   f32x4 kf0[U], vf0[U];
