@@ -313,6 +313,8 @@ def sample_n_sharded(gpt, c_tokens, Lc, sample_n, dist=None, **sample_kw):
     S = int(sample_n)
     world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
     rank = 0 if world == 1 else dist.get_rank()
+    if world > 1 and S < world and sample_kw.get("stop_early", True):      # decided identically on every rank: nobody enters a collective
+        raise ValueError("sample_n_sharded: fewer sequences than ranks with the early stop on (a rank without rows cannot follow the stop votes)")
     lo, hi = S * rank // world, S * (rank + 1) // world
     if hi - lo > 4 * gpt.MAX_CHAIN_ROWS:
         raise ValueError(f"sample_n_sharded: {hi - lo} rows on one rank (at most {4 * gpt.MAX_CHAIN_ROWS}: successive rounds stop independently)")
@@ -331,8 +333,6 @@ def sample_n_sharded(gpt, c_tokens, Lc, sample_n, dist=None, **sample_kw):
             return bool(t.item())
         res = gpt.sample(rows, lens, row_offset=lo, rows_total=S, ended_reduce=ended_reduce, to_host=True, **sample_kw)
         res = {k: v for k, v in res.items() if k in ("samples", "log_prob", "steps")}
-    elif world > 1 and sample_kw.get("stop_early", True):
-        raise ValueError("sample_n_sharded: fewer sequences than ranks with the early stop on (a rank without rows cannot follow the stop checks)")
     if world == 1:
         return res
     parts = [None] * world

@@ -175,6 +175,33 @@ ok = ok and torch.allclose(flat[30:40], 3.0 + mean[30:40]) and rs.params_in_flig
 for name in rs.params_in_flight():
     ok = ok and rs.wait_params(name)
 ok = ok and torch.allclose(flat, 3.0 + mean) and rs.params_in_flight() == []
+# SURVEY 8(e) single-shape option (dist.sample_n_sharded): row split, collective early stop, gather in global row order - with a
+# stand-in sampler (the real one needs the GPU: tests/test_ddp_gpu.py).  Row g "ends" after g + 2 checks; the loop may stop only
+# when EVERY row of EVERY rank has ended: 7 rows -> after check 8, on both ranks.
+class FakeGPT:
+    MAX_CHAIN_ROWS, dev = 192, "cpu"
+    def sample(self, rows, lens, row_offset=0, rows_total=None, ended_reduce=None, to_host=True, max_steps=64, check_every=4, stop_early=True, **kw):
+        n, checks, done = rows.shape[0], 0, 0
+        assert rows_total == 7 and kw.get("shared_prefix") == "auto" and bool((rows == rows[:1]).all())
+        while done < max_steps:
+            done += check_every; checks += 1
+            mine = all(checks >= row_offset + j + 2 for j in range(n))
+            if stop_early and ended_reduce(mine):
+                break
+        g = torch.arange(row_offset, row_offset + n)
+        return dict(samples=(g[:, None, None] * 100 + torch.arange(done)[None, :, None] + torch.zeros(1, 1, 2, dtype=torch.long)),
+                    log_prob=g[:, None, None].float() * torch.ones(1, done, 2), steps=done, state="not gathered")
+c1 = torch.full((1, 5, 2), 3, dtype=torch.int32)
+r = D.sample_n_sharded(FakeGPT(), c1, torch.tensor([5], dtype=torch.int32), 7, dist, max_steps=64, check_every=4)
+ok = ok and r["steps"] == 32 and r["samples"].shape == (7, 32, 2) and r["samples"][:, 0, 0].tolist() == [0, 100, 200, 300, 400, 500, 600]
+ok = ok and r["log_prob"][:, 0, 0].tolist() == [0., 1., 2., 3., 4., 5., 6.] and "state" not in r
+r = D.sample_n_sharded(FakeGPT(), c1, torch.tensor([5], dtype=torch.int32), 7, dist, max_steps=12, check_every=4, stop_early=False)
+ok = ok and r["steps"] == 12 and r["samples"].shape == (7, 12, 2)
+try:
+    D.sample_n_sharded(FakeGPT(), c1, torch.tensor([5], dtype=torch.int32), 1, dist)       # fewer sequences than ranks, early stop on:
+    ok = False                                                                              # refused on EVERY rank (nobody waits in a collective)
+except ValueError:
+    pass
 print("OK" if ok and t.item() == world else "FAIL", flush=True)
 dist.barrier(); dist.destroy_process_group()
 """
