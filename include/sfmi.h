@@ -31,6 +31,14 @@ int sfmi_version(void);
 /* one wavefront busy for `ticks` of the 100 MHz wall clock (<= 1 s) on `stream`: the stream-concurrency probe of the interleaved
  * decode chains (no reference counterpart: the reference runs one chain on one stream, shapeformer.py:85-132) */
 int sfmi_stream_spin(long long ticks, void* stream);
+/* [host] a HIP stream restricted to the compute units whose bit is set in mask[0 .. words) (bit i of word i / 32; consecutive bits go round
+ * the 8 XCDs of gfx950) / its release.  Measurement plumbing for the CU-partition experiments (profiles/r06_overlap.md); no reference
+ * counterpart and no use on the product path. */
+int sfmi_stream_create_cumask(const unsigned* mask, int words, void** stream_out);
+int sfmi_stream_destroy(void* stream);
+/* [measurement plumbing] out[2 wg] = {XCC_ID, HW_ID} hardware registers of each of `blocks` workgroups (kept resident `ticks` x 10 ns): which
+ * compute units a (masked) stream really uses */
+int sfmi_hwid_probe(unsigned* out, int blocks, int threads, long long ticks, void* stream);
 /* [host] launch-shape tuning knobs of the decode step (performance only - no knob changes a result bit unless its comment in
  * csrc/gpt.hip says so); read at launch time, so a captured hipGraph keeps the values it was captured with.  No reference
  * counterpart.  sfmi_tune_get returns -1 for an unknown name. */

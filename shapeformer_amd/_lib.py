@@ -21,6 +21,9 @@ i32, i64, sz, f32 = C.c_int, C.c_longlong, C.c_size_t, C.c_float
 PROTOTYPES = {
     "sfmi_version": (i32, []),
     "sfmi_stream_spin": (i32, [i64, c_ptr]),
+    "sfmi_stream_create_cumask": (i32, [c_ptr, i32, c_ptr]),
+    "sfmi_stream_destroy": (i32, [c_ptr]),
+    "sfmi_hwid_probe": (i32, [c_ptr, i32, i32, i64, c_ptr]),
     "sfmi_tune_set": (i32, [C.c_char_p, i32]),
     "sfmi_tune_get": (i32, [C.c_char_p]),
     "sfmi_tune_generation": (i32, []),

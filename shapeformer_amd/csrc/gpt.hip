@@ -169,6 +169,7 @@ struct DGemmArgs {
   int M, N, K, ldo /*row stride when out is row-major (out_packed == 0)*/, ln, act, out_packed;
   float* slab; int* cnt;   // split-K scratch: ceil(M/16)*ceil(N/16)*S*320 floats, ceil(M/16)*ceil(N/16) ints (zeroed once)
   int* pblk; unsigned long long* prof;   // optional in-situ launch timing (prof_begin / prof_end_last)
+  int prio;                              // s_setprio level of every wave of the launch (0 = hardware default; knob dgemm_prio)
 };
 
 // Decode activations live in MFMA-fragment-packed layout: an (M x N) tensor is stored as
@@ -217,6 +218,8 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs a) {
   __shared__ float st1[NW][MT][16], st2[NW][MT][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, ml = lane & 15;
   const int sp = blockIdx.y, S = gridDim.y;
+  // wave priority (the immediate has to be a constant): beside another chain's KV stream the MFMA family then wins the SIMD's issue slots
+  if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
   prof_begin(a.prof, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
   const int ntiles = (a.N + 15) >> 4;
   const int nt0 = blockIdx.x * NT;             // first n-tile of this workgroup (an odd tile count: the last workgroup's second tile is masked)
@@ -1170,7 +1173,7 @@ static int decode_gemm_launch(const float* x, const float* Wp16, const float* c1
   if (kslice % (16 * NWv)) return SFMI_EINVAL;
   DGemmArgs a;
   a.x = x; a.Wp = Wp16; a.c1 = c1; a.c2 = c2; a.resid = resid; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.ln = ln; a.act = act;
-  a.out_packed = out_packed; a.slab = slab; a.cnt = cnt; a.pblk = pblk; a.prof = prof;
+  a.out_packed = out_packed; a.slab = slab; a.cnt = cnt; a.pblk = pblk; a.prof = prof; a.prio = g_tune.dgemm_prio;
   hipStream_t st = (hipStream_t)stream;
   if ((g_tune.dgemm_nt2 == 2 || (g_tune.dgemm_nt2 == 1 && tiles % 3 == 0)) && NWv == 8 && (kslice / 8 / 16) % 2 == 0 && tiles >= 3) {
     // two n-tiles per wave, row groups of <= 3 row tiles, batches of two k16-steps: 5 operand loads per 24 MFMAs (7 in the one-tile

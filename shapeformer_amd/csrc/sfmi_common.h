@@ -103,5 +103,7 @@ __device__ __forceinline__ float sfmi_dropout_mul(unsigned seed, unsigned idx, f
 //   sk_stagger  : experiment: the second resident workgroup of a CU starts `sk_stagger` x 256 cycles late (0 = off; bit-identical)
 //   enc_fused   : 1 (default) = the five per-point stages of the local-pool encoder in one launch (run-aligned workgroups, csrc/encoder.hip
 //                 enc_fused_kernel); 0 = one launch per stage (round 1-4 form).  Bit-identical to each other.
-struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse, sk_grid, sk_tile, sk_loop, sk_stagger, enc_fused; };
+//   dgemm_prio  : wave priority (s_setprio 0..3) of the decode GEMM's waves: beside the KV stream of another chain the two families
+//                 share each SIMD's issue slots; 0 = the hardware default (round 6 A/B, profiles/r06_overlap.md).  Scheduling only.
+struct SfmiTune { int attn_blocks, attn_unroll, attn_waves, attn_lds_pad, sdf_blocks, dgemm_nt2, dgemm_nw, dgemm_un, conv_xreuse, sk_grid, sk_tile, sk_loop, sk_stagger, enc_fused, dgemm_prio; };
 extern SfmiTune g_sfmi_tune;

@@ -8,7 +8,11 @@ with HIP events, optionally with one kernel family disabled (timing-only ablatio
 A configuration line is `name key=value ...`; keys: the sfmi_tune_set knobs (attn_blocks, attn_unroll, attn_waves,
 attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `lanes=` (gpt.ATTN_LANES: attention turnstile, at most that many
 chains stream their KV cache at a time), `prefetch=` (gpt.PREFETCH_BLOCKS: Infinity-Cache weight prefetch branch of a single chain),
-`profile=attn,gemm` (in-situ launch timing: prints launches and mean us per family).  Lines starting with # are skipped.
+`profile=attn,gemm` (in-situ launch timing: prints launches and mean us per family), `cus=<n>` (every chain on a stream restricted to
+the first n compute-unit mask bits = n / 8 CUs of every XCD; hipExtStreamCreateWithCUMask), `cusplit=<n>` (chains 0, 1 on the first n
+bits, chains 2, 3 on the other 256 - n: spatial partition of the two kernel families together with a per-chain ablate=),
+`cumode=block` (mask bits taken as contiguous blocks instead: bits [0, n) vs [n, 256)), `hwid=1` (print which XCC / SE / CU the masked
+streams' workgroups land on).  Lines starting with # are skipped.
 Condition lengths are uniform in [100, 216] (mean 158 = the bench's synthetic clouds); positions ascending, end-token closed.
 """
 from __future__ import annotations
@@ -149,6 +153,19 @@ def main():
                 ops.sdf_query_grid(bgst["axis"], bgst["grid"], bgst["vq"].sdf_w, sigmoid=True, out=bgst["out"])
                 e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
         return evs
+    import ctypes
+    mask_streams = {}
+
+    def hwid_report(stream, tag):
+        out_ = torch.zeros(2 * 2048, device=dev, dtype=torch.int32)
+        L.check(lib.sfmi_hwid_probe(out_.data_ptr(), 2048, 256, 20000, stream.cuda_stream), "sfmi_hwid_probe")
+        stream.synchronize()
+        v = out_.cpu().numpy().astype(np.uint32).reshape(-1, 2)
+        xcc, hw = v[:, 0] & 0xf, v[:, 1]
+        cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
+        ids = sorted(set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist())))
+        per_x = {x: sum(1 for i in ids if i[0] == x) for x in sorted(set(xcc.tolist()))}
+        say(f"#   hwid {tag}: {len(ids)} distinct (xcc, se, sh, cu); per XCC {per_x}; SE ids {sorted(set(se.tolist()))} CU ids {sorted(set(cu.tolist()))}")
     cache = {}
     for line in sys.stdin:
         line = line.strip()
@@ -163,6 +180,33 @@ def main():
         gpt.S_PROJ_M, gpt.S_FC2 = int(kv.pop("sproj", "1")), int(kv.pop("sfc2", "4"))      # in-kernel split-K of proj / fc2 (part of the graph key)
         gpt._profile = kv.pop("profile", "")
         bg = kv.pop("bgsdf", None)
+        cus, cusplit, cumode, hwid = int(kv.pop("cus", "0")), int(kv.pop("cusplit", "0")), kv.pop("cumode", "interleave"), int(kv.pop("hwid", "0"))
+        if cus or cusplit:
+            # masked streams, one per chain (every CU-masked stream owns a hardware queue); chain i of a split takes side i // 2
+            n_a = cus or cusplit
+            sides = [tuple(range(n_a)), tuple(range(n_a, 256))]
+            if cumode == "xcdblock":      # whole XCDs: bit b belongs to XCD b % 8 under the interleaved map
+                nx = n_a // 32
+                sides = [tuple(b for b in range(256) if b % 8 < nx), tuple(b for b in range(256) if b % 8 >= nx)]
+            chain_bits = [sides[0] if (cus or i < chains // 2) else sides[1] for i in range(chains)]
+            streams_ = []
+            for i, b in enumerate(chain_bits):      # one stream object per chain (two chains of a side must not share a queue)
+                k2 = ("chain", i, b)
+                if k2 not in mask_streams:
+                    words = (ctypes.c_uint * 8)()
+                    for bit in b:
+                        words[bit // 32] |= 1 << (bit % 32)
+                    sp_ = ctypes.c_void_p()
+                    L.check(lib.sfmi_stream_create_cumask(words, 8, ctypes.byref(sp_)), "sfmi_stream_create_cumask")
+                    mask_streams[k2] = torch.cuda.ExternalStream(sp_.value, device=dev)
+                streams_.append(mask_streams[k2])
+            gpt._mb_streams, gpt._mb_shared_queue = streams_, False
+            if hwid:
+                for i in sorted({0, chains - 1}):
+                    hwid_report(streams_[i], f"chain {i} ({len(chain_bits[i])} mask bits, {cumode})")
+        elif getattr(gpt, "_masked_prev", False):
+            gpt._mb_streams = []          # back to probed plain streams
+        gpt._masked_prev = bool(cus or cusplit)
         for k, v in defaults.items():
             L.check(lib.sfmi_tune_set(k.encode(), int(kv.pop(k, v))), f"tune {k}")
         for k, v in kv.items():
@@ -216,6 +260,8 @@ def main():
             if gpt._profile:
                 pr = gpt.launch_profile(reset=True)
                 bginfo += "   in situ: " + ", ".join(f"{k} {n} launches x {us:.2f} us" for k, (n, us) in pr.items() if n)
+            if cus or cusplit:      # did the run keep the masked streams (gpt._chain_streams re-probes a set that fails its overlap check)?
+                bginfo += "   masked streams " + ("kept" if all(x is y for x, y in zip(gpt._mb_streams, streams_)) else "REPLACED by the stream probe")
             say(f"{name:28s} rows {rows} chains {chains} {' '.join(kvs):50s} ms/step " + " ".join(f"{m:.3f}" for m in ms)
                 + f"   rows/ms {rows / min(ms):.1f}" + (f"   turnstile tickets {sem[0]} time-outs {sem[2]}" if gpt.ATTN_LANES else "") + bginfo + pw)
         except Exception as e:   # keep sweeping
