@@ -390,8 +390,10 @@ def config3_record(pipe, gpt, Xct, a):
     ts = []
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        r = pipe.complete(X16, max_steps=a.ar_steps, decode_res=a.decode_res, seed=it, stop_early=False, sigmoid=True)
+        r = pipe.complete(X16, max_steps=a.ar_steps, decode_res=a.decode_res, seed=CHECK_SEED + it, stop_early=False, sigmoid=True)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        if it == 0:      # BASELINE config 3's own batch: its sampled tokens against the committed checksum, like the headline batch's
+            rec["batch16_tokens"] = token_checksums(r, 16, a)
     assert int(r["steps"]) == a.ar_steps
     rec["batch16_whole_path"] = {"shapes_per_s": round(16 / min(ts[1:]), 2), "ms_per_step": round(min(ts[1:]) * 1e3, 1),
                                  "note": "16 different shapes, encode -> 512 AR steps (one 16-row chain) -> UNet + 128^3 SDF query"}
@@ -477,12 +479,15 @@ def train_record(gpt, a, batches=(1, 8), steps=5, warm=2):
 CHECK_SEED = 1000
 
 
-def token_checksums(r, B, a):
+def token_checksums(r, B, a, seed=None):
     """CRC-32 of the tokens the AR loop sampled in the fixed-seed pass (row 0 and all rows: int32 (pos, val) pairs of the `ar_steps`
     generated positions), compared with the value committed in tests/golden/bench_token_checksums.json for this exact workload
     (the run is deterministic: counter-hash uniforms, no float atomics, fixed summation orders).  A mismatch means the sampled
-    sequences changed - a kernel's rounding, the sampler, or the input selection - and is reported in the line, never hidden."""
+    sequences changed - a kernel's rounding, the sampler, or the input selection: it is reported in the line AND the run exits
+    non-zero after printing it (main: `token_crc_ok` false anywhere in the line) - the checksum is what ties the timed kernels to the
+    parity suite."""
     import zlib
+    seed = CHECK_SEED if seed is None else seed
     st = r["state"]
     seq, lc = st["seq"].cpu().numpy(), st["Lc"].cpu().numpy()
     rows = [np.ascontiguousarray(seq[b, lc[b]:lc[b] + a.ar_steps]).astype(np.int32) for b in range(seq.shape[0])]
@@ -490,7 +495,7 @@ def token_checksums(r, B, a):
     crc_all = 0
     for x in rows:
         crc_all = zlib.crc32(x.tobytes(), crc_all)
-    key = f"batch{B}_arsteps{a.ar_steps}_points{a.points}_seed{CHECK_SEED}"
+    key = f"batch{B}_arsteps{a.ar_steps}_points{a.points}_seed{seed}"
     path = os.path.join(ROOT, "tests", "golden", "bench_token_checksums.json")
     want = json.load(open(path)).get(key) if os.path.exists(path) else None
     out = {"token_crc32_row0": crc0, "token_crc32_all_rows": crc_all, "token_crc_key": key,
@@ -577,6 +582,7 @@ def main_train(a, rank, world, dev, dist):
 def main():
     a = parse()
     launch_ranks(a)
+    crc_failed = False
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -824,9 +830,17 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline_kv"], line["cpu_baseline"] = cpu_baseline(a.points, a.ar_steps, a.decode_res)
         print(json.dumps(line), flush=True)
+        bad = [k for k, v in (("headline", line.get("sanity", {})), ("config3.batch16", line.get("config3", {}).get("batch16_tokens", {})))
+               if v.get("token_crc_ok") is False]
+        if bad:
+            crc_failed = True
+            print(f"bench.py: FATAL sampled tokens differ from tests/golden/bench_token_checksums.json ({', '.join(bad)}): the timed kernels "
+                  "no longer produce the sequences the parity suite pinned", file=sys.stderr, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if crc_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

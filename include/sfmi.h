@@ -161,6 +161,10 @@ int sfmi_ce_rows_f32(const float* logits, const int* target, float* loss, long l
 int sfmi_decode_gemm_padded_rows(int M);
 size_t sfmi_skinny16_pack_floats(int N, int K);
 int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out); /* [host] (N,K) -> [N/16][K/16][64][4] */
+/* the same on the device, with the LayerNorm in front of the Linear folded in (mingpt.py:103-111: LN(x) W^T + b = rstd (x W'^T - mean c1) + c2,
+ * W' = W diag(gamma), c1 = rowsum(W'), c2 = W beta + b; float64 row sums); gamma = beta = c1 = c2 = NULL: plain pack */
+int sfmi_ln_fold_pack_f32(const float* W, const float* gamma, const float* beta, const float* bias, float* Wp, float* c1, float* c2, int N,
+                          int K, void* stream);
 size_t sfmi_decode_gemm_slab_floats(int M, int N, int S);
 int sfmi_decode_gemm_f32(const float* x, const float* Wp16, const float* c1, const float* c2, const float* resid, float* out,
                          int M, int N, int K, int ldo, int ln, int act, int out_packed, int S, float* slab, int* cnt, void* stream);
@@ -276,6 +280,8 @@ int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpac
 /* structured Q^3 lattice of nputil.makeGrid 'ij' (xgutils/nputil.py:618-654) from a Q-entry f32 axis table */
 int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, const float* wpack, float* out, int B, int G,
                             int apply_sigmoid, void* stream);
+/* nputil.sigmoid over stored logits (vqdif.py:262, shapeformer.py:388): y = 1 / (1 + exp(-x)), the fused epilogue's expression; may alias */
+int sfmi_sigmoid_f32(const float* x, float* y, long long n, void* stream);
 
 /* ---- Training step of the VQDIF autoencoder (csrc/train_vqdif.hip): vqdif.py:78-137 (forward, VQLoss,
  *      Adam), quantizer.py:68-89 (EMA codebook, straight-through), backward of enc.py:66-140, updown.py:79-132,

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "sfmi_sdf_pack_weights": (i32, [c_ptr] * 11),
     "sfmi_sdf_query_f32": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i32, i64, i32, i32, c_ptr]),
     "sfmi_sdf_query_grid_f32": (i32, [c_ptr, i32, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
+    "sfmi_sigmoid_f32": (i32, [c_ptr, c_ptr, i64, c_ptr]),
     # encoder (per-point path)
     "sfmi_enc_pack_floats": (sz, []),
     "sfmi_enc_pack_weights": (i32, [c_ptr] * 10),
@@ -90,6 +91,7 @@ PROTOTYPES = {
     "sfmi_decode_gemm_padded_rows": (i32, [i32]),
     "sfmi_skinny16_pack_floats": (sz, [i32, i32]),
     "sfmi_skinny16_pack_weight": (i32, [c_ptr, i32, i32, c_ptr]),
+    "sfmi_ln_fold_pack_f32": (i32, [c_ptr] * 7 + [i32, i32, c_ptr]),
     "sfmi_gpt_embed_f32": (i32, [c_ptr] * 15 + [i32] * 5 + [c_ptr, i32, c_ptr]),
     "sfmi_gpt_rowprep_f32": (i32, [c_ptr] * 12 + [i32] * 5 + [c_ptr, i32, c_ptr]),
     "sfmi_sgemm_mfma_splits": (i32, [i32, i32, i32]),

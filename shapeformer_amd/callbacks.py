@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from . import meshio, tokens as T
+from . import meshio, ops, tokens as T
 from .dist import effective_indices
 
 
@@ -123,7 +123,7 @@ class VisSparseRecon3D(VisCallback):
         for b in range(th.shape[0]):
             t = filter_end_tokens(th[b, :lh[b]], self.end_tokens)
             rows.append(np.concatenate([np.full((len(t), 1), b, np.int64), t], 1))
-        self._occ_dev = torch.sigmoid(logits[..., 0])                        # stays in HBM for the mesh extraction
+        self._occ_dev = ops.sigmoid(logits)[..., 0]                          # stays in HBM for the mesh extraction
         return _np({"logits": logits, "quant_ind": raw.long(), "sparse": np.concatenate(rows, 0),
                     "grid_mask": mask.bool(), "batch": batch})
 
@@ -134,7 +134,7 @@ class VisSparseRecon3D(VisCallback):
         occ = getattr(self, "_occ_dev", None)
         if occ is None or occ.shape[-1] != Q ** 3:
             dev = getattr(self.pl_module, "core", self.pl_module).dev
-            occ = torch.sigmoid(torch.as_tensor(computed["logits"]).to(dev)[..., 0])     # nputil.sigmoid(logits)
+            occ = ops.sigmoid(torch.as_tensor(computed["logits"]).to(dev))[..., 0]       # nputil.sigmoid(logits)
         self._occ_dev = None
         v, f, voff, toff = mcubes.marching_cubes_dev(occ[:1].reshape(1, Q, Q, Q), self.thresh)
         vert, face = v.cpu().numpy().astype(np.float64), f.cpu().numpy().astype(int)

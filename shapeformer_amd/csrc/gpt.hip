@@ -1147,6 +1147,42 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   if (tid == 0) loss[m] = mx + __logf((red[4] + red[5]) + (red[6] + red[7])) - row[target[m]];
 }
 
+// Decode-path weights from the raw parameters (load time, and after a training -> sampling switch): one workgroup per 16-row n-tile of
+// W (N,K).  Wp = fragment order of W' = W diag(gamma) (gamma NULL: W itself); c1[n] = sum_k W'[n][k]; c2[n] = sum_k beta[k] W[n][k] + bias[n]
+// (the constants of dgemm_kernel's LayerNorm form).  The two row sums are accumulated in float64 in a fixed order (16 partial sums of
+// contiguous K ranges per row, added in range order) and rounded once: deterministic, and closer to the exact constants than an f32 sum.
+__global__ __launch_bounds__(256) void ln_fold_pack_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ bias, float* __restrict__ Wp, float* __restrict__ c1,
+                                                          float* __restrict__ c2, int N, int K) {
+  __shared__ double p1[16][17], p2[16][17];
+  const int nt = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 16 * K; i += 256) {      // fragment order [K/16][64 lanes][4]: lane = (k % 16 / 4) * 16 + row, j = k % 4
+    const int k16 = i >> 8, l = (i >> 2) & 63, j = i & 3;
+    const int n = nt * 16 + (l & 15), k = k16 * 16 + 4 * (l >> 4) + j;
+    float w = n < N ? W[(long long)n * K + k] : 0.0f;
+    if (gamma) w *= gamma[k];
+    Wp[(long long)nt * 16 * K + i] = w;
+  }
+  if (!c1) return;
+  const int r = tid >> 4, part = tid & 15, n = nt * 16 + r, kp = K / 16;
+  double s1 = 0.0, s2 = 0.0;
+  if (n < N)
+    for (int k = part * kp; k < (part + 1) * kp; ++k) {
+      const float w = W[(long long)n * K + k];
+      s1 += (double)(gamma ? w * gamma[k] : w);      // the f32 product the GEMM multiplies with
+      if (beta) s2 += (double)beta[k] * (double)w;
+    }
+  p1[r][part] = s1; p2[r][part] = s2;
+  __syncthreads();
+  if (part == 0) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < 16; ++q) { a += p1[r][q]; b += p2[r][q]; }
+    if (n < N && bias) b += (double)bias[n];
+    c1[nt * 16 + r] = (float)a;
+    c2[nt * 16 + r] = (float)b;
+  }
+}
+
 __global__ void set_len_kernel(int* len, const int* src, int B, int delta) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) len[i] = src[i] + delta;
@@ -1234,6 +1270,16 @@ int sfmi_skinny16_pack_weight(const float* W, int N, int K, float* out) {
           out[(((size_t)nt * (K / 16) + k16) * 64 + l) * 4 + j] = n < N ? W[(size_t)n * K + k] : 0.0f;
         }
       }
+  return SFMI_OK;
+}
+// device form of sfmi_skinny16_pack_weight with the LayerNorm fold of dgemm_kernel's header: W (N,K) row-major, gamma / beta (K) of the
+// LayerNorm in front of the Linear (mingpt.py:103-111; both NULL: plain pack), bias (N) or NULL -> Wp (ceil(N/16)*16*K floats), c1 / c2
+// (ceil(N/16)*16 floats each; NULL with a plain pack).  No library GEMV / reduction on the load path.
+int sfmi_ln_fold_pack_f32(const float* W, const float* gamma, const float* beta, const float* bias, float* Wp, float* c1, float* c2, int N,
+                          int K, void* stream) {
+  if (!W || !Wp || N <= 0 || K <= 0 || K % 16 || (!c1) != (!c2) || ((gamma || beta) && !c1)) return SFMI_EINVAL;
+  hipLaunchKernelGGL(ln_fold_pack_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, W, gamma, beta, bias, Wp, c1, c2, N, K);
+  SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
 // replaces LayerNorm + nn.Linear (+GELU / +residual) of Block.forward at decode time (mingpt.py:103-111).

@@ -233,6 +233,19 @@ int sfmi_sdf_pack_weights(const float* fc_p_w /*32x3*/, const float* fc_p_b, con
   return SFMI_OK;
 }
 
+// nputil.sigmoid over a logits tensor (the inference drivers keep the reference's `logits` result key and extract the mesh from the
+// occupancy, shapeformer.py:382-391 / vqdif.py:243-269): the expression of the fused epilogue above, as a grid-stride pass
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long n4 = n >> 2, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = 1.0f / (1.0f + __expf(-x[i]));
+}
+
 static int sdf_grid_dim(long long total_tiles) {
   long long wgs = (total_tiles + 7) / 8;
   if (wgs > g_sfmi_tune.sdf_blocks) wgs = g_sfmi_tune.sdf_blocks;   // default 512 = 256 CUs x 2 resident workgroups (LDS-limited), persistent tile loop
@@ -264,6 +277,15 @@ int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, cons
   hipLaunchKernelGGL(sdf_query_kernel<true>, dim3(sdf_grid_dim(tiles)), dim3(512),
                      SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, nullptr, axis, grid_cl, wpack,
                      out, B, N, G, Q, apply_sigmoid);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// replaces nputil.sigmoid(logits) of the inference drivers (vqdif.py:262, shapeformer.py:388); x and y 16-byte aligned, may alias
+int sfmi_sigmoid_f32(const float* x, float* y, long long n, void* stream) {
+  if (!x || !y || n <= 0) return SFMI_EINVAL;
+  const long long wgs = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)(wgs < 1 ? 1 : wgs > 4096 ? 4096 : wgs)), dim3(256), 0, (hipStream_t)stream, x, y, n);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -316,8 +316,20 @@ def sample_n_sharded(gpt, c_tokens, Lc, sample_n, dist=None, **sample_kw):
     if world > 1 and S < world and sample_kw.get("stop_early", True):      # decided identically on every rank: nobody enters a collective
         raise ValueError("sample_n_sharded: fewer sequences than ranks with the early stop on (a rank without rows cannot follow the stop votes)")
     lo, hi = S * rank // world, S * (rank + 1) // world
-    if hi - lo > 4 * gpt.MAX_CHAIN_ROWS:
-        raise ValueError(f"sample_n_sharded: {hi - lo} rows on one rank (at most {4 * gpt.MAX_CHAIN_ROWS}: successive rounds stop independently)")
+    biggest = -(-S // world)        # the largest shard of any rank: the limit is tested on a rank-independent number, so EVERY rank raises
+    if biggest > 4 * gpt.MAX_CHAIN_ROWS:
+        raise ValueError(f"sample_n_sharded: {biggest} rows on one rank (at most {4 * gpt.MAX_CHAIN_ROWS}: successive rounds stop independently)")
+    if world > 1:
+        # every rank must hold the SAME condition (the reference's inference sharding hands the ranks different items: enabling this
+        # option under that split would gather rows of different shapes into one result): compare a checksum before anyone samples
+        import zlib
+        ct = torch.as_tensor(c_tokens)[:1].to("cpu", torch.int64).contiguous()
+        n = int(torch.as_tensor(Lc).reshape(-1)[0])
+        h = zlib.crc32(ct[0, :n].numpy().tobytes(), n) & 0x7fffffff
+        t = torch.tensor([h, -h], dtype=torch.int64, device=gpt.dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # max(h) == -max(-h) = min(h) iff all ranks agree
+        if int(t[0]) != -int(t[1]):
+            raise ValueError("sample_n_sharded: the ranks hold different conditions (c_tokens / Lc); the sample_n split needs ONE shape on every rank")
     sample_kw = dict(sample_kw)
     sample_kw.setdefault("shared_prefix", "auto")
     res = None

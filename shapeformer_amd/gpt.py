@@ -81,6 +81,15 @@ class CondTupleGPT:
         self._profile = ""
         self._sem = torch.zeros(4, device=self.dev, dtype=torch.int32)   # attention turnstile {next ticket, finished, time-outs}
 
+    def _sync_params(self):
+        """A trainer that leaves parameter updates in flight (train.GPTTrainer, grad_sync "rs_ag": all-gathers waited for lazily by the next
+        training forward) registers its drain here; every OTHER reader of the parameter tensors - sampling, the teacher-forced forward,
+        state_dict, the decode-weight refresh - calls it first, whichever entry point it came through."""
+        ref = getattr(self, "_param_sync", None)      # weakref.WeakMethod: the model must not keep a dropped trainer (3.9 GB) alive
+        hook = ref() if ref is not None else None
+        if hook is not None:
+            hook()
+
     def get_block_size(self):
         return self.Lmax
 
@@ -92,6 +101,7 @@ class CondTupleGPT:
     def state_dict(self):
         """The reference's 419-tensor key set (mingpt.py:187-254) from the live device parameters: the fused QKV
         rows are split back into query / key / value, the causal-mask buffers are regenerated (tril), tensors on the CPU."""
+        self._sync_params()
         D, sd = self.D, {}
         cpu = lambda t: t.detach().cpu().clone()
         sd["pos_emb"], sd["cond_pos_emb"] = cpu(self.pos_emb).view(1, -1, D), cpu(self.cond_pos_emb).view(1, -1, D)
@@ -156,19 +166,19 @@ class CondTupleGPT:
         (csrc/gpt.hip dgemm_kernel):  LN(x) W^T + b = rstd (x W'^T - mean c1) + c2,  W' = W diag(gamma),
         c1 = rowsum(W'), c2 = W beta + b; all matrices in 16x16x4-MFMA fragment order.  Call after the raw
         weights change (training)."""
-        def fold(w, bias, ln):
-            gam, bet = ln
-            wp = w * gam[None, :]
-            c1 = wp.sum(1)
-            c2 = w @ bet + (bias if bias is not None else 0)
-            pad = (-w.shape[0]) % 16
-            if pad:
-                c1, c2 = torch.cat([c1, c1.new_zeros(pad)]), torch.cat([c2, c2.new_zeros(pad)])
-            return pack_skinny16(wp), c1.contiguous(), c2.contiguous()
+        self._sync_params()
+        def fold(w, bias, ln):      # one in-tree launch per matrix (csrc/gpt.hip:ln_fold_pack_kernel): no library GEMV / reduction at load time
+            N, K = w.shape
+            Np = (N + 15) // 16 * 16
+            wp = torch.empty(Np * K, device=self.dev)
+            c1, c2 = (torch.empty(Np, device=self.dev), torch.empty(Np, device=self.dev)) if ln is not None else (None, None)
+            L.check(L.lib().sfmi_ln_fold_pack_f32(L.ptr(w), L.ptr(ln[0]) if ln else None, L.ptr(ln[1]) if ln else None, L.ptr(bias),
+                                                  L.ptr(wp), L.ptr(c1), L.ptr(c2), N, K, L.stream_ptr()), "sfmi_ln_fold_pack_f32")
+            return wp, c1, c2
         for ly in self.layers:
             ly.pqkv, ly.c1qkv, ly.c2qkv = fold(ly.wqkv, ly.bqkv, ly.ln1)
             ly.pfc1, ly.c1fc1, ly.c2fc1 = fold(ly.wfc1, ly.bfc1, ly.ln2)
-            ly.pproj, ly.pfc2 = pack_skinny16(ly.wproj), pack_skinny16(ly.wfc2)
+            ly.pproj, ly.pfc2 = fold(ly.wproj, None, None)[0], fold(ly.wfc2, None, None)[0]
         self.head_f = [fold(self.head_w[s], None, self.head_ln[s]) for s in range(2)]
         self._graphs = {}
         self._decode_stale = False
@@ -349,6 +359,7 @@ class CondTupleGPT:
     def forward(self, idx, extra_idx=None, L_cond=1, target_idx=None):
         """CondTupleGPT.forward: idx (B,L,2), extra_idx (B,L,1) or None (-> AR_N rule), target_idx (B,L,2)
         -> [logits_pos (B,L,V), logits_val (B,L,V)] (float32, on device)."""
+        self._sync_params()
         idx = torch.as_tensor(idx).to(self.dev, torch.int32)
         B, Lq, _ = idx.shape
         assert Lq <= self.Lmax, "Cannot forward, model block size is exhausted."   # mingpt.py:279
@@ -373,6 +384,7 @@ class CondTupleGPT:
     __call__ = forward
 
     def _forward_state(self, idx, extra_idx, L_cond):
+        self._sync_params()
         idx = torch.as_tensor(idx).to(self.dev, torch.int32)
         B, Lq, _ = idx.shape
         assert Lq <= self.Lmax, "Cannot forward, model block size is exhausted."   # mingpt.py:279
@@ -488,6 +500,7 @@ class CondTupleGPT:
         Lz = 0 if z_tokens is None else int(z_tokens.shape[1])
         if B > self.MAX_CHAIN_ROWS:
             raise L.SfmiError(f"a decode chain holds up to {self.MAX_CHAIN_ROWS} rows (larger batches run as several chains: sample / sample_microbatched)")
+        self._sync_params()
         if getattr(self, "_decode_stale", False):
             self.refresh_decode_weights()
         Lc_host = Lc.cpu().tolist()
@@ -629,7 +642,9 @@ class CondTupleGPT:
             while done < steps:
                 self.decode_step(st, B, sp)
                 done += 1
-                if stop_early and done % check_every == 0 and ended():
+                # the same check points as the graph loop and sample_microbatched: every check_every steps AND after the last step (a
+                # caller's ended_reduce is a collective: every process must reach it the same number of times whatever loop it runs)
+                if stop_early and (done % check_every == 0 or done == steps) and ended():
                     break
         if not to_host:   # device-resident result for the completion pipeline (no D2H of tokens)
             return dict(state=st, steps=done)

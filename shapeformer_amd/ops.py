@@ -49,6 +49,15 @@ def sdf_query(xyz, grid_cl, wpack, sigmoid=False, out=None):
     return out
 
 
+def sigmoid(x, out=None):
+    """nputil.sigmoid of a device logits tensor (in-tree kernel: the SDF query's own epilogue expression)."""
+    _chk_cuda(x)
+    x = _c(x, torch.float32)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().sfmi_sigmoid_f32(L.ptr(x), L.ptr(out), x.numel(), L.stream_ptr()), "sfmi_sigmoid_f32")
+    return out
+
+
 def sdf_query_grid(axis, grid_cl, wpack, sigmoid=False, out=None):
     """Structured Q^3 'ij' query grid from a Q-entry f32 axis table -> (B,Q^3,1)."""
     _chk_cuda(axis, grid_cl, wpack)

@@ -407,14 +407,16 @@ class ShapeFormerModel:
         c, z, _, _ = self.representer.get_indices(Xct, Xbd, stage=stage)
         return c, z
 
-    def make_trainer(self, optim_opt=None, dist=None, grad_sync="ring"):
+    def make_trainer(self, optim_opt=None, dist=None, grad_sync="ring", **trainer_kw):
         """AdamW trainer of the transformer (shapeformer.py:198-206).  dist: torch.distributed for data-parallel training
         (trainer.py:22,93); grad_sync "ring" = per-block all-reduce, "rs_ag" = reduce-scatter / sharded AdamW / all-gather (the weights
         are the same bit for bit).  `save_checkpoint` never runs a collective: with "rs_ag" it stores this rank's shard of the
         moments unless the training loop hands it the state it gathered on every rank (`trainer.gather_optimizer_state()`)."""
         from .train import GPTTrainer
         lr = (optim_opt or getattr(self, "optim_opt", None) or {}).get("lr", 1e-5)
-        self.trainer = GPTTrainer(self.transformer, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, dist=dist, grad_sync=grad_sync)
+        kw = dict(betas=(0.9, 0.95), weight_decay=0.01, grad_sync=grad_sync)
+        kw.update(trainer_kw)
+        self.trainer = GPTTrainer(self.transformer, lr=lr, dist=dist, **kw)
         return self.trainer
 
     def training_step(self, batch, batch_idx=0):
@@ -470,13 +472,15 @@ class ShapeFormerModel:
         tsd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
         if not tsd:
             raise KeyError(f"{path}: no transformer.* keys in the checkpoint")
+        old = getattr(self, "trainer", None)
+        if old is not None:
+            old.finish_param_gather()      # rs_ag: nothing of the old trainer may still be writing parameter tensors we are about to replace
         self.transformer.load_state_dict(tsd)
         vsd = {k[len(self._VQ):]: v for k, v in sd.items() if k.startswith(self._VQ)}
         if vsd:
             self.representer.vqvae_model.core.load_state_dict(vsd)
-        old = getattr(self, "trainer", None)
-        if old is not None:
-            self.make_trainer(dict(lr=old.lr), dist=old.dist)
+        if old is not None:      # same settings as the trainer it replaces (gradient mode, GEMM route, optimizer fusion, ...)
+            self.make_trainer(dict(lr=old.lr), dist=old.dist, **old.settings())
         st = _optimizer_state_of(ck)
         if resume_optimizer and st is not None:
             if old is None:

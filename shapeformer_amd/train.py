@@ -71,6 +71,11 @@ class GPTTrainer:
         are final - gradient collective waited for per bucket, AdamW launched per bucket on the side stream - so the 9 GB of optimizer
         traffic (HBM-bound) runs under the backward pass of the blocks below (MFMA-bound) instead of after it.  Same update, same bits."""
         assert gemm in ("sk", "tile")
+        # the constructor's own settings, so that a trainer can be rebuilt on new parameter tensors as it was (plugin.load_checkpoint)
+        self._settings = dict(betas=tuple(betas), weight_decay=weight_decay, eps=eps, pdrop=pdrop, dropout_seed=dropout_seed,
+                              single_rank_collectives=bool(single_rank_collectives), grad_sync=grad_sync, profile_waits=bool(profile_waits),
+                              gemm=gemm, overlap_param_gather=bool(overlap_param_gather), side_stream=bool(side_stream),
+                              fused_optimizer=bool(fused_optimizer))
         self.gemm_algo, self.overlap_param_gather, self.fused_optimizer = gemm, bool(overlap_param_gather), bool(fused_optimizer)
         self._fused = False
         # the per-bucket optimizer of the fused step gets a stream of its own: it has to wait for the bucket's gradient collective, and
@@ -125,6 +130,8 @@ class GPTTrainer:
                                    profile_waits=profile_waits)
         self._sync = False
         self._emb_range = rng["emb"]
+        import weakref
+        gpt._param_sync = weakref.WeakMethod(self.finish_param_gather)      # every non-training reader of the parameters drains the in-flight gathers first (gpt._sync_params)
         # order in which a forward pass first reads the buckets' parameters (the order the rs_ag parameter gathers are launched in)
         self._fwd_order = ["emb"] + [f"L{li}" for li in range(len(g.layers))] + ["heads"]
         lib = L.lib()
@@ -134,6 +141,10 @@ class GPTTrainer:
         self._sk_cnt = [torch.zeros(1 << 20, device=self.dev, dtype=torch.int32) for _ in range(ns)]            # tickets: zeroed once, re-armed by the kernel
         self._cr_cnt = [torch.zeros(4096, device=self.dev, dtype=torch.int32) for _ in range(ns)]               # same for the column reductions
         self._cr_part = [None] * ns
+
+    def settings(self):
+        """The keyword arguments this trainer was built with (besides the model, `lr` and `dist`)."""
+        return dict(self._settings)
 
     # ------------------------------------------------------------------ small wrappers
     def _f(self, *shape):
@@ -377,6 +388,12 @@ class GPTTrainer:
             # every gradient below is WRITTEN (GEMM / column-reduction epilogues), except the embedding tables: E0 is accumulated
             # twice and the positional tables only receive the rows the batch touches - those 57 MB are zeroed, not the 1.3 GB buffer
             lo, hi = self._emb_range
+            if getattr(self, "debug_poison_grads", False):
+                # debug: the claim above is checked - everything outside the embedding range starts as NaN and must have been overwritten
+                # (not added to) by the end of the backward pass; with grad_sync "rs_ag" the buffer holds PARAMETER values at this point,
+                # which a conditionally written gradient would silently absorb
+                self.flat_grad[:lo].fill_(float("nan"))
+                self.flat_grad[hi:].fill_(float("nan"))
             self.flat_grad[lo:hi].zero_()
         c = torch.as_tensor(c_indices).to(dev, torch.int32)
         z = torch.as_tensor(z_indices).to(dev, torch.int32)
@@ -544,6 +561,8 @@ class GPTTrainer:
                                         L.stream_ptr()), "colsum")
         self._ready("emb")
         self._join_side()      # the gradients of every block are complete on the main stream from here on
+        if getattr(self, "debug_poison_grads", False) and not accumulate and not self._fused and not (self._sync and self.buckets.active):
+            assert bool(torch.isfinite(self.flat_grad).all()), "a gradient range was not fully written by the backward pass"
         return loss
 
     # ------------------------------------------------------------------ optimizer / data parallel
@@ -653,6 +672,9 @@ class GPTTrainer:
         self.step_count += 1
         try:
             loss = self.loss_and_grad(c_indices, z_indices, sync=True, dropout_key=key, _fused=True)
+        except BaseException:
+            self.step_count -= 1       # no update was completed under this count
+            raise
         finally:
             self._fused = False
         self.buckets.end_step()

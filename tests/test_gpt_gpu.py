@@ -455,3 +455,34 @@ def test_decode_gemm_two_n_tile_form_and_row_groups_are_bit_identical(dev, M):
             assert torch.equal(a, b), (M, N, K, float((a - b).abs().max()))
     finally:
         L.check(lib.sfmi_tune_set(b"dgemm_nt2", 1), "tune")
+
+
+@pytest.mark.parametrize("N,K", [(3072, 1024), (50, 64), (4097, 1024)])
+def test_ln_fold_pack_kernel_against_host_pack_and_float64_sums(dev, N, K):
+    """csrc/gpt.hip ln_fold_pack_kernel (the decode weights' LayerNorm fold, mingpt.py:103-111): the fragment-ordered matrix must be the
+    host packer's (`sfmi_skinny16_pack_weight`) of W diag(gamma) bit for bit - rows beyond N zero - and c1 / c2 the float64 row sums
+    rounded once; gamma = beta = NULL is the plain pack."""
+    from shapeformer_amd import _lib as L
+    lib = L.lib()
+    rs = np.random.RandomState(N + K)
+    W = (rs.randn(N, K) * 0.05).astype(np.float32)
+    gam, bet, bias = (1 + 0.1 * rs.randn(K)).astype(np.float32), (0.1 * rs.randn(K)).astype(np.float32), rs.randn(N).astype(np.float32)
+    Np = (N + 15) // 16 * 16
+    t = lambda a: torch.from_numpy(a).to(dev)
+    Wd, gd, bd, biasd = t(W), t(gam), t(bet), t(bias)
+    wp, c1, c2 = torch.empty(Np * K, device=dev), torch.empty(Np, device=dev), torch.empty(Np, device=dev)
+    L.check(lib.sfmi_ln_fold_pack_f32(L.ptr(Wd), L.ptr(gd), L.ptr(bd), L.ptr(biasd), L.ptr(wp), L.ptr(c1), L.ptr(c2), N, K, L.stream_ptr()), "fold")
+    Wg = W * gam[None, :]                      # the f32 products the kernel forms
+    want = np.empty(Np * K, np.float32)
+    L.check(lib.sfmi_skinny16_pack_weight(Wg.ctypes.data, N, K, want.ctypes.data), "pack")
+    assert np.array_equal(wp.cpu().numpy(), want)
+    r1 = Wg.astype(np.float64).sum(1)
+    r2 = (W.astype(np.float64) * bet.astype(np.float64)[None, :]).sum(1) + bias
+    assert np.array_equal(c1.cpu().numpy()[N:], np.zeros(Np - N, np.float32)) and np.array_equal(c2.cpu().numpy()[N:], np.zeros(Np - N, np.float32))
+    # float64 sums in another association order: equal after the single rounding to f32 up to one ulp
+    assert np.allclose(c1.cpu().numpy()[:N], r1.astype(np.float32), rtol=2e-7, atol=1e-9)
+    assert np.allclose(c2.cpu().numpy()[:N], r2.astype(np.float32), rtol=2e-7, atol=1e-9)
+    wp2 = torch.empty(Np * K, device=dev)
+    L.check(lib.sfmi_ln_fold_pack_f32(L.ptr(Wd), None, None, None, L.ptr(wp2), None, None, N, K, L.stream_ptr()), "pack only")
+    L.check(lib.sfmi_skinny16_pack_weight(W.ctypes.data, N, K, want.ctypes.data), "pack")
+    assert np.array_equal(wp2.cpu().numpy(), want)

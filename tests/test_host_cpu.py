@@ -202,6 +202,16 @@ try:
     ok = False                                                                              # refused on EVERY rank (nobody waits in a collective)
 except ValueError:
     pass
+try:      # 2 x 768 + 1 rows: only rank 1's shard (769) is over the limit, but the test is on ceil(S / world): BOTH ranks refuse
+    D.sample_n_sharded(FakeGPT(), c1, torch.tensor([5], dtype=torch.int32), 2 * 4 * 192 + 1, dist, stop_early=False)
+    ok = False
+except ValueError as e:
+    ok = ok and "769 rows" in str(e)
+try:      # the ranks hold DIFFERENT conditions (the reference's item split): refused on every rank before anyone samples
+    D.sample_n_sharded(FakeGPT(), c1 + rank, torch.tensor([5], dtype=torch.int32), 7, dist, max_steps=8, check_every=4)
+    ok = False
+except ValueError as e:
+    ok = ok and "different conditions" in str(e)
 print("OK" if ok and t.item() == world else "FAIL", flush=True)
 dist.barrier(); dist.destroy_process_group()
 """

@@ -58,6 +58,7 @@ def test_loss_and_every_gradient_vs_oracle_autograd(dev):
     from shapeformer_amd.train import GPTTrainer
     sd, cfg, g, c, z = _setup(dev)
     tr = GPTTrainer(g)
+    tr.debug_poison_grads = True      # every gradient outside the embedding tables must be WRITTEN by the backward pass (the step only zeroes those)
     loss = tr.loss_and_grad(c, z).item()
     want_loss, og, _ = _oracle_grads(sd, cfg, c, z)
     assert abs(loss - want_loss) < 1e-5 * max(1.0, abs(want_loss))
