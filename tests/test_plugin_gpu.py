@@ -202,6 +202,46 @@ def test_checkpoint_resume_is_bit_exact_for_both_models(dev, tmp_path):
     assert v3.trainer.step_count == ck3["global_step"]
 
 
+def test_rs_ag_trainer_checkpoint_round_trip_through_the_plugin(dev, tmp_path):
+    """an rs_ag trainer (sharded AdamW, overlapped parameter gathers) saved and reloaded through ShapeFormerModel.save_checkpoint /
+    load_checkpoint.  The rebuilt trainer keeps the old one's settings (gradient mode, fusion, overlap), the rank-local optimizer shard is
+    accepted, and the resumed run continues with exactly the losses of the uninterrupted one.  One rank, gloo, collectives forced on
+    (the sharded code path with world 1); the callback-level sampling right after a training step drains the in-flight gathers."""
+    import torch.distributed as dist
+    from shapeformer_amd import plugin as P, synthetic
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    try:
+        b = synthetic.make_batch(9, 2, n_full=8192, n_partial=4096)
+        batch = {k: torch.from_numpy(v) for k, v in b.items()}
+
+        def steps(model, n, seed0):
+            out = []
+            for i in range(n):
+                np.random.seed(seed0 + i)
+                out.append(float(model.training_step(batch)))
+            return out
+        opt = P.get_opt(_opt())
+        m1 = P.instantiate_from_opt(opt["pl_model_opt"])
+        tr = m1.make_trainer(dict(lr=1e-3), dist=dist, grad_sync="rs_ag", single_rank_collectives=True)
+        assert tr.buckets.active and tr.buckets.mode == "rs_ag" and tr.settings()["single_rank_collectives"]
+        steps(m1, 2, 0)
+        assert tr.buckets.params_in_flight(), "the step leaves its parameter gathers to the next forward"
+        # a reader that goes straight to the transformer (what VisShapeFormer.compute_batch does) drains them through the model's hook
+        enc = m1.pipe.encode_cloud(batch["Xct"][:1].to(dev))
+        m1.transformer.sample(enc["c_tokens"], enc["Lc"], max_steps=4, stop_early=False)
+        assert not tr.buckets.params_in_flight()
+        path = m1.save_checkpoint(str(tmp_path / "ck" / "rsag.ckpt"))
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        assert ck["sfmi_optimizer_state"]["shard_ranges"] and ck["sfmi_optimizer_state"]["world"] == 1
+        want = steps(m1, 2, 2)
+        m1.load_checkpoint(path)                         # in place: the old trainer is rebuilt on the new tensors AS IT WAS
+        t2 = m1.trainer
+        assert t2 is not tr and t2.settings() == tr.settings() and t2.buckets.mode == "rs_ag" and t2.step_count == 2
+        assert steps(m1, 2, 2) == want
+    finally:
+        dist.destroy_process_group()
+
+
 def test_config1_demo_yaml_through_listdataset_and_callback(dev, tmp_path, monkeypatch):
     """BASELINE config 1 on the GPU box: `configs/demo/demo_vqdif.yaml` (its merged option tree, committed as
     tests/golden/demo_ds/demo_vqdif.yaml by oracle/make_golden_demo.py) through OUR plugin loader -> DataModule -> ListDataset

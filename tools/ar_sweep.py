@@ -182,31 +182,39 @@ def main():
         bg = kv.pop("bgsdf", None)
         cus, cusplit, cumode, hwid = int(kv.pop("cus", "0")), int(kv.pop("cusplit", "0")), kv.pop("cumode", "interleave"), int(kv.pop("hwid", "0"))
         if cus or cusplit:
-            # masked streams, one per chain (every CU-masked stream owns a hardware queue); chain i of a split takes side i // 2
+            # masked streams, one per chain (every CU-masked stream owns a hardware queue of its own: ROCclr never pools them); chain i of
+            # a split takes side i // 2.  The previous configuration's masked streams are destroyed first - call 1 of round 6 left ~100 of
+            # them alive and the later configurations ran on an oversubscribed queue set - and gpt._chain_streams is bypassed: its
+            # overlap probe replaced the masked streams by plain ones.
             n_a = cus or cusplit
             sides = [tuple(range(n_a)), tuple(range(n_a, 256))]
             if cumode == "xcdblock":      # whole XCDs: bit b belongs to XCD b % 8 under the interleaved map
                 nx = n_a // 32
                 sides = [tuple(b for b in range(256) if b % 8 < nx), tuple(b for b in range(256) if b % 8 >= nx)]
             chain_bits = [sides[0] if (cus or i < chains // 2) else sides[1] for i in range(chains)]
-            streams_ = []
-            for i, b in enumerate(chain_bits):      # one stream object per chain (two chains of a side must not share a queue)
-                k2 = ("chain", i, b)
-                if k2 not in mask_streams:
+            key_ = tuple(chain_bits)
+            if mask_streams.get("key") != key_:
+                torch.cuda.synchronize()
+                for st_ in mask_streams.get("streams", []):
+                    L.check(lib.sfmi_stream_destroy(st_.cuda_stream), "sfmi_stream_destroy")
+                streams_ = []
+                for b in chain_bits:
                     words = (ctypes.c_uint * 8)()
                     for bit in b:
                         words[bit // 32] |= 1 << (bit % 32)
                     sp_ = ctypes.c_void_p()
                     L.check(lib.sfmi_stream_create_cumask(words, 8, ctypes.byref(sp_)), "sfmi_stream_create_cumask")
-                    mask_streams[k2] = torch.cuda.ExternalStream(sp_.value, device=dev)
-                streams_.append(mask_streams[k2])
-            gpt._mb_streams, gpt._mb_shared_queue = streams_, False
+                    streams_.append(torch.cuda.ExternalStream(sp_.value, device=dev))
+                mask_streams["key"], mask_streams["streams"] = key_, streams_
+            streams_ = mask_streams["streams"]
+            gpt._chain_streams = (lambda ss: (lambda n: ss[:n]))(streams_)      # instance attribute: shadows the probing method
+            gpt._mb_shared_queue = False
             if hwid:
                 for i in sorted({0, chains - 1}):
                     hwid_report(streams_[i], f"chain {i} ({len(chain_bits[i])} mask bits, {cumode})")
-        elif getattr(gpt, "_masked_prev", False):
-            gpt._mb_streams = []          # back to probed plain streams
-        gpt._masked_prev = bool(cus or cusplit)
+        elif "_chain_streams" in gpt.__dict__:
+            del gpt.__dict__["_chain_streams"]      # back to the probed plain streams
+            gpt._mb_streams = []
         for k, v in defaults.items():
             L.check(lib.sfmi_tune_set(k.encode(), int(kv.pop(k, v))), f"tune {k}")
         for k, v in kv.items():
@@ -260,8 +268,6 @@ def main():
             if gpt._profile:
                 pr = gpt.launch_profile(reset=True)
                 bginfo += "   in situ: " + ", ".join(f"{k} {n} launches x {us:.2f} us" for k, (n, us) in pr.items() if n)
-            if cus or cusplit:      # did the run keep the masked streams (gpt._chain_streams re-probes a set that fails its overlap check)?
-                bginfo += "   masked streams " + ("kept" if all(x is y for x, y in zip(gpt._mb_streams, streams_)) else "REPLACED by the stream probe")
             say(f"{name:28s} rows {rows} chains {chains} {' '.join(kvs):50s} ms/step " + " ".join(f"{m:.3f}" for m in ms)
                 + f"   rows/ms {rows / min(ms):.1f}" + (f"   turnstile tickets {sem[0]} time-outs {sem[2]}" if gpt.ATTN_LANES else "") + bginfo + pw)
         except Exception as e:   # keep sweeping
