@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--train-gemm", default="sk", choices=["sk", "tile"],
                     help="--mode train: GEMM of the step: sk = work-balanced csrc/sgemm_sk.hip with fused GELU epilogues (default), tile = csrc/sgemm.hip + split-K reduce / GELU launches (rounds 2-4)")
     ap.add_argument("--train-side-stream", type=int, default=1, help="--mode train: 1 = weight-gradient GEMMs / column reductions on a second HIP stream (default), 0 = one stream")
+    ap.add_argument("--train-graph", type=int, default=1, help="--mode train: 1 = the step replays one captured hipGraph where it can (one rank, no gradient collectives; default), 0 = eager")
     ap.add_argument("--train-fused-opt", type=int, default=1, help="--mode train: 1 = AdamW per bucket inside the backward pass (default), 0 = one AdamW launch after it")
     ap.add_argument("--train-lc", type=int, default=200)
     ap.add_argument("--train-lz", type=int, default=300)
@@ -457,22 +458,33 @@ def train_record(gpt, a, batches=(1, 8), steps=5, warm=2):
     fused AdamW; no gradient collective with one rank) at the YAML's per-GPU batch 1 and at batch 8."""
     from shapeformer_amd.train import GPTTrainer
     F32 = 157.3
-    tr = GPTTrainer(gpt, lr=1e-5, dist=None)
-    rec = {"workload": "BASELINE config 5 on one rank: CondTupleGPT 20+4 layers d1024, fwd+bwd+AdamW, synthetic tokens L_c 200 + L_z 300", "dtype": "f32"}
+    tr = GPTTrainer(gpt, lr=1e-5, dist=None, graph=True)
+    rec = {"workload": "BASELINE config 5 on one rank: CondTupleGPT 20+4 layers d1024, fwd+bwd+AdamW, synthetic tokens L_c 200 + L_z 300", "dtype": "f32",
+           "step": "one captured hipGraph per step (train.GPTTrainer(graph=True): forward, backward and the per-bucket AdamW on three streams; tokens, "
+                   "dropout seeds and AdamW bias corrections read from device memory), bit-identical to the eager step timed beside it"}
     for bs in batches:
         c, z = synth_tokens(1000, bs, a.train_lc, a.train_lz)
-        for _ in range(warm):
-            loss = tr.training_step(c, z)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = tr.training_step(c, z)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        t = {}
+        for mode in ("eager", "graph"):
+            tr.use_graph = mode == "graph"
+            for _ in range(warm + (1 if mode == "graph" else 0)):      # graph: the first step of a shape is eager, the second captures
+                loss = tr.training_step(c, z)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = tr.training_step(c, z)
+            t_host = time.perf_counter() - t0
+            torch.cuda.synchronize(); t[mode] = (time.perf_counter() - t0) / steps
+            t[mode + "_host"] = t_host / steps
+        dt = t["graph"]
         tok = bs * (a.train_lc + a.train_lz - 1)
         tf = 6 * 324.95e6 * tok / dt / 1e12
         rec[f"batch{bs}"] = {"ms_per_step": round(dt * 1e3, 3), "tokens_per_s": round(tok / dt, 1), "loss": round(float(loss.item()), 4),
+                             "eager_ms_per_step": round(t["eager"] * 1e3, 3), "host_enqueue_ms_per_step": round(t["graph_host"] * 1e3, 3),
+                             "eager_host_enqueue_ms_per_step": round(t["eager_host"] * 1e3, 3),
                              "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": F32, "unit": "TFLOP/s", "frac": round(tf / F32, 4),
                                           "note": "model FLOPs 6 x 324.95 M parameters x tokens (attention FLOPs not counted)"}}
     del tr
+    torch.cuda.empty_cache()
     return rec
 
 
@@ -527,7 +539,8 @@ def main_train(a, rank, world, dev, dist):
     from shapeformer_amd.gpt import CondTupleGPT
     from shapeformer_amd.train import GPTTrainer
     g = CondTupleGPT(device=dev)
-    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist, grad_sync=a.grad_sync, profile_waits=True, gemm=a.train_gemm, side_stream=bool(a.train_side_stream), fused_optimizer=bool(a.train_fused_opt))
+    tr = GPTTrainer(g, lr=1e-5, dist=dist, single_rank_collectives=a.force_dist, grad_sync=a.grad_sync, profile_waits=True, gemm=a.train_gemm, side_stream=bool(a.train_side_stream), fused_optimizer=bool(a.train_fused_opt),
+                    graph=bool(a.train_graph))
     c, z = synth_tokens(1000 + rank, a.train_batch, a.train_lc, a.train_lz)
     losses = []
     for _ in range(a.warmup):
@@ -562,6 +575,7 @@ def main_train(a, rank, world, dev, dist):
             "config": {"workload": "ShapeFormer DDP training step, synthetic IMNet-style token batches (BASELINE config 5)",
                        "batch_per_gpu": a.train_batch, "L_c": a.train_lc, "L_z": a.train_lz, "parallelism": f"dp{world}",
                        "grad_sync_mode": a.grad_sync, "gemm": a.train_gemm, "side_stream": bool(a.train_side_stream), "fused_optimizer": bool(a.train_fused_opt),
+                       "hipgraph_step": bool(tr._graphs),
                        "grad_sync": ("26 gradient buckets (one per block) all-reduced under the backward pass" if a.grad_sync == "ring" else
                                      "26 gradient buckets reduce-scattered under the backward pass, AdamW on the rank's 1/N shard, updated "
                                      "parameters all-gathered in place through the same flat buffer")},

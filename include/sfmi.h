@@ -278,6 +278,30 @@ int sfmi_adamw_multi_shard_f32(float* const* p, const long long* foff, const flo
 int sfmi_unflatten_multi_f32(float* const* p, const long long* foff, const int* ctensor, const long long* coff, const int* clen,
                              int nchunks, const float* flat, void* stream);
 
+/* ---- the training step captured in a hipGraph (no reference counterpart: Lightning enqueues every step from the host).  A captured launch
+ *      keeps its arguments, so what changes from step to step is read from DEVICE memory at run time: the dropout seed of a site
+ *      (mingpt.py:62-63,85,90,105,292) through `drop_seed_dev` (NULL: the by-value seed, as in the plain entry points), AdamW's bias
+ *      corrections through `bc_dev` = {1 - beta1^t, 1 - beta2^t} (sfmi_adamw_bias_corrections forms them exactly as the by-value path).
+ *      Same kernels, same arithmetic: a replayed step is bit-identical to the eager one. */
+int sfmi_sgemm_sk_sd_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, float* C2,
+                         int ldc, int accumulate, const float* bias, int act, const float* aux, const float* resid, float drop_p,
+                         unsigned drop_seed, const unsigned* drop_seed_dev, float* slab, long long slab_floats, int* cnt, long long cnt_ints,
+                         void* stream);
+int sfmi_gpt_attn_prefill_lse_sd_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
+                                     int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, float* lse,
+                                     void* stream);
+int sfmi_attn_train_fwd_small_sd_f32(const float* qkv, float* y, float* lse, int B, int L, int D, int H, float drop_p, unsigned drop_seed,
+                                     const unsigned* drop_seed_dev, void* stream);
+int sfmi_attn_bwd_lse_sd_f32(const float* qkv, const float* y, const float* dy, const float* lse, float* delta, float* dqkv, int B, int L,
+                             int D, int H, float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, void* stream);
+int sfmi_layernorm_bwd_rows_drop_sd_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats,
+                                        float* dx2, float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, int M, int D, void* stream);
+int sfmi_dropout_sd_f32(const float* x, float* y, long long n, float p, unsigned seed, const unsigned* seed_dev, void* stream);
+int sfmi_adamw_bias_corrections(float beta1, float beta2, int step, float* out2); /* [host] */
+int sfmi_adamw_multi_shard_bc_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
+                                  const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                                  float eps, int step, const float* bc_dev, float* pflat, void* stream);
+
 /* ---- Implicit decoder SDF/occupancy query: dec.py:62-100 (grid_sample + 5-block conditioned MLP), layers.py:39-48 - */
 size_t sfmi_sdf_pack_floats(void);
 int sfmi_sdf_pack_weights(const float* fc_p_w, const float* fc_p_b, const float* fc_c_w, const float* fc_c_b,

@@ -140,6 +140,16 @@ PROTOTYPES = {
     "sfmi_adamw_f32": (i32, [c_ptr] * 4 + [i64] + [C.c_float] * 5 + [i32, c_ptr]),
     "sfmi_adamw_multi_f32": (i32, [c_ptr] * 6 + [i32, c_ptr, c_ptr, c_ptr, f32, f32, f32, f32, i32, c_ptr]),
     "sfmi_adamw_multi_shard_f32": (i32, [c_ptr] * 6 + [i32, c_ptr, c_ptr, c_ptr, f32, f32, f32, f32, i32, c_ptr, c_ptr]),
+    # device-resident step state (captured training step)
+    "sfmi_sgemm_sk_sd_f32": (i32, [i32] * 5 + [c_ptr, i32, c_ptr, i32, c_ptr, c_ptr, i32, i32, c_ptr, i32, c_ptr, c_ptr, f32, C.c_uint, c_ptr, c_ptr, i64,
+                                   c_ptr, i64, c_ptr]),
+    "sfmi_gpt_attn_prefill_lse_sd_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, f32, C.c_uint, c_ptr, c_ptr, c_ptr]),
+    "sfmi_attn_train_fwd_small_sd_f32": (i32, [c_ptr] * 3 + [i32] * 4 + [f32, C.c_uint, c_ptr, c_ptr]),
+    "sfmi_attn_bwd_lse_sd_f32": (i32, [c_ptr] * 6 + [i32] * 4 + [f32, C.c_uint, c_ptr, c_ptr]),
+    "sfmi_layernorm_bwd_rows_drop_sd_f32": (i32, [c_ptr] * 7 + [f32, C.c_uint, c_ptr, i32, i32, c_ptr]),
+    "sfmi_dropout_sd_f32": (i32, [c_ptr, c_ptr, i64, f32, C.c_uint, c_ptr, c_ptr]),
+    "sfmi_adamw_bias_corrections": (i32, [f32, f32, i32, c_ptr]),
+    "sfmi_adamw_multi_shard_bc_f32": (i32, [c_ptr] * 6 + [i32, c_ptr, c_ptr, c_ptr, f32, f32, f32, f32, i32, c_ptr, c_ptr, c_ptr]),
     "sfmi_unflatten_multi_f32": (i32, [c_ptr] * 5 + [i32, c_ptr, c_ptr]),
 }
 

@@ -691,7 +691,8 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
                                                                 float* __restrict__ Vc, const int* __restrict__ nval,
                                                                 float* __restrict__ y, int P, int D, int Lmax, float scale,
                                                                 const int* __restrict__ rowoff, float drop_p, unsigned drop_seed,
-                                                                float* __restrict__ lse) {
+                                                                float* __restrict__ lse, const unsigned* __restrict__ drop_seed_dev) {
+  if (drop_seed_dev) drop_seed = *drop_seed_dev;      // training step captured in a hipGraph: the seed of this site lives in device memory
   // row strides HD + 4: 16-byte aligned rows whose ds_read_b128 of 16 consecutive rows hit distinct banks; 51 KB of LDS per workgroup
   // at HD = 64 -> three resident workgroups per CU (a workgroup walks only 1-4 key blocks: its prologue latency needs company)
   constexpr int AP_KS = HD + 4, AP_VS = HD + 4, KK = HD / 4, DT = HD / 16;
@@ -1472,16 +1473,25 @@ int sfmi_gpt_attn_prefill_f32(const float* qkv, float* Kc, float* Vc, const int*
   return sfmi_gpt_attn_prefill_lse_f32(qkv, Kc, Vc, nval, y, B, P, D, H, Lmax, rowoff, drop_p, drop_seed, nullptr, stream);
 }
 // the same launch; lse != NULL also receives the (B,H,P) row log-sum-exps of the scaled scores (what sfmi_attn_bwd_lse_f32 starts from)
+int sfmi_gpt_attn_prefill_lse_sd_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
+                                     int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, float* lse,
+                                     void* stream);
 int sfmi_gpt_attn_prefill_lse_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
                                   int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, float* lse, void* stream) {
+  return sfmi_gpt_attn_prefill_lse_sd_f32(qkv, Kc, Vc, nval, y, B, P, D, H, Lmax, rowoff, drop_p, drop_seed, nullptr, lse, stream);
+}
+// the same with the dropout seed optionally in device memory (drop_seed_dev != NULL overrides drop_seed at run time)
+int sfmi_gpt_attn_prefill_lse_sd_f32(const float* qkv, float* Kc, float* Vc, const int* nval, float* y, int B, int P, int D, int H,
+                                     int Lmax, const int* rowoff, float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, float* lse,
+                                     void* stream) {
   const int HD = H > 0 ? D / H : 0;
   if (!qkv || !Kc || !Vc || !nval || !y || H <= 0 || D % H || (HD != 16 && HD != 32 && HD != 64) || P <= 0 || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   const dim3 grid(B, H, (P + 63) / 64);
   const float scale = 1.0f / sqrtf((float)HD);
   hipStream_t st = (hipStream_t)stream;
-  if (HD == 64) hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse);
-  else if (HD == 32) hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse);
-  else hipLaunchKernelGGL(attn_prefill_mfma_kernel<16>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse);
+  if (HD == 64) hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse, drop_seed_dev);
+  else if (HD == 32) hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse, drop_seed_dev);
+  else hipLaunchKernelGGL(attn_prefill_mfma_kernel<16>, grid, dim3(256), 0, st, qkv, Kc, Vc, nval, y, P, D, Lmax, scale, rowoff, drop_p, drop_seed, lse, drop_seed_dev);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -40,7 +40,7 @@ constexpr int SK_GM = 8;              // M-tiles per panel of the tile order
 struct SkArgs {
   const float* A; const float* B; float* C; float* C2; const float* bias; const float* aux; const float* resid;
   int M, N, K, lda, ldb, ldc, accumulate, act;
-  float drop_p; unsigned drop_seed;
+  float drop_p; unsigned drop_seed; const unsigned* drop_seed_dev;   // drop_seed_dev != NULL: the seed is read from device memory (captured training step)
   float* slab;     // [G][2][BM * BN] partial tiles (slot 0: a workgroup's first segment, slot 1: its last)
   int* cnt;        // [tiles][4] arrival tickets, zero before the first launch, re-armed by the last arriver
   int nbm, nbn, nch, stagger;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_sk_kernel(SkArgs a) {
     }
     if (a.drop_p > 0.f) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] *= sfmi_dropout_mul(a.drop_seed, (unsigned)(m * a.N + n + e), a.drop_p, 1.0f / (1.0f - a.drop_p));
+      for (int e = 0; e < 4; ++e) x[e] *= sfmi_dropout_mul(a.drop_seed_dev ? *a.drop_seed_dev : a.drop_seed, (unsigned)(m * a.N + n + e), a.drop_p, 1.0f / (1.0f - a.drop_p));
     }
     if (a.resid) x = x + *reinterpret_cast<const f32x4*>(a.resid + off);
     *reinterpret_cast<f32x4*>(cp) = x;
@@ -481,9 +481,21 @@ long long sfmi_sgemm_sk_cnt_ints(int M, int N) { return 4ll * ((M + 63) / 64) * 
 // GELU'(aux[m][n]) (aux (M,N; ldc)).  slab / cnt: caller-owned scratch (sfmi_sgemm_sk_slab_floats / _cnt_ints; cnt zeroed once), one
 // pair per stream that may run these launches concurrently.  Deterministic: a tile's slices are added in k order.
 // Replaces the cuBLAS sgemm behind nn.Linear and its autograd (mingpt.py:46-111) in the training step at small batch.
+int sfmi_sgemm_sk_sd_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, float* C2,
+                         int ldc, int accumulate, const float* bias, int act, const float* aux, const float* resid, float drop_p,
+                         unsigned drop_seed, const unsigned* drop_seed_dev, float* slab, long long slab_floats, int* cnt, long long cnt_ints,
+                         void* stream);
 int sfmi_sgemm_sk_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, float* C2,
                       int ldc, int accumulate, const float* bias, int act, const float* aux, const float* resid, float drop_p,
                       unsigned drop_seed, float* slab, long long slab_floats, int* cnt, long long cnt_ints, void* stream) {
+  return sfmi_sgemm_sk_sd_f32(transA, transB, M, N, K, A, lda, B, ldb, C, C2, ldc, accumulate, bias, act, aux, resid, drop_p, drop_seed, nullptr, slab,
+                              slab_floats, cnt, cnt_ints, stream);
+}
+// the same with the dropout seed optionally in device memory (drop_seed_dev != NULL overrides drop_seed at run time)
+int sfmi_sgemm_sk_sd_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, float* C2,
+                         int ldc, int accumulate, const float* bias, int act, const float* aux, const float* resid, float drop_p,
+                         unsigned drop_seed, const unsigned* drop_seed_dev, float* slab, long long slab_floats, int* cnt, long long cnt_ints,
+                         void* stream) {
   if (!A || !B || !C || !slab || !cnt || M <= 0 || N <= 0 || K <= 0 || N % 4 || lda % 4 || ldb % 4 || ldc % 4) return SFMI_EINVAL;
   if (!transA && K % 4) return SFMI_EINVAL;          // A K-contiguous: float4 along k
   if (transA && (M % 4 || M < 4)) return SFMI_EINVAL; // A row-contiguous: float4 along m
@@ -492,7 +504,7 @@ int sfmi_sgemm_sk_f32(int transA, int transB, int M, int N, int K, const float* 
   const int TM = sfmi_sgemm_sk_tile(M, N, K), BM = 64 * TM;
   SkArgs a;
   a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.aux = aux; a.resid = resid; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
-  a.ldc = ldc; a.accumulate = accumulate; a.act = act; a.drop_p = drop_p; a.drop_seed = drop_seed; a.slab = slab; a.cnt = cnt;
+  a.ldc = ldc; a.accumulate = accumulate; a.act = act; a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_seed_dev = drop_seed_dev; a.slab = slab; a.cnt = cnt;
   a.nbm = (M + BM - 1) / BM; a.nbn = (N + BM - 1) / BM; a.nch = (K + SK_KC - 1) / SK_KC;
   const long long tiles = (long long)a.nbm * a.nbn;
   a.units = tiles * a.nch;

@@ -129,8 +129,9 @@ template <int NE>
 __global__ __launch_bounds__(256) void ln_bwd_rows_wave_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ gamma, const float* __restrict__ dres,
                                                                float* __restrict__ dx, float* __restrict__ stats, float* __restrict__ dx2,
-                                                               int M, float drop_p, unsigned drop_seed) {
+                                                               int M, float drop_p, unsigned drop_seed, const unsigned* __restrict__ drop_seed_dev) {
   constexpr int D = 64 * NE;
+  if (drop_seed_dev) drop_seed = *drop_seed_dev;      // the seed lives in device memory (a captured hipGraph of the training step is reused across steps)
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (m >= M) return;
   const long long rb = (long long)m * D;
@@ -654,8 +655,9 @@ __device__ __forceinline__ void attn_bwd_dkv_role(float* __restrict__ smem_all, 
 template <int RW, int NG>
 __global__ __launch_bounds__(64 * RW * NG) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ y,
                                                                       float* __restrict__ lse, int L, int D, float scale, float drop_p,
-                                                                      unsigned drop_seed) {
+                                                                      unsigned drop_seed, const unsigned* __restrict__ drop_seed_dev) {
   constexpr int GT = 64 * RW, NIT = 1024 / GT, GROUP_FLOATS = 2 * 64 * AB_S + RW * 16 * AB_S;
+  if (drop_seed_dev) drop_seed = *drop_seed_dev;
   __shared__ __attribute__((aligned(16))) float smem_all[NG * GROUP_FLOATS];
   const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, qb = blockIdx.z;
   const int grp = NG == 1 ? 0 : (int)(threadIdx.x / GT), tid = threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;
@@ -793,8 +795,9 @@ template <int RW, int NG>
 __global__ __launch_bounds__(64 * RW * NG) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ dy,
                                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                                       float* __restrict__ dqkv, int L, int D, float scale, float drop_p,
-                                                                      unsigned drop_seed) {
+                                                                      unsigned drop_seed, const unsigned* __restrict__ drop_seed_dev) {
   __shared__ __attribute__((aligned(16))) float smem[NG * (2 * 64 * AB_S + 2 * RW * 16 * AB_S)];
+  if (drop_seed_dev) drop_seed = *drop_seed_dev;
   const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y, z = blockIdx.z, nqb = gridDim.z >> 1;
   if (z & 1) attn_bwd_dkv_role<RW, NG>(smem, qkv, dy, lse, delta, dqkv, b, h, H, z >> 1, L, D, scale, drop_p, drop_seed);
   else attn_bwd_dq_role<RW, NG>(smem, qkv, dy, lse, delta, dqkv, b, h, H, nqb - 1 - (z >> 1), L, D, scale, drop_p, drop_seed);
@@ -802,13 +805,13 @@ __global__ __launch_bounds__(64 * RW * NG) void attn_bwd_fused_kernel(const floa
 
 // small launches (every workgroup resident at once: the heaviest wave is the launch's duration) run 32-row tiles x two wave groups
 static void attn_bwd_fused_launch(hipStream_t st, const float* qkv, const float* dy, const float* lse, const float* delta, float* dqkv, int B,
-                                  int L, int D, int H, float drop_p, unsigned drop_seed) {
+                                  int L, int D, int H, float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev) {
   const int nqb = (L + 63) / 64;
   if ((long long)B * H * 2 * nqb <= 256 && nqb > 1) {
     const int n32 = (L + 31) / 32;
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<2, 2>), dim3(B, H, 2 * n32), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<2, 2>), dim3(B, H, 2 * n32), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed, drop_seed_dev);
   } else {
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<4, 1>), dim3(B, H, 2 * nqb), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<4, 1>), dim3(B, H, 2 * nqb), dim3(256), 0, st, qkv, dy, lse, delta, dqkv, L, D, 0.125f, drop_p, drop_seed, drop_seed_dev);
   }
 }
 
@@ -870,9 +873,11 @@ __global__ void fixed_to_float_kernel(const long long* __restrict__ acc, float* 
 }
 
 // nn.Dropout on a flat tensor, forward and backward alike: y[i] = x[i] * mask_i / (1 - p), mask from the counter hash
-__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p, float inv_keep, unsigned seed) {
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p, float inv_keep, unsigned seed,
+                               const unsigned* __restrict__ seed_dev) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
+  if (seed_dev) seed = *seed_dev;
   f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] *= sfmi_dropout_mul(seed, (unsigned)(4 * i + e), p, inv_keep);
@@ -905,6 +910,7 @@ struct AdamMultiArgs {
   const int* ctensor; const long long* coff; const int* clen;
   const float* g; float* m; float* v;
   float lr, b1, b2, eps, bc1, bc2;
+  const float* bc_dev;   // optional {1 - beta1^t, 1 - beta2^t} in device memory (the captured training step: t advances between replays)
   float* pflat;   // optional: the updated parameter is ALSO written to pflat[flat index] (may alias g: the all-gather send buffer of the sharded update)
 };
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
@@ -912,7 +918,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
   const long long o = a.coff[c], fo = a.foff[t] + o;
   const int n = a.clen[c];
   float* p = a.p[t] + o;
-  const float decay = 1.0f - a.lr * a.wd[t], sb2 = sqrtf(a.bc2), step = a.lr / a.bc1;
+  const float bc1 = a.bc_dev ? a.bc_dev[0] : a.bc1, bc2 = a.bc_dev ? a.bc_dev[1] : a.bc2;
+  const float decay = 1.0f - a.lr * a.wd[t], sb2 = sqrtf(bc2), step = a.lr / bc1;
   // 9.1 GB of pure streaming per step at d = 1024 (read p, g, m, v; write p, m, v): 16-byte nontemporal accesses (the bare-stream
   // probe of round 5 reads 7.1 TB/s nontemporal against 6.4 TB/s with the default policy); the per-element arithmetic is unchanged
   if (((fo | o | (long long)n) & 3) == 0) {
@@ -1022,25 +1029,30 @@ int sfmi_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, 
 }
 // LayerNorm backward, row part only: dx = dLN/dx (+ dres), stats (M,2) = row mean / rstd for the parameter sums, which the caller
 // adds to a block's sfmi_col_reduce_f32 launch (kind 1 job).
-int sfmi_layernorm_bwd_rows_drop_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats,
-                                     float* dx2, float drop_p, unsigned drop_seed, int M, int D, void* stream) {
+// drop_seed_dev != NULL: the seed is read from device memory at run time (the captured training step, csrc/train.hip header of this family)
+int sfmi_layernorm_bwd_rows_drop_sd_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats,
+                                        float* dx2, float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, int M, int D, void* stream) {
   if (!dy || !x || !gamma || !dx || !stats || M <= 0 || D <= 0 || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((M + 3) / 4);
-  if (D == 1024) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<16>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed);
-  else if (D == 512) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<8>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed);
-  else if (D == 256) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<4>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed);
-  else if (D == 128) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<2>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed);
+  if (D == 1024) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<16>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed, drop_seed_dev);
+  else if (D == 512) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<8>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed, drop_seed_dev);
+  else if (D == 256) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<4>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed, drop_seed_dev);
+  else if (D == 128) hipLaunchKernelGGL(ln_bwd_rows_wave_kernel<2>, grid, dim3(256), 0, st, dy, x, gamma, dres, dx, stats, dx2, M, drop_p, drop_seed, drop_seed_dev);
   else {      // other widths: the block-per-row form, then the dropout as its own launch
     hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3(M), dim3(256), 0, st, dy, x, gamma, dres, dx, stats, D);
     if (dx2) {
       const long long n = (long long)M * D;
       if (n % 4) return SFMI_EINVAL;
-      hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dx, dx2, n / 4, drop_p, 1.0f / (1.0f - drop_p), drop_seed);
+      hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dx, dx2, n / 4, drop_p, 1.0f / (1.0f - drop_p), drop_seed, drop_seed_dev);
     }
   }
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
+}
+int sfmi_layernorm_bwd_rows_drop_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats,
+                                     float* dx2, float drop_p, unsigned drop_seed, int M, int D, void* stream) {
+  return sfmi_layernorm_bwd_rows_drop_sd_f32(dy, x, gamma, dres, dx, stats, dx2, drop_p, drop_seed, nullptr, M, D, stream);
 }
 int sfmi_layernorm_bwd_rows_f32(const float* dy, const float* x, const float* gamma, const float* dres, float* dx, float* stats, int M,
                                 int D, void* stream) {
@@ -1090,33 +1102,40 @@ int sfmi_attn_bwd_f32(const float* qkv, const float* y, const float* dy, float* 
   const int nqb = (L + 63) / 64;
   float* delta = lse + (size_t)B * H * L;
   hipLaunchKernelGGL(attn_stats_mfma_kernel, dim3(B, H, nqb), dim3(256), 0, st, qkv, y, dy, lse, delta, L, D, 0.125f);
-  attn_bwd_fused_launch(st, qkv, dy, lse, delta, dqkv, B, L, D, H, drop_p, drop_seed);
+  attn_bwd_fused_launch(st, qkv, dy, lse, delta, dqkv, B, L, D, H, drop_p, drop_seed, nullptr);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }
 // the same from the forward's (B,H,L) log-sum-exps (sfmi_gpt_attn_prefill_lse_f32): a row-sum launch for delta (B*H*L floats of scratch)
 // + the fused launch.  H must divide 64 (head dim 64: D = 64 H).
-int sfmi_attn_bwd_lse_f32(const float* qkv, const float* y, const float* dy, const float* lse, float* delta, float* dqkv, int B, int L,
-                          int D, int H, float drop_p, unsigned drop_seed, void* stream) {
+int sfmi_attn_bwd_lse_sd_f32(const float* qkv, const float* y, const float* dy, const float* lse, float* delta, float* dqkv, int B, int L,
+                             int D, int H, float drop_p, unsigned drop_seed, const unsigned* drop_seed_dev, void* stream) {
   if (!qkv || !y || !dy || !lse || !delta || !dqkv || H <= 0 || D != 64 * H || 64 % H || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nqb = (L + 63) / 64;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long long)B * L + 3) / 4)), dim3(256), 0, st, y, dy, delta, B, L, D, H);
-  attn_bwd_fused_launch(st, qkv, dy, lse, delta, dqkv, B, L, D, H, drop_p, drop_seed);
+  attn_bwd_fused_launch(st, qkv, dy, lse, delta, dqkv, B, L, D, H, drop_p, drop_seed, drop_seed_dev);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
+}
+int sfmi_attn_bwd_lse_f32(const float* qkv, const float* y, const float* dy, const float* lse, float* delta, float* dqkv, int B, int L,
+                          int D, int H, float drop_p, unsigned drop_seed, void* stream) {
+  return sfmi_attn_bwd_lse_sd_f32(qkv, y, dy, lse, delta, dqkv, B, L, D, H, drop_p, drop_seed, nullptr, stream);
 }
 // Training forward of CausalSelfAttention (mingpt.py:73-91) for launches too small to fill the chip with the 64-row prefill tiles
 // (B * H * ceil(L / 64) <= 128, head dim 64): 32-row tiles x two key-block groups per workgroup, (B,H,L) log-sum-exps for the backward
 // pass.  Larger launches use sfmi_gpt_attn_prefill_lse_f32.  Returns SFMI_EINVAL when the launch is not "small".
-int sfmi_attn_train_fwd_small_f32(const float* qkv, float* y, float* lse, int B, int L, int D, int H, float drop_p, unsigned drop_seed,
-                                  void* stream) {
+int sfmi_attn_train_fwd_small_sd_f32(const float* qkv, float* y, float* lse, int B, int L, int D, int H, float drop_p, unsigned drop_seed,
+                                     const unsigned* drop_seed_dev, void* stream) {
   if (!qkv || !y || !lse || B <= 0 || L <= 0 || H <= 0 || D != 64 * H || drop_p < 0.f || drop_p >= 1.f) return SFMI_EINVAL;
   if ((long long)B * H * ((L + 63) / 64) > 128) return SFMI_EINVAL;
   hipLaunchKernelGGL((attn_train_fwd_kernel<2, 2>), dim3(B, H, (L + 31) / 32), dim3(256), 0, (hipStream_t)stream, qkv, y, lse, L, D, 0.125f, drop_p,
-                     drop_seed);
+                     drop_seed, drop_seed_dev);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
+}
+int sfmi_attn_train_fwd_small_f32(const float* qkv, float* y, float* lse, int B, int L, int D, int H, float drop_p, unsigned drop_seed,
+                                  void* stream) {
+  return sfmi_attn_train_fwd_small_sd_f32(qkv, y, lse, B, L, D, H, drop_p, drop_seed, nullptr, stream);
 }
 // nn.Embedding backward: acc (rows*D int64, zeroed by the caller) += scatter(dx) ; then sfmi_fixed_to_float_f32
 int sfmi_embed_scatter_f32(const float* dx, const int* idx, long long* acc, long long M, int D, void* stream) {
@@ -1134,11 +1153,15 @@ int sfmi_fixed_to_float_f32(const long long* acc, float* out, long long n, int a
 }
 // nn.Dropout(p) with the counter-hash mask of `seed` (embedding / residual dropouts and their backward: mingpt.py:90,105,218,292);
 // n a multiple of 4; y may alias x
-int sfmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned seed, void* stream) {
+int sfmi_dropout_sd_f32(const float* x, float* y, long long n, float p, unsigned seed, const unsigned* seed_dev, void* stream) {
   if (!x || !y || n <= 0 || n % 4 || p < 0.f || p >= 1.f) return SFMI_EINVAL;
-  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4, p, 1.0f / (1.0f - p), seed);
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4, p, 1.0f / (1.0f - p), seed,
+                     seed_dev);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
+}
+int sfmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned seed, void* stream) {
+  return sfmi_dropout_sd_f32(x, y, n, p, seed, nullptr, stream);
 }
 int sfmi_add_f32(const float* a, const float* b, float* out, long long n, void* stream) {
   if (!a || !b || !out || n <= 0) return SFMI_EINVAL;
@@ -1161,18 +1184,31 @@ int sfmi_adamw_f32(float* p, const float* g, float* m, float* v, long long n, fl
 // chunk tables ctensor / coff / clen (nchunks; any partition of every tensor into chunks, e.g. 16384 elements each).
 // pflat (optional, may alias g): the updated parameters are also written to pflat[flat index] - the optimizer-sharded step
 // (reduce-scatter -> this update on the rank's shard -> all-gather of pflat -> sfmi_unflatten_multi_f32) sends them from there.
-int sfmi_adamw_multi_shard_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
-                               const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
-                               float eps, int step, float* pflat, void* stream) {
-  if (!p || !foff || !wd || !ctensor || !coff || !clen || !g || !m || !v || nchunks <= 0 || step <= 0) return SFMI_EINVAL;
+// [host] the two bias corrections {1 - beta1^step, 1 - beta2^step} exactly as sfmi_adamw_multi_shard_f32 forms them
+int sfmi_adamw_bias_corrections(float beta1, float beta2, int step, float* out2) {
+  if (!out2 || step <= 0) return SFMI_EINVAL;
+  out2[0] = 1.0f - powf(beta1, (float)step); out2[1] = 1.0f - powf(beta2, (float)step);
+  return SFMI_OK;
+}
+// bc_dev != NULL: the bias corrections are read from device memory at run time (2 floats, sfmi_adamw_bias_corrections of the step count)
+// instead of being formed from `step` at launch time - the captured training step replays one launch for every step count
+int sfmi_adamw_multi_shard_bc_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
+                                  const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                                  float eps, int step, const float* bc_dev, float* pflat, void* stream) {
+  if (!p || !foff || !wd || !ctensor || !coff || !clen || !g || !m || !v || nchunks <= 0 || (step <= 0 && !bc_dev)) return SFMI_EINVAL;
   AdamMultiArgs a;
-  a.pflat = pflat;
+  a.pflat = pflat; a.bc_dev = bc_dev;
   a.p = p; a.foff = foff; a.wd = wd; a.ctensor = ctensor; a.coff = coff; a.clen = clen; a.g = g; a.m = m; a.v = v;
   a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
   a.bc1 = 1.0f - powf(beta1, (float)step); a.bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
+}
+int sfmi_adamw_multi_shard_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
+                               const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                               float eps, int step, float* pflat, void* stream) {
+  return sfmi_adamw_multi_shard_bc_f32(p, foff, wd, ctensor, coff, clen, nchunks, g, m, v, lr, beta1, beta2, eps, step, nullptr, pflat, stream);
 }
 int sfmi_adamw_multi_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
                          const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,

@@ -57,7 +57,8 @@ def _concurrent_streams(dev, n, candidates=8):
 
 class GPTTrainer:
     def __init__(self, gpt, lr=1e-5, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8, dist=None, pdrop=None, dropout_seed=0,
-                 single_rank_collectives=False, grad_sync="ring", profile_waits=False, gemm="sk", overlap_param_gather=True, side_stream=True, fused_optimizer=True):
+                 single_rank_collectives=False, grad_sync="ring", profile_waits=False, gemm="sk", overlap_param_gather=True, side_stream=True, fused_optimizer=True,
+                 graph=False):
         """grad_sync: "ring" = per-bucket all-reduce, every rank updates every parameter; "rs_ag" = per-bucket reduce-scatter,
         AdamW on the rank's 1/N shard, all-gather of the updated parameters (dist.GradBuckets).  Same weights either way.
         gemm: "sk" = the work-balanced GEMM with fused GELU epilogues (csrc/sgemm_sk.hip, round 5); "tile" = one workgroup per
@@ -67,6 +68,13 @@ class GPTTrainer:
         side_stream: the weight-gradient GEMMs and the per-block column reductions - needed by nobody before the optimizer - are issued
         on a second HIP stream, so that their workgroups fill the launch ramps and tails of the dependent chain (dX GEMMs, LayerNorm and
         attention backward) instead of queueing behind it; per-stream scratch, event-ordered, joined before the gradient collectives.
+        graph: training_step() replays ONE captured hipGraph per (batch shape, train / eval mode) - forward, backward and the per-bucket AdamW
+        on their three streams - instead of enqueueing ~860 launches from the host (the step is host-bound at the YAML's batch 1).  What
+        changes between steps is read from device memory by the captured launches: the token tensors (static input buffers), every
+        dropout site's seed and AdamW's bias corrections (one small host -> device copy per step, `_words`).  The first step of a shape
+        runs eagerly (it also creates the lazily built scratch and tables), the second is captured.  Needs fused_optimizer and the "sk"
+        GEMMs; with gradient collectives active (more than one rank) the step stays eager.  Same kernels in the same order: losses and
+        weights are bit-identical to the eager step.
         fused_optimizer: training_step() updates a bucket (one transformer block / the heads / the embeddings) as soon as its gradients
         are final - gradient collective waited for per bucket, AdamW launched per bucket on the side stream - so the 9 GB of optimizer
         traffic (HBM-bound) runs under the backward pass of the blocks below (MFMA-bound) instead of after it.  Same update, same bits."""
@@ -75,7 +83,14 @@ class GPTTrainer:
         self._settings = dict(betas=tuple(betas), weight_decay=weight_decay, eps=eps, pdrop=pdrop, dropout_seed=dropout_seed,
                               single_rank_collectives=bool(single_rank_collectives), grad_sync=grad_sync, profile_waits=bool(profile_waits),
                               gemm=gemm, overlap_param_gather=bool(overlap_param_gather), side_stream=bool(side_stream),
-                              fused_optimizer=bool(fused_optimizer))
+                              fused_optimizer=bool(fused_optimizer), graph=bool(graph))
+        self.use_graph = bool(graph)
+        self._graphs, self._capture, self._graph_seen = {}, None, set()
+        # per-step words read by the captured launches: [0:2] AdamW bias corrections (f32 bits), [2:] dropout seeds of the sites in capture order
+        self._words = torch.zeros(2 + 256, device=gpt.dev, dtype=torch.int32)
+        # a ring of pinned host mirrors: the host may run several replays ahead of the device, a mirror is rewritten only after its copy ran
+        self._words_ring = [dict(buf=torch.zeros(2 + 256, dtype=torch.int32).pin_memory(), ev=None) for _ in range(4)] if graph else []
+        self._words_next = 0
         self.gemm_algo, self.overlap_param_gather, self.fused_optimizer = gemm, bool(overlap_param_gather), bool(fused_optimizer)
         self._fused = False
         # the per-bucket optimizer of the fused step gets a stream of its own: it has to wait for the bucket's gradient collective, and
@@ -164,10 +179,11 @@ class GPTTrainer:
         lib = L.lib()
         if self.gemm_algo == "sk":
             slab, cnt = self._sk_slab[int(self._on_side)], self._sk_cnt[int(self._on_side)]
-            L.check(lib.sfmi_sgemm_sk_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(C), L.ptr(c2), ldc, int(accumulate), L.ptr(bias), act,
-                                          L.ptr(aux), L.ptr(resid), float(drop[0]), int(drop[1]), L.ptr(slab), slab.numel(), L.ptr(cnt), cnt.numel(),
-                                          L.stream_ptr()), "sgemm_sk")
+            L.check(lib.sfmi_sgemm_sk_sd_f32(int(tA), int(tB), M, N, K, L.ptr(A), lda, L.ptr(B), ldb, L.ptr(C), L.ptr(c2), ldc, int(accumulate), L.ptr(bias), act,
+                                             L.ptr(aux), L.ptr(resid), float(drop[0]), int(drop[1]), drop[2] if len(drop) > 2 else None, L.ptr(slab), slab.numel(),
+                                             L.ptr(cnt), cnt.numel(), L.stream_ptr()), "sgemm_sk")
             return
+        assert len(drop) < 3 or drop[2] is None, "the captured step needs the work-balanced GEMM (gemm='sk')"
         need = lib.sfmi_sgemm_mfma_splits(M, N, K) * M * N
         ws = None
         if need > M * N:
@@ -265,8 +281,9 @@ class GPTTrainer:
         the next GEMMs need when the forward dropped this tensor); else `dropped` is dx itself."""
         dx, stats = self._f(M, self.D), self._f(M, 2)
         dx2 = self._f(M, self.D) if drop[0] > 0.0 else None
-        L.check(L.lib().sfmi_layernorm_bwd_rows_drop_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(stats), L.ptr(dx2),
-                                                         float(drop[0]), int(drop[1]), M, self.D, L.stream_ptr()), "ln_bwd_rows")
+        L.check(L.lib().sfmi_layernorm_bwd_rows_drop_sd_f32(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(stats), L.ptr(dx2),
+                                                            float(drop[0]), int(drop[1]), drop[2] if len(drop) > 2 else None, M, self.D,
+                                                            L.stream_ptr()), "ln_bwd_rows")
         return dx, stats, (dx2 if dx2 is not None else dx)
 
     def _col_reduce(self, jobs, M):
@@ -337,10 +354,11 @@ class GPTTrainer:
         if key not in self._opt_tabs:
             self._opt_tabs[key] = self._chunk_table([bk.shard(name) if sharded else bk.ranges[name]])
         tb = self._opt_tabs[key]
-        L.check(L.lib().sfmi_adamw_multi_shard_f32(L.ptr(tb["p"]), L.ptr(tb["foff"]), L.ptr(tb["wd"]), L.ptr(tb["ct"]), L.ptr(tb["co"]), L.ptr(tb["cl"]),
-                                                   tb["n"], L.ptr(self.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), self.lr, self.betas[0],
-                                                   self.betas[1], self.eps, self.step_count, L.ptr(self.flat_grad) if sharded else None,
-                                                   L.stream_ptr()), "adamw_multi")
+        L.check(L.lib().sfmi_adamw_multi_shard_bc_f32(L.ptr(tb["p"]), L.ptr(tb["foff"]), L.ptr(tb["wd"]), L.ptr(tb["ct"]), L.ptr(tb["co"]), L.ptr(tb["cl"]),
+                                                      tb["n"], L.ptr(self.flat_grad), L.ptr(self.flat_m), L.ptr(self.flat_v), self.lr, self.betas[0],
+                                                      self.betas[1], self.eps, self.step_count,
+                                                      self._words.data_ptr() if self._capture is not None else None,      # captured step: bias corrections from the step words
+                                                      L.ptr(self.flat_grad) if sharded else None, L.stream_ptr()), "adamw_multi")
         if sharded and bk.sharded(name):
             if self.overlap_param_gather:
                 bk.launch_param_gather(name)
@@ -411,14 +429,20 @@ class GPTTrainer:
         from .weights import _fnv1a32
         p_embd, p_resid, p_attn = self.pdrop if dropout_key is not None else (0.0, 0.0, 0.0)
 
-        def site(p, name):          # (p, seed) of one dropout site
-            return (p, _fnv1a32(f"dropout-{dropout_key}-{name}")) if p > 0.0 else (0.0, 0)
+        def site(p, name):          # (p, seed, device address of the seed or None) of one dropout site
+            if p <= 0.0:
+                return (0.0, 0, None)
+            if self._capture is not None:      # captured step: the launch reads this site's seed from the step words at run time
+                idx = self._capture["sites"].setdefault(name, len(self._capture["sites"]))
+                assert idx < self._words.numel() - 2, "too many dropout sites for the step-word table"
+                return (p, 0, self._words.data_ptr() + 4 * (2 + idx))
+            return (p, _fnv1a32(f"dropout-{dropout_key}-{name}"), None)
 
         def drop_(x, ps, out=None):  # elementwise nn.Dropout (forward == backward): out = x * mask / (1 - p)
             if ps[0] == 0.0:
                 return x
             out = out if out is not None else self._f(*x.shape)
-            L.check(lib.sfmi_dropout_f32(L.ptr(x), L.ptr(out), x.numel(), ps[0], ps[1], L.stream_ptr()), "dropout")
+            L.check(lib.sfmi_dropout_sd_f32(L.ptr(x), L.ptr(out), x.numel(), ps[0], ps[1], ps[2], L.stream_ptr()), "dropout")
             return out
         # ---- forward, keeping what the backward needs --------------------------------------------------------
         saved = []
@@ -439,11 +463,11 @@ class GPTTrainer:
             lse_l = self._f(B, g.H, Lq)        # row log-sum-exps of the scaled scores: the attention backward starts from them
             if D == 64 * g.H and B * g.H * ((Lq + 63) // 64) <= 128:
                 # too few 64-row tiles for 256 CUs (the YAML's batch 1): 32-row tiles x two key-block groups per workgroup
-                L.check(lib.sfmi_attn_train_fwd_small_f32(L.ptr(qkv), L.ptr(y), L.ptr(lse_l), B, Lq, D, g.H, *site(p_attn, f"L{li}.attn"),
-                                                          L.stream_ptr()), "attn")
+                L.check(lib.sfmi_attn_train_fwd_small_sd_f32(L.ptr(qkv), L.ptr(y), L.ptr(lse_l), B, Lq, D, g.H, *site(p_attn, f"L{li}.attn"),
+                                                             L.stream_ptr()), "attn")
             else:
-                L.check(lib.sfmi_gpt_attn_prefill_lse_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
-                                                          g.H, g.Lmax + 1, None, *site(p_attn, f"L{li}.attn"), L.ptr(lse_l), L.stream_ptr()), "attn")
+                L.check(lib.sfmi_gpt_attn_prefill_lse_sd_f32(L.ptr(qkv), L.ptr(kv[0]), L.ptr(kv[1]), L.ptr(st["nval"]), L.ptr(y), B, Lq, D,
+                                                             g.H, g.Lmax + 1, None, *site(p_attn, f"L{li}.attn"), L.ptr(lse_l), L.stream_ptr()), "attn")
             r1 = self._f(M, D)
             self._gemm(y, ly.wproj, ly.bproj, resid, r1, M, D, D, drop=site(p_resid, f"L{li}.proj"))
             xn2 = self._f(M, D)
@@ -531,14 +555,14 @@ class GPTTrainer:
             dy = self._dx(dp, p + "wproj", ly.wproj, M, D, D)
             # attention
             dqkv = self._f(M, 3 * D)
-            L.check(lib.sfmi_attn_bwd_lse_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(s["lse"]), L.ptr(delta), L.ptr(dqkv), B, Lq, D, g.H,
-                                              *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn_bwd")
+            L.check(lib.sfmi_attn_bwd_lse_sd_f32(L.ptr(s["qkv"]), L.ptr(s["y"]), L.ptr(dy), L.ptr(s["lse"]), L.ptr(delta), L.ptr(dqkv), B, Lq, D, g.H,
+                                                 *site(p_attn, f"L{li}.attn"), L.stream_ptr()), "attn_bwd")
             # qkv
             self._aside(lambda: self._dW(dqkv, s["xn1"], M, 3 * D, D, p + "wqkv"), dqkv, s["xn1"])
             dxn1 = self._dx(dqkv, p + "wqkv", ly.wqkv, M, 3 * D, D)
             # ... and through the MLP dropout of the block below, unless a stage boundary rewrites dr first
             below = li > 0 and g.layers[li - 1].stage == ly.stage
-            dr, st1, dm_pre = self._ln_rows(dxn1, s["x_in"], ly.ln1[0], dr1, M, drop=site(p_resid, f"L{li - 1}.mlp") if below else (0.0, 0))
+            dr, st1, dm_pre = self._ln_rows(dxn1, s["x_in"], ly.ln1[0], dr1, M, drop=site(p_resid, f"L{li - 1}.mlp") if below else (0.0, 0, None))
             if not below:
                 dm_pre = None
             # the block's four bias gradients and two LayerNorm parameter gradients: one launch
@@ -664,6 +688,8 @@ class GPTTrainer:
         (see the constructor); else loss_and_grad -> all_reduce_grads -> optimizer_step.  The result is the same bit for bit."""
         rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
         key = f"{self.dropout_seed}-{rank}-{self.step_count}" if any(self.pdrop) else None
+        if self.use_graph and self.fused_optimizer and self.gemm_algo == "sk" and not self.buckets.active and not self._blas():
+            return self._training_step_graphed(c_indices, z_indices, key)
         if not self.fused_optimizer:
             loss = self.loss_and_grad(c_indices, z_indices, sync=True, dropout_key=key)
             self.all_reduce_grads()
@@ -680,3 +706,68 @@ class GPTTrainer:
         self.buckets.end_step()
         self.g.mark_decode_weights_stale()
         return loss
+
+    # ------------------------------------------------------------------ the step as one hipGraph
+    @torch.no_grad()
+    def _training_step_graphed(self, c_indices, z_indices, key):
+        """training_step() through a captured hipGraph (see the constructor).  `key`: this step's dropout key or None (eval-mode graph)."""
+        from .weights import _fnv1a32
+        dev = self.dev
+        c = torch.as_tensor(c_indices)
+        z = torch.as_tensor(z_indices)
+        gkey = (tuple(c.shape), tuple(z.shape), key is not None, self.lr, int(L.lib().sfmi_tune_generation()))
+        G = self._graphs.get(gkey)
+        if G is None and gkey not in self._graph_seen:
+            # first step of this shape: eager.  It builds what the step creates lazily OUTSIDE a capture pool (per-bucket AdamW tables,
+            # column-reduction scratch, kernel attributes) and is a full, ordinary step
+            self._graph_seen.add(gkey)
+            self.step_count += 1
+            try:
+                loss = self.loss_and_grad(c, z, sync=True, dropout_key=key, _fused=True)
+            except BaseException:
+                self.step_count -= 1
+                raise
+            finally:
+                self._fused = False
+            self.buckets.end_step()
+            self.g.mark_decode_weights_stale()
+            return loss
+        self.step_count += 1
+        if G is None:
+            cb = torch.zeros(tuple(c.shape), device=dev, dtype=torch.int32)
+            zb = torch.zeros(tuple(z.shape), device=dev, dtype=torch.int32)
+            self._capture = dict(sites={})
+            graph = torch.cuda.CUDAGraph()
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph):
+                    loss = self.loss_and_grad(cb, zb, sync=True, dropout_key="captured" if key is not None else None, _fused=True)
+                G = dict(graph=graph, c=cb, z=zb, loss=loss, sites=dict(self._capture["sites"]))
+            except BaseException:
+                self.step_count -= 1
+                raise
+            finally:
+                self._capture, self._fused = None, False
+            self._graphs[gkey] = G
+        # this step's words: AdamW bias corrections and the seed of every dropout site, one host -> device copy ahead of the replay
+        import ctypes as C
+        bc = (C.c_float * 2)()
+        L.check(L.lib().sfmi_adamw_bias_corrections(self.betas[0], self.betas[1], self.step_count, bc), "bias corrections")
+        slot = self._words_ring[self._words_next]
+        self._words_next = (self._words_next + 1) % len(self._words_ring)
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        w = slot["buf"]
+        w[:2] = torch.frombuffer(bytearray(bytes(bc)), dtype=torch.int32)
+        for name, idx in G["sites"].items():
+            v = _fnv1a32(f"dropout-{key}-{name}")
+            w[2 + idx] = v - (1 << 32) if v >= (1 << 31) else v
+        self._words.copy_(w, non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record()
+        G["c"].copy_(c.to(torch.int32), non_blocking=True)
+        G["z"].copy_(z.to(torch.int32), non_blocking=True)
+        G["graph"].replay()
+        self.buckets.end_step()
+        self.g.mark_decode_weights_stale()
+        return G["loss"].clone()

@@ -258,3 +258,31 @@ def test_training_step_gemm_forms_agree(dev):
     for name in ta.grad:
         a, b = ta.grad[name], tb.grad[name]
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, name
+
+
+@pytest.mark.parametrize("pdrop", [(0.0, 0.0, 0.0), (0.1, 0.15, 0.2)])
+def test_captured_training_step_is_bit_identical_to_the_eager_step(dev, pdrop):
+    """GPTTrainer(graph=True): forward + backward + per-bucket AdamW of a step replayed as ONE hipGraph (three streams; token tensors,
+    dropout seeds and AdamW's bias corrections read from device memory).  Five steps on two alternating batches - the first of each shape
+    eager, the second captured, then replays - must give the losses AND the weights / moments of the eager trainer bit for bit, with
+    dropout off and on (the per-step masks come from the step words)."""
+    from shapeformer_amd import weights as W
+    from shapeformer_amd.gpt import CondTupleGPT
+    from shapeformer_amd.train import GPTTrainer
+    t = np.load(os.path.join(G, "gpt_tiny.npz"))
+    c, z = torch.from_numpy(t["c_idx"]), torch.from_numpy(t["z_idx"])
+    batches = [(c, z), (c[:1], z[:1]), (c, z), (c.flip(0), z.flip(0)), (c[:1], z[:1]), (c, z), (c[:1], z[:1])]
+    out = []
+    for graph in (False, True):
+        kw = dict(n_embd=128, n_layers=(2, 1), block_size=96)
+        g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
+        tr = GPTTrainer(g, lr=1e-3, pdrop=pdrop, graph=graph)
+        losses = [float(tr.training_step(cc, zz).item()) for cc, zz in batches]
+        if graph:
+            assert len(tr._graphs) == 2 and tr.step_count == len(batches)
+            assert (len(next(iter(tr._graphs.values()))["sites"]) > 0) == any(pdrop)
+        out.append((losses, [p.detach().cpu().clone() for _, p, _ in tr.params], tr.flat_m.cpu().clone(), tr.flat_v.cpu().clone()))
+    (l0, w0, m0, v0), (l1, w1, m1, v1) = out
+    assert l0 == l1, (l0, l1)
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1)) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert l0[-2] < l0[0]
