@@ -312,6 +312,10 @@ int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpac
 /* structured Q^3 lattice of nputil.makeGrid 'ij' (xgutils/nputil.py:618-654) from a Q-entry f32 axis table */
 int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, const float* wpack, float* out, int B, int G,
                             int apply_sigmoid, void* stream);
+/* planes x0 <= ix < x1 of that lattice (ix = the slowest index): out (B, (x1 - x0) Q^2); the slabs concatenate to the whole-lattice result bit
+ * for bit (the z-slab split of one shape over the ranks; shapeformer.py:382-391, dec.py:62-100) */
+int sfmi_sdf_query_grid_slab_f32(const float* axis, int Q, int x0, int x1, const float* grid_cl, const float* wpack, float* out, int B, int G,
+                                 int apply_sigmoid, void* stream);
 /* nputil.sigmoid over stored logits (vqdif.py:262, shapeformer.py:388): y = 1 / (1 + exp(-x)), the fused epilogue's expression; may alias */
 int sfmi_sigmoid_f32(const float* x, float* y, long long n, void* stream);
 

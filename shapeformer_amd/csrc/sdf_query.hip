@@ -61,6 +61,7 @@ template <bool GRID_MODE>
 __global__ __launch_bounds__(512, 4) void sdf_query_kernel(
     const float* __restrict__ xyz,      // (B,N,3) in [-1,1]           (!GRID_MODE)
     const float* __restrict__ axis,     // (Q) f32 axis table          (GRID_MODE: pt = (ix*Q+iy)*Q+iz)
+    const float* __restrict__ axis_x,   // the table the SLOWEST lattice index reads: axis itself, or axis + x0 for the slab of planes x0 .. (N / Q^2 of them)
     const float* __restrict__ grid,     // (B,G,G,G,32) channels-last, [z][y][x][c]
     const float* __restrict__ wpack,    // SDF_PACK_FLOATS
     float* __restrict__ out,            // (B,N)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(512, 4) void sdf_query_kernel(
       const int iz = (int)(p32 - r * uq);
       const int ixx = (int)(r / uq);
       const int iy = (int)(r - (unsigned)ixx * uq);
-      px = axis[ixx]; py = axis[iy]; pz = axis[iz];
+      px = axis_x[ixx]; py = axis[iy]; pz = axis[iz];
     } else {
       const float* p = xyz + ((long long)b * N + pt) * 3;
       px = p[0]; py = p[1]; pz = p[2];
@@ -260,7 +261,7 @@ int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpac
   long long tiles = ((N + 31) >> 5) * B;
   if (tiles >= (1ll << 31)) return SFMI_EINVAL;
   hipLaunchKernelGGL(sdf_query_kernel<false>, dim3(sdf_grid_dim(tiles)), dim3(512),
-                     SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, xyz, nullptr, grid_cl, wpack,
+                     SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, xyz, nullptr, nullptr, grid_cl, wpack,
                      out, B, N, G, 0, apply_sigmoid);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
@@ -268,14 +269,23 @@ int sfmi_sdf_query_f32(const float* xyz, const float* grid_cl, const float* wpac
 
 // structured Q^3 query grid (nputil.makeGrid 'ij', shapeformer.py:219-220 / vqdif.py:223-224):
 // coordinates synthesised from the Q-entry axis table -> 4 B/pt of HBM traffic.
+int sfmi_sdf_query_grid_slab_f32(const float* axis, int Q, int x0, int x1, const float* grid_cl, const float* wpack, float* out,
+                                 int B, int G, int apply_sigmoid, void* stream);
 int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, const float* wpack, float* out,
                             int B, int G, int apply_sigmoid, void* stream) {
-  if (!axis || !grid_cl || !wpack || !out || B <= 0 || Q <= 0 || Q > 1024 || G < 2) return SFMI_EINVAL;   // Q^3 < 2^31 (32-bit lattice index)
-  long long N = (long long)Q * Q * Q;
+  return sfmi_sdf_query_grid_slab_f32(axis, Q, 0, Q, grid_cl, wpack, out, B, G, apply_sigmoid, stream);
+}
+// the planes x0 <= ix < x1 of the same lattice (ix is the slowest index of the 'ij' flatten, so a slab is a contiguous range of lattice
+// points): out (B, (x1 - x0) Q^2).  Every point's arithmetic is that of the whole-lattice call - the slabs of a lattice, computed by
+// different processes, concatenate to its result bit for bit (the z-slab split of ONE shape, dist.sdf_query_sharded).
+int sfmi_sdf_query_grid_slab_f32(const float* axis, int Q, int x0, int x1, const float* grid_cl, const float* wpack, float* out,
+                                 int B, int G, int apply_sigmoid, void* stream) {
+  if (!axis || !grid_cl || !wpack || !out || B <= 0 || Q <= 0 || Q > 1024 || G < 2 || x0 < 0 || x1 > Q || x0 >= x1) return SFMI_EINVAL;   // Q^3 < 2^31 (32-bit lattice index)
+  long long N = (long long)(x1 - x0) * Q * Q;
   long long tiles = ((N + 31) >> 5) * B;
   if (tiles >= (1ll << 31)) return SFMI_EINVAL;
   hipLaunchKernelGGL(sdf_query_kernel<true>, dim3(sdf_grid_dim(tiles)), dim3(512),
-                     SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, nullptr, axis, grid_cl, wpack,
+                     SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, nullptr, axis, axis + x0, grid_cl, wpack,
                      out, B, N, G, Q, apply_sigmoid);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;

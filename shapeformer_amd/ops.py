@@ -58,14 +58,16 @@ def sigmoid(x, out=None):
     return out
 
 
-def sdf_query_grid(axis, grid_cl, wpack, sigmoid=False, out=None):
-    """Structured Q^3 'ij' query grid from a Q-entry f32 axis table -> (B,Q^3,1)."""
+def sdf_query_grid(axis, grid_cl, wpack, sigmoid=False, out=None, x_range=None):
+    """Structured Q^3 'ij' query grid from a Q-entry f32 axis table -> (B,Q^3,1); x_range = (x0, x1): only the planes x0 <= ix < x1 of
+    the slowest lattice index -> (B,(x1-x0) Q^2,1), the same values the whole-lattice call computes for them."""
     _chk_cuda(axis, grid_cl, wpack)
     axis, grid_cl = _c(axis, torch.float32), _c(grid_cl, torch.float32)
     Q = axis.numel()
+    x0, x1 = (0, Q) if x_range is None else (int(x_range[0]), int(x_range[1]))
     B, G = grid_cl.shape[0], grid_cl.shape[1]
     if out is None:
-        out = torch.empty(B, Q ** 3, 1, device=axis.device, dtype=torch.float32)
-    L.check(L.lib().sfmi_sdf_query_grid_f32(L.ptr(axis), Q, L.ptr(grid_cl), L.ptr(wpack), L.ptr(out), B, G,
-                                            int(sigmoid), L.stream_ptr()), "sfmi_sdf_query_grid_f32")
+        out = torch.empty(B, (x1 - x0) * Q * Q, 1, device=axis.device, dtype=torch.float32)
+    L.check(L.lib().sfmi_sdf_query_grid_slab_f32(L.ptr(axis), Q, x0, x1, L.ptr(grid_cl), L.ptr(wpack), L.ptr(out), B, G,
+                                                 int(sigmoid), L.stream_ptr()), "sfmi_sdf_query_grid_slab_f32")
     return out

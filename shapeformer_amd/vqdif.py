@@ -526,13 +526,14 @@ class VQDIF:
         return self.decoder.decoder_grid_cl(code_cl, final_affine=final_affine)
 
     # ------------------------------------------------------------------ a20, a23
-    def decode_index(self, code_ind, Xtg=None, grid_Q=None, sigmoid=False):
-        """vqdif.py:60-76. Xtg (B,N,3) arbitrary points, or grid_Q=Q for the makeGrid 'ij' Q^3 lattice."""
+    def decode_index(self, code_ind, Xtg=None, grid_Q=None, sigmoid=False, x_range=None):
+        """vqdif.py:60-76. Xtg (B,N,3) arbitrary points, or grid_Q=Q for the makeGrid 'ij' Q^3 lattice (x_range = (x0, x1): only its planes
+        x0 <= ix < x1 - one rank's slab of dist.sdf_query_sharded)."""
         from . import ops
         grid = self.decoder_grid_cl(self.get_code_cl(code_ind))
         if grid_Q is not None:
             axis = torch.from_numpy(np.linspace(-1.0, 1.0, grid_Q).astype(np.float32)).to(self.dev)
-            return dict(logits=ops.sdf_query_grid(axis, grid, self.sdf_w, sigmoid=sigmoid))
+            return dict(logits=ops.sdf_query_grid(axis, grid, self.sdf_w, sigmoid=sigmoid, x_range=x_range))
         return dict(logits=ops.sdf_query(Xtg.to(self.dev, torch.float32), grid, self.sdf_w, sigmoid=sigmoid))
 
     def decode(self, grid_feat, Xtg):
