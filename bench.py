@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--no-subrecords", action="store_true", help="skip the config2 / config3 / config4 / train sub-records (BASELINE configs 2-5 on this GPU)")
     ap.add_argument("--mode", default="complete", choices=["complete", "train"],
                     help="complete: the shapes/s metric (default); train: DDP training step of the transformer (BASELINE config 5)")
+    ap.add_argument("--rank-crcs", action="store_true",
+                    help="every rank also runs the fixed-seed pass and the line carries each rank's token CRC pair (rank_token_crcs): the N-rank run "
+                         "against N single-process runs of the same inputs (--as-rank), tests/test_ddp_gpu.py")
+    ap.add_argument("--as-rank", type=int, default=None, help="TEST ONLY: draw the synthetic inputs rank R of an N-rank run draws (single process)")
     ap.add_argument("--share-device", action="store_true",
                     help="TEST ONLY: all ranks use cuda:0 and rendezvous over gloo (exercises the N-rank path on a 1-GPU box)")
     ap.add_argument("--force-dist", action="store_true",
@@ -485,6 +489,31 @@ def train_record(gpt, a, batches=(1, 8), steps=5, warm=2):
                                           "note": "model FLOPs 6 x 324.95 M parameters x tokens (attention FLOPs not counted)"}}
     del tr
     torch.cuda.empty_cache()
+    # the gradient-collective path with ONE rank over RCCL (its own process: `--mode train --force-dist` under torch.distributed.run), both
+    # synchronisation modes: what the compute stream waits for collectives when there is nobody to talk to - the baseline the first real
+    # multi-GPU run's allreduce_wait_ms / param_allgather_wait_ms are read against.  Eager steps (collectives stay outside a graph).
+    import socket
+    import subprocess
+    one = {}
+    for mode in ("ring", "rs_ag"):
+        try:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+                   str(port), os.path.abspath(__file__), "--gpus", "1", "--force-dist", "--mode", "train", "--grad-sync", mode, "--steps", "5", "--warmup", "2",
+                   "--train-lc", str(a.train_lc), "--train-lz", str(a.train_lz)]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+            ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
+            if r.returncode != 0 or not ln:
+                one[mode] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            d = json.loads(ln[-1])
+            one[mode] = {k: d.get(k) for k in ("ms_per_step", "allreduce_wait_ms", "param_allgather_wait_ms", "host_enqueue_ms_per_step")}
+        except Exception as e:      # a record, never a reason to lose the bench line
+            one[mode] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    rec["rccl_one_rank_batch1"] = dict(one, note="1 rank, RCCL process group forced on (26 bucket collectives per step run for real, over no links): the "
+                                                 "exposed waits of a step when communication is free; eager steps")
     return rec
 
 
@@ -507,7 +536,7 @@ def token_checksums(r, B, a, seed=None):
     crc_all = 0
     for x in rows:
         crc_all = zlib.crc32(x.tobytes(), crc_all)
-    key = f"batch{B}_arsteps{a.ar_steps}_points{a.points}_seed{seed}"
+    key = f"batch{B}_arsteps{a.ar_steps}_points{a.points}_seed{seed}" + (f"_rank{a.in_rank}" if getattr(a, "in_rank", 0) else "")
     path = os.path.join(ROOT, "tests", "golden", "bench_token_checksums.json")
     want = json.load(open(path)).get(key) if os.path.exists(path) else None
     out = {"token_crc32_row0": crc0, "token_crc32_all_rows": crc_all, "token_crc_key": key,
@@ -635,14 +664,15 @@ def main():
     B = a.batch
     # synthetic partial clouds; keep only shapes whose condition length leaves room for ALL ar_steps inside the
     # 812-token block (the unit of work is exactly 512 sampled tuples), decided before the timed region
-    kept, seed0 = [], 314 + rank * 16 * B
+    in_rank = a.in_rank = rank if a.as_rank is None else a.as_rank      # whose inputs: rank r of any run draws the same shapes
+    kept, seed0 = [], 314 + in_rank * 16 * B
     while sum(k.shape[0] for k in kept) < B:          # any rank, any seed: keep drawing until B shapes qualify
         n = max(16, B // 4)
         cand = torch.from_numpy(synthetic.make_batch(seed0, n, n_partial=a.points)["Xct"]).to(dev)
         seed0 += n
         lcs = torch.cat([pipe.encode_cloud(cand[i:i + 64])["Lc"].clone() for i in range(0, n, 64)])
         kept.append(cand[torch.nonzero(lcs <= gpt.Lmax - a.ar_steps).flatten()])
-        assert seed0 < 314 + (rank + 1) * 16 * B, "synthetic generator yields too few shapes with a short enough condition"
+        assert seed0 < 314 + (in_rank + 1) * 16 * B, "synthetic generator yields too few shapes with a short enough condition"
     Xct = torch.cat(kept)[:B].contiguous()
     del kept, cand
 
@@ -675,6 +705,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert int(r["steps"]) == a.ar_steps, f"only {r['steps']} of {a.ar_steps} AR steps were run"
+    rank_crcs = None
+    if a.rank_crcs:      # every rank's tokens of the fixed-seed pass (no data-path collective: each rank's result is its single-process result)
+        tc = token_checksums(step(CHECK_SEED), B, a)
+        mine = [tc["token_crc32_row0"], tc["token_crc32_all_rows"]]
+        rank_crcs = [mine]
+        if dist is not None:
+            rank_crcs = [None] * world
+            dist.all_gather_object(rank_crcs, mine)
     occ = r["occupancy"]
     sanity = dict(ar_steps_done=int(r["steps"]), occ_mean=round(float(occ.mean().item()), 4),
                   Lc_mean=round(float(r["Lc"].float().mean().item()), 1))
@@ -695,6 +733,8 @@ def main():
                        "other_batches": "--batch 320 = the round-2 workload (4 x 80-row chains); --batch 192 = round 1 (4 x 48); --batch 16 = BASELINE config 3's batch (one 16-row chain, also measured in this run: config3)"},
             "sanity": sanity,
         }
+        if rank_crcs is not None:
+            line["rank_token_crcs"] = rank_crcs
         if not a.no_roofline:
             # one extra, untimed pass with stage marks: where the batch time goes, and the AR loop against its HBM stream
             tm = {}

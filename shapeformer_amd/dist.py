@@ -353,3 +353,32 @@ def sample_n_sharded(gpt, c_tokens, Lc, sample_n, dist=None, **sample_kw):
     steps = parts[0]["steps"]
     assert all(p["steps"] == steps for p in parts), [p["steps"] for p in parts]
     return dict(samples=torch.cat([p["samples"] for p in parts], 0), log_prob=torch.cat([p["log_prob"] for p in parts], 0), steps=steps)
+
+
+def sdf_query_sharded(vq, code_ind, grid_Q, dist=None, sigmoid=False):
+    """SURVEY section 8(e), the other single-shape option: the Q^3 occupancy lattice of `decode_index` (vqdif.py:60-76 driven by
+    shapeformer.py:382-391; dec.py:62-100) split into slabs of lattice planes over the ranks.  Every rank holds the same code grid and
+    computes the decoder feature grid itself (UNet3D + Upsampler: 0.6 ms per shape, replicated - cheaper than shipping 33.5 MB per
+    shape); rank r evaluates the planes [Q r / W, Q (r + 1) / W) of the slowest lattice index (`VQDIF.decode_index(x_range=...)`,
+    csrc/sdf_query.hip: a contiguous range of lattice points) and the slabs are all-gathered - the one exchange of this path.
+    -> dict(logits (B, Q^3, 1)) on every rank, bit for bit what `decode_index` returns in one process: a point's arithmetic does not
+    depend on which slab it is in (tests/test_ddp_gpu.py)."""
+    Q = int(grid_Q)
+    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
+    rank = 0 if world == 1 else dist.get_rank()
+    if world == 1:
+        return vq.decode_index(code_ind, grid_Q=Q, sigmoid=sigmoid)
+    if Q < world:
+        raise ValueError(f"sdf_query_sharded: {Q} lattice planes for {world} ranks")
+    x0, x1 = Q * rank // world, Q * (rank + 1) // world
+    part = vq.decode_index(code_ind, grid_Q=Q, sigmoid=sigmoid, x_range=(x0, x1))["logits"]      # (B, (x1 - x0) Q^2, 1)
+    B = part.shape[0]
+    planes = -(-Q // world)                       # slabs differ by at most one plane: pad to the largest, gather, cut
+    pad = torch.zeros(B, planes * Q * Q, 1, device=part.device, dtype=part.dtype)
+    pad[:, :part.shape[1]] = part
+    staged = dist.get_backend() == "gloo" and pad.is_cuda      # gloo has no device path (the 2-process tests on a 1-GPU box)
+    send = pad.cpu() if staged else pad
+    got = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(got, send)
+    out = torch.cat([got[r][:, :(Q * (r + 1) // world - Q * r // world) * Q * Q] for r in range(world)], 1)
+    return dict(logits=out.to(part.device) if staged else out)

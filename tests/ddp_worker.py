@@ -76,6 +76,13 @@ def main():
     for name, skw in (("sn", dict(max_steps=40, seed=9, check_every=4)), ("sn_full", dict(max_steps=24, seed=9, stop_early=False, mask_invalid=False))):
         r = sample_n_sharded(g4, c1, torch.tensor([c1.shape[1]], dtype=torch.int32), 7, dist, **skw)
         out[name + "_samples"], out[name + "_logp"], out[name + "_steps"] = r["samples"].numpy(), r["log_prob"].numpy(), np.int64(r["steps"])
+    # ---- SURVEY 8(e), the other single-shape option: the 33^3 occupancy lattice of ONE shape in two slabs of planes (16 + 17), gathered
+    from shapeformer_amd.dist import sdf_query_sharded
+    from shapeformer_amd.vqdif import VQDIF
+    vq = VQDIF(res=16, device=dev)
+    code = torch.from_numpy(np.load(os.path.join(G, "vqdif16_small.npz"))["quant_ind"][:1].astype(np.int64)).to(dev)
+    for sg in (False, True):
+        out["sdf_slabs" + ("_sig" if sg else "")] = sdf_query_sharded(vq, code, 33, dist, sigmoid=sg)["logits"].cpu().numpy()
     # ---- VQDIF autoencoder: item r of a 2-item batch; gradients averaged, EMA statistics summed over ranks ------
     T = np.load(os.path.join(G, "vqdif_train.npz"))
     Xbd = np.concatenate([T["Xbd"], T["Xbd"][:, ::-1] * np.float32(0.9)], 0)      # two different clouds

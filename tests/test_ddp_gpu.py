@@ -230,3 +230,42 @@ def test_sample_n_of_one_shape_split_over_two_ranks(dev, ranks):
             assert np.array_equal(r[name + "_samples"], one["samples"].numpy()), name
             assert np.array_equal(r[name + "_logp"], one["log_prob"].numpy()), name
     assert len(set(map(tuple, one["samples"][1:, :, 0].tolist()))) > 1       # the stochastic rows differ from each other
+
+
+def test_sdf_lattice_of_one_shape_split_into_slabs_over_two_ranks(dev, ranks):
+    """SURVEY section 8(e), the other single-shape option (dist.sdf_query_sharded): the 33^3 occupancy lattice of ONE shape evaluated as two
+    slabs of lattice planes (16 on rank 0, 17 on rank 1: uneven on purpose), feature grid replicated, slabs all-gathered == `decode_index`
+    of one process bit for bit, logits and fused sigmoid; and the slab entry alone reproduces any plane range of the whole-lattice call."""
+    from shapeformer_amd.vqdif import VQDIF
+    vq = VQDIF(res=16, device=dev)
+    code = torch.from_numpy(np.load(os.path.join(G, "vqdif16_small.npz"))["quant_ind"][:1].astype(np.int64)).to(dev)
+    for sg, key in ((False, "sdf_slabs"), (True, "sdf_slabs_sig")):
+        one = vq.decode_index(code, grid_Q=33, sigmoid=sg)["logits"].cpu().numpy()
+        assert one.shape == (1, 33 ** 3, 1) and np.isfinite(one).all()
+        for r in ranks:
+            assert np.array_equal(r[key], one), key
+    whole = vq.decode_index(code, grid_Q=20)["logits"]
+    for x0, x1 in ((0, 1), (3, 11), (19, 20), (0, 20)):
+        part = vq.decode_index(code, grid_Q=20, x_range=(x0, x1))["logits"]
+        assert torch.equal(part, whole[:, x0 * 400:x1 * 400])
+
+
+def test_bench_two_ranks_sharing_the_device_sample_what_single_processes_sample(dev):
+    """bench.py end to end as the driver launches it for N = 2 (torch.distributed.run, one process per rank; here both ranks on cuda:0
+    over gloo): the shapes are sharded with no data-path collective, so each rank's tokens of the fixed-seed pass must be exactly the
+    tokens ONE process samples for that rank's inputs (`--as-rank`), and the line's aggregate is over both ranks."""
+    import json
+    base = ["--batch", "24", "--ar-steps", "48", "--decode-res", "32", "--points", "4096", "--steps", "1", "--warmup", "1", "--no-roofline",
+            "--no-subrecords", "--no-cpu-baseline", "--rank-crcs"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(args):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + base, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    two = run(["--gpus", "2", "--share-device"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and len(two["rank_token_crcs"]) == 2
+    singles = [run(["--gpus", "1", "--as-rank", str(r)])["rank_token_crcs"][0] for r in range(2)]
+    assert two["rank_token_crcs"] == singles, (two["rank_token_crcs"], singles)
+    assert singles[0] != singles[1]                      # the ranks really work on different shapes
+    assert two["sanity"]["ar_steps_done"] == 48
