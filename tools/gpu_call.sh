@@ -6,7 +6,7 @@
 #
 #   pytest[=<pytest args>]        python -m pytest <args, default "tests -m gpu -x -q">        -> pytest_<n>.txt
 #   py=<script and args>          python <script and args>                                       -> py_<n>.txt
-#   sweep=<tools/sweeps file>[,reps]   tools/ar_sweep.py < file                                  -> ar_sweep_<file>.txt
+#   sweep=<tools/sweeps file>[,reps[,steps]]   tools/ar_sweep.py < file                           -> ar_sweep_<file>.txt
 #   bench[=<bench.py args>]       python bench.py <args, default the driver's "--gpus 1 --steps 20 --warmup 5">  -> bench_<n>.json
 #   trace=<name>:<command>        rocprofv3 --kernel-trace --stats of <command> (tools/prof_run.sh)  -> prof_<name>.txt
 #   pmc=<name>:<counters>:<kernel LIKE pattern>:<command>   one rocprofv3 --pmc pass (--kernel-trace only, as the pool requires) and the
@@ -23,12 +23,14 @@ for step in "$@"; do
   case $kind in
     pytest)
       timeout 1500 python -m pytest ${arg:-tests -m gpu -x -q} > $O/pytest_$n.txt 2>&1; echo "pytest rc $?" >> $O/pytest_$n.txt; tail -n 6 $O/pytest_$n.txt ;;
+    ubench)      # ubench=<name>: compile tools/ubench/<name>.hip and run it                      -> ubench_<name>.txt
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/$arg.hip -o /tmp/ub_$arg > $O/ubench_$arg.txt 2>/dev/null; timeout 300 /tmp/ub_$arg >> $O/ubench_$arg.txt 2>&1; echo "rc $?" >> $O/ubench_$arg.txt; tail -n 20 $O/ubench_$arg.txt ;;
     py)
       timeout 900 python $arg > $O/py_$n.txt 2>&1; echo "rc $?" >> $O/py_$n.txt; tail -n 40 $O/py_$n.txt ;;
     sweep)
-      f=${arg%%,*}; reps=2; [[ "$arg" == *,* ]] && reps=${arg#*,}
+      IFS=, read -r f reps steps <<< "$arg"; reps=${reps:-2}; steps=${steps:-512}
       b=$(basename $f .txt)
-      timeout 900 python tools/ar_sweep.py --out $O/ar_sweep_$b.txt --reps $reps < $f > $O/ar_sweep_$b.log 2>&1; echo "rc $?"; tail -n 12 $O/ar_sweep_$b.txt ;;
+      timeout 900 python tools/ar_sweep.py --out $O/ar_sweep_$b.txt --reps $reps --steps $steps < $f > $O/ar_sweep_$b.log 2>&1; echo "rc $?"; tail -n 12 $O/ar_sweep_$b.txt ;;
     bench)
       timeout 1200 python bench.py ${arg:---gpus 1 --steps 20 --warmup 5} > $O/bench_$n.json 2> $O/bench_$n.err; echo "bench rc $?"; cut -c1-600 $O/bench_$n.json; tail -n 3 $O/bench_$n.err ;;
     trace)
