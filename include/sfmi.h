@@ -194,7 +194,7 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_packed, float* Kc, float* Vc
 /* the same launch in its SELF-PARTITIONING form (no reference counterpart; scheduling only, results identical): workgroups that find
  * themselves on a compute unit with CU id >= cut (in its shader engine), or on one that already holds `cap` workgroups of this launch,
  * leave at once; the others pull (row, head) items from a device queue until it is empty.  part = sfmi_gpt_attn_part_ints() zeroed
- * ints per chain (re-armed by the kernel); blk required; grid = workgroups launched (0: four per compute unit). */
+ * ints per chain (re-armed by the kernel); blk required; grid = workgroups launched (0: sixteen per compute unit). */
 size_t sfmi_gpt_attn_part_ints(void);
 int sfmi_gpt_attn_decode_part_f32(const float* qkv_packed, float* Kc, float* Vc, const int* len, float* y_packed, int B, int D, int H,
                                   int Lmax, int* sem, int* blk, int lanes, unsigned long long* prof, int* part, int cut, int cap,

@@ -1438,7 +1438,7 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
 }
 // the same launch in its SELF-PARTITIONING form (attn_decode_part_kernel): `part` = SFMI_ATTN_PART_INTS ints of this chain, zero before the
 // first launch (the kernel re-arms them); compute units with CU id < cut (per shader engine) are the attention's, at most cap workgroups
-// of one launch per unit; grid = workgroups launched (0: four per compute unit of the device).  blk is required.  Bit-identical results.
+// of one launch per unit; grid = workgroups launched (0: sixteen per compute unit of the device).  blk is required.  Bit-identical results.
 size_t sfmi_gpt_attn_part_ints(void) { return SFMI_ATTN_PART_INTS; }
 int sfmi_gpt_attn_decode_part_f32(const float* qkv_part, float* Kc, float* Vc, const int* len, float* y, int B, int D, int H, int Lmax,
                                   int* sem, int* blk, int lanes, unsigned long long* prof, int* part, int cut, int cap, int grid, void* stream) {
@@ -1451,7 +1451,7 @@ int sfmi_gpt_attn_decode_part_f32(const float* qkv_part, float* Kc, float* Vc, c
   if (grid == 0) {
     static int ncu = 0;
     if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return SFMI_EINVAL; ncu = pr.multiProcessorCount; }
-    grid = 4 * ncu;
+    grid = 16 * ncu;      // a small grid is burnt through on the first CU of each shader engine (the dispatcher is first-fit and a leaving workgroup frees its slot at once): 4 per CU left one or two workgroups with all the items (280 ms per step), 16 per CU fills the chip
   }
   hipStream_t st = (hipStream_t)stream;
   if (sem) hipLaunchKernelGGL(attn_gate_kernel, dim3(1), dim3(64), 0, st, sem, lanes);

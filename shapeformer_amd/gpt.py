@@ -443,7 +443,7 @@ class CondTupleGPT:
     ATTN_LANES = 2
     # Self-partitioning decode attention of the interleaved chains (csrc/gpt.hip:attn_decode_part_kernel): (cut, cap, grid) - compute units
     # with CU id < cut in their shader engine (of 8-9) belong to the KV streams, at most cap workgroups of one launch per unit, grid
-    # workgroups launched (0 = four per CU); cut 0 = off (one workgroup per item on every CU).  Scheduling only: bit-identical tokens.
+    # workgroups launched (0 = sixteen per CU); cut 0 = off (one workgroup per item on every CU).  Scheduling only: bit-identical tokens.
     ATTN_PART = (0, 1, 0)
     MAX_CHAIN_ROWS = 192   # rows per decode chain: row groups of up to 6 row tiles (96 rows) per decode-GEMM workgroup; larger batches = several chains
     # shared_prefix="auto" (the sample_n copies of one condition, shapeformer.py:222-260): one prefill and one copy of the condition's

@@ -98,7 +98,7 @@ class GPTTrainer:
         extra = _concurrent_streams(gpt.dev, (1 if side_stream else 0) + (1 if (side_stream and fused_optimizer) else 0))
         self._side = extra[0] if side_stream else None
         self._opt_stream = extra[1] if (side_stream and fused_optimizer) else None
-        self._on_side, self._keep = False, []
+        self._on_side, self._keep, self._defer_side = False, [], None
         self.g, self.dev, self.D = gpt, gpt.dev, gpt.D
         # (embd_pdrop, resid_pdrop, attn_pdrop): the model's (CondTupleGPT ctor kwargs / YAML) unless given
         self.pdrop = tuple(float(v) for v in (pdrop if pdrop is not None else getattr(gpt, "pdrop", (0.0, 0.0, 0.0))))
@@ -255,6 +255,10 @@ class GPTTrainer:
         joined (their memory must not be handed to a later main-stream allocation while the side stream still reads it)."""
         if self._side is None:
             return fn()
+        if self._defer_side is not None:      # captured step: a block's side work is issued as ONE fork at the block's end (_ready)
+            self._defer_side.append(fn)
+            self._keep.extend(tensors)
+            return None
         ev = torch.cuda.Event()
         ev.record()
         self._side.wait_event(ev)
@@ -271,7 +275,7 @@ class GPTTrainer:
         if self._side is not None:
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._side)
-            if self._opt_stream is not None:
+            if self._opt_stream is not None and self._capture is None:      # (the captured step never forks onto the optimizer stream)
                 cur.wait_stream(self._opt_stream)
             self._keep.clear()
 
@@ -327,7 +331,7 @@ class GPTTrainer:
             if self._sync:
                 self.buckets.ready(name)
             if self._fused:
-                if self._opt_stream is None:
+                if self._opt_stream is None or self._capture is not None:      # captured step (no collective to wait for): AdamW follows on the side stream
                     self._opt_bucket(name)
                 else:      # optimizer stream: after the side stream's work so far (this bucket's weight gradients, its collective launch)
                     ev = torch.cuda.Event()
@@ -335,6 +339,15 @@ class GPTTrainer:
                     self._opt_stream.wait_event(ev)
                     with torch.cuda.stream(self._opt_stream):
                         self._opt_bucket(name)
+        if self._defer_side is not None:
+            # one cross-stream dependency per bucket instead of five: a fork of a captured hipGraph costs ~20 us of latency on its branch
+            # (profiles/r04_b16_experiments.md), and with five per block the replayed step was SLOWER than the eager one (16.8 vs 14.7 ms)
+            queued, self._defer_side = self._defer_side, None
+            try:
+                self._aside(lambda: [f() for f in queued] + [go()])
+            finally:
+                self._defer_side = []
+            return
         if self._side is not None and ((self._sync and self.buckets.active) or self._fused):
             self._aside(go)
         else:
@@ -737,6 +750,7 @@ class GPTTrainer:
             cb = torch.zeros(tuple(c.shape), device=dev, dtype=torch.int32)
             zb = torch.zeros(tuple(z.shape), device=dev, dtype=torch.int32)
             self._capture = dict(sites={})
+            self._defer_side = [] if self._side is not None else None
             graph = torch.cuda.CUDAGraph()
             try:
                 torch.cuda.synchronize()
@@ -747,7 +761,7 @@ class GPTTrainer:
                 self.step_count -= 1
                 raise
             finally:
-                self._capture, self._fused = None, False
+                self._capture, self._fused, self._defer_side = None, False, None
             self._graphs[gkey] = G
         # this step's words: AdamW bias corrections and the seed of every dropout site, one host -> device copy ahead of the replay
         import ctypes as C
