@@ -316,6 +316,10 @@ int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, cons
  * for bit (the z-slab split of one shape over the ranks; shapeformer.py:382-391, dec.py:62-100) */
 int sfmi_sdf_query_grid_slab_f32(const float* axis, int Q, int x0, int x1, const float* grid_cl, const float* wpack, float* out, int B, int G,
                                  int apply_sigmoid, void* stream);
+/* the same on a decoder grid whose last GroupNorm (updown.py:119-132) has not been applied: its per-(shape, channel) affine aff_scale / aff_shift
+ * (B,32) is applied to the interpolated features inside the kernel (the trilinear weights of the 'border' gather sum to one); both NULL: final grid */
+int sfmi_sdf_query_grid_aff_f32(const float* axis, int Q, int x0, int x1, const float* grid_cl, const float* aff_scale, const float* aff_shift,
+                                const float* wpack, float* out, int B, int G, int apply_sigmoid, void* stream);
 /* nputil.sigmoid over stored logits (vqdif.py:262, shapeformer.py:388): y = 1 / (1 + exp(-x)), the fused epilogue's expression; may alias */
 int sfmi_sigmoid_f32(const float* x, float* y, long long n, void* stream);
 

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "sfmi_sdf_query_grid_f32": (i32, [c_ptr, i32, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
     "sfmi_sigmoid_f32": (i32, [c_ptr, c_ptr, i64, c_ptr]),
     "sfmi_sdf_query_grid_slab_f32": (i32, [c_ptr, i32, i32, i32, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
+    "sfmi_sdf_query_grid_aff_f32": (i32, [c_ptr, i32, i32, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
     # encoder (per-point path)
     "sfmi_enc_pack_floats": (sz, []),
     "sfmi_enc_pack_weights": (i32, [c_ptr] * 10),

@@ -57,7 +57,11 @@ __device__ __forceinline__ SdfAxis sdf_axis(float x_api, int G) {
   return a;
 }
 
-template <bool GRID_MODE>
+// AFF: the decoder grid's last GroupNorm (updown.py:119-132: ... Conv, ReLU, GroupNorm of the Upsampler's final block) is handed over as
+// its per-(shape, channel) affine instead of being applied to the 64^3 x 32 grid in a pass of its own (67 MB of traffic per shape): the
+// trilinear weights of the 'border' gather sum to one, so  interp(x * scale + shift) = interp(x) * scale + shift  - 16 FMAs per lane on
+// the gathered features (fp32 rounding differs from the applied form by ~1e-7 of the feature).
+template <bool GRID_MODE, bool AFF = false>
 __global__ __launch_bounds__(512, 4) void sdf_query_kernel(
     const float* __restrict__ xyz,      // (B,N,3) in [-1,1]           (!GRID_MODE)
     const float* __restrict__ axis,     // (Q) f32 axis table          (GRID_MODE: pt = (ix*Q+iy)*Q+iz)
@@ -65,7 +69,8 @@ __global__ __launch_bounds__(512, 4) void sdf_query_kernel(
     const float* __restrict__ grid,     // (B,G,G,G,32) channels-last, [z][y][x][c]
     const float* __restrict__ wpack,    // SDF_PACK_FLOATS
     float* __restrict__ out,            // (B,N)
-    int B, long long N, int G, int Q, int apply_sigmoid) {
+    int B, long long N, int G, int Q, int apply_sigmoid,
+    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr) {   // AFF: (B,32) each
   extern __shared__ __attribute__((aligned(16))) float lds[];
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(wpack);
@@ -126,6 +131,17 @@ __global__ __launch_bounds__(512, 4) void sdf_query_kernel(
         f32x4 v = cp[2 * g];
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[4 * g + j] = fmaf(v[j], w, c[4 * g + j]);
+      }
+    }
+
+    if (AFF) {
+      const f32x4* sp = reinterpret_cast<const f32x4*>(aff_scale + b * 32 + 4 * hi);
+      const f32x4* tp = reinterpret_cast<const f32x4*>(aff_shift + b * 32 + 4 * hi);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 sc = sp[2 * g], sh = tp[2 * g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[4 * g + j] = fmaf(c[4 * g + j], sc[j], sh[j]);
       }
     }
 
@@ -278,15 +294,30 @@ int sfmi_sdf_query_grid_f32(const float* axis, int Q, const float* grid_cl, cons
 // the planes x0 <= ix < x1 of the same lattice (ix is the slowest index of the 'ij' flatten, so a slab is a contiguous range of lattice
 // points): out (B, (x1 - x0) Q^2).  Every point's arithmetic is that of the whole-lattice call - the slabs of a lattice, computed by
 // different processes, concatenate to its result bit for bit (the z-slab split of ONE shape, dist.sdf_query_sharded).
+int sfmi_sdf_query_grid_aff_f32(const float* axis, int Q, int x0, int x1, const float* grid_cl, const float* aff_scale, const float* aff_shift,
+                                const float* wpack, float* out, int B, int G, int apply_sigmoid, void* stream);
 int sfmi_sdf_query_grid_slab_f32(const float* axis, int Q, int x0, int x1, const float* grid_cl, const float* wpack, float* out,
                                  int B, int G, int apply_sigmoid, void* stream) {
+  return sfmi_sdf_query_grid_aff_f32(axis, Q, x0, x1, grid_cl, nullptr, nullptr, wpack, out, B, G, apply_sigmoid, stream);
+}
+// the same on a feature grid whose last GroupNorm has NOT been applied: aff_scale / aff_shift (B,32) = that GroupNorm's per-(shape, channel)
+// affine (sfmi_groupnorm_coeffs_f32), applied to the interpolated features inside the kernel (both NULL: the grid is final).
+// Replaces the apply pass of updown.py:119-132's last GroupNorm in front of dec.py:62-100.
+int sfmi_sdf_query_grid_aff_f32(const float* axis, int Q, int x0, int x1, const float* grid_cl, const float* aff_scale, const float* aff_shift,
+                                const float* wpack, float* out, int B, int G, int apply_sigmoid, void* stream) {
+  if ((aff_scale == nullptr) != (aff_shift == nullptr)) return SFMI_EINVAL;
   if (!axis || !grid_cl || !wpack || !out || B <= 0 || Q <= 0 || Q > 1024 || G < 2 || x0 < 0 || x1 > Q || x0 >= x1) return SFMI_EINVAL;   // Q^3 < 2^31 (32-bit lattice index)
   long long N = (long long)(x1 - x0) * Q * Q;
   long long tiles = ((N + 31) >> 5) * B;
   if (tiles >= (1ll << 31)) return SFMI_EINVAL;
-  hipLaunchKernelGGL(sdf_query_kernel<true>, dim3(sdf_grid_dim(tiles)), dim3(512),
-                     SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, nullptr, axis, axis + x0, grid_cl, wpack,
-                     out, B, N, G, Q, apply_sigmoid);
+  if (aff_scale)
+    hipLaunchKernelGGL((sdf_query_kernel<true, true>), dim3(sdf_grid_dim(tiles)), dim3(512),
+                       SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, nullptr, axis, axis + x0, grid_cl, wpack,
+                       out, B, N, G, Q, apply_sigmoid, aff_scale, aff_shift);
+  else
+    hipLaunchKernelGGL((sdf_query_kernel<true, false>), dim3(sdf_grid_dim(tiles)), dim3(512),
+                       SDF_PACK_FLOATS * sizeof(float), (hipStream_t)stream, nullptr, axis, axis + x0, grid_cl, wpack,
+                       out, B, N, G, Q, apply_sigmoid, nullptr, nullptr);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

@@ -58,9 +58,10 @@ def sigmoid(x, out=None):
     return out
 
 
-def sdf_query_grid(axis, grid_cl, wpack, sigmoid=False, out=None, x_range=None):
+def sdf_query_grid(axis, grid_cl, wpack, sigmoid=False, out=None, x_range=None, affine=None):
     """Structured Q^3 'ij' query grid from a Q-entry f32 axis table -> (B,Q^3,1); x_range = (x0, x1): only the planes x0 <= ix < x1 of
-    the slowest lattice index -> (B,(x1-x0) Q^2,1), the same values the whole-lattice call computes for them."""
+    the slowest lattice index -> (B,(x1-x0) Q^2,1), the same values the whole-lattice call computes for them.  affine = (scale, shift)
+    (B,32) each: grid_cl is the decoder grid BEFORE its last GroupNorm, whose affine the kernel applies to the interpolated features."""
     _chk_cuda(axis, grid_cl, wpack)
     axis, grid_cl = _c(axis, torch.float32), _c(grid_cl, torch.float32)
     Q = axis.numel()
@@ -68,6 +69,8 @@ def sdf_query_grid(axis, grid_cl, wpack, sigmoid=False, out=None, x_range=None):
     B, G = grid_cl.shape[0], grid_cl.shape[1]
     if out is None:
         out = torch.empty(B, (x1 - x0) * Q * Q, 1, device=axis.device, dtype=torch.float32)
-    L.check(L.lib().sfmi_sdf_query_grid_slab_f32(L.ptr(axis), Q, x0, x1, L.ptr(grid_cl), L.ptr(wpack), L.ptr(out), B, G,
-                                                 int(sigmoid), L.stream_ptr()), "sfmi_sdf_query_grid_slab_f32")
+    sc, sh = (None, None) if affine is None else (_c(affine[0], torch.float32), _c(affine[1], torch.float32))
+    assert affine is None or (sc.shape == (B, 32) and sh.shape == (B, 32))
+    L.check(L.lib().sfmi_sdf_query_grid_aff_f32(L.ptr(axis), Q, x0, x1, L.ptr(grid_cl), L.ptr(sc), L.ptr(sh), L.ptr(wpack), L.ptr(out), B, G,
+                                                int(sigmoid), L.stream_ptr()), "sfmi_sdf_query_grid_aff_f32")
     return out

@@ -530,10 +530,13 @@ class VQDIF:
         """vqdif.py:60-76. Xtg (B,N,3) arbitrary points, or grid_Q=Q for the makeGrid 'ij' Q^3 lattice (x_range = (x0, x1): only its planes
         x0 <= ix < x1 - one rank's slab of dist.sdf_query_sharded)."""
         from . import ops
-        grid = self.decoder_grid_cl(self.get_code_cl(code_ind))
         if grid_Q is not None:
+            # lattice route: the Upsampler's last GroupNorm travels as its (B,32) affine and is applied inside the query kernel
+            # (csrc/sdf_query.hip AFF) instead of in a 67 MB-per-shape pass over the 64^3 x 32 grid
+            grid, sc, sh = self.decoder_grid_cl(self.get_code_cl(code_ind), final_affine=False)
             axis = torch.from_numpy(np.linspace(-1.0, 1.0, grid_Q).astype(np.float32)).to(self.dev)
-            return dict(logits=ops.sdf_query_grid(axis, grid, self.sdf_w, sigmoid=sigmoid, x_range=x_range))
+            return dict(logits=ops.sdf_query_grid(axis, grid, self.sdf_w, sigmoid=sigmoid, x_range=x_range, affine=(sc, sh)))
+        grid = self.decoder_grid_cl(self.get_code_cl(code_ind))
         return dict(logits=ops.sdf_query(Xtg.to(self.dev, torch.float32), grid, self.sdf_w, sigmoid=sigmoid))
 
     def decode(self, grid_feat, Xtg):

@@ -117,7 +117,9 @@ def test_config4_res32_256cubed_stress(dev):
     pts = torch.from_numpy(np.stack([ax[ix], ax[iy], ax[iz]], -1))[None].expand(8, -1, -1).contiguous()
     grid = vq.decoder_grid_cl(vq.get_code_cl(q))
     pm = ops.sdf_query(pts.to(dev), grid, vq.sdf_w)
-    assert torch.equal(pm[:, :, 0], lg[:, sel.to(dev), 0])
+    # the lattice route applies the decoder grid's last GroupNorm inside the query kernel (to the interpolated features), the point route
+    # reads the grid with the affine applied: the same value up to fp32 rounding of the 32 feature channels (bit-equal until round 5)
+    assert float((pm[:, :, 0] - lg[:, sel.to(dev), 0]).abs().max()) < 2e-5 * max(1.0, float(pm.abs().max()))
     # oracle on shape 0 at the sampled points
     sd_t = O.to_torch_sd(W.make_state_dict(W.vqdif_spec(32)))
     ref = O.decode_index(sd_t, q[:1].cpu(), pts[:1])

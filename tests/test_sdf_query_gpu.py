@@ -48,6 +48,29 @@ def test_sdf_query_grid_mode_matches_point_mode_and_oracle(dev, vq16_sd, vq16_sd
     torch.testing.assert_close(s, torch.sigmoid(ref), atol=1e-5, rtol=1e-4)
 
 
+def test_sdf_query_with_the_last_groupnorm_applied_in_the_kernel(dev, vq16_sd, vq16_sd_t):
+    """sfmi_sdf_query_grid_aff_f32 (csrc/sdf_query.hip AFF): the decoder grid BEFORE its last GroupNorm + that GroupNorm's (B,32) affine ==
+    the query on the affined grid (the trilinear 'border' weights sum to one) to fp32 rounding, == the oracle on the affined grid; a slab
+    of planes of the affine form is bit-equal to the same planes of its whole-lattice call."""
+    from oracle import vqdif_oracle as O
+    from shapeformer_amd import ops
+    Q, B = 24, 3
+    grid = _rand_grid(B, 5)
+    g = torch.Generator().manual_seed(7)
+    sc, sh = torch.rand(B, 32, generator=g) + 0.5, torch.randn(B, 32, generator=g) * 0.3
+    axis = torch.from_numpy(np.linspace(-1.0, 1.0, Q).astype(np.float32)).to(dev)
+    wp = torch.from_numpy(ops.sdf_pack_weights(vq16_sd)).to(dev)
+    raw_cl = grid.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    aff_grid = grid * sc[:, :, None, None, None] + sh[:, :, None, None, None]
+    a = ops.sdf_query_grid(axis, raw_cl, wp, affine=(sc.to(dev), sh.to(dev))).cpu()
+    b = ops.sdf_query_grid(axis, aff_grid.permute(0, 2, 3, 4, 1).contiguous().to(dev), wp).cpu()
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+    pts = torch.from_numpy(O.make_grid(Q))[None].expand(B, -1, -1).contiguous()
+    torch.testing.assert_close(a, O.sdf_query(vq16_sd_t, aff_grid, pts), atol=ATOL, rtol=RTOL)
+    part = ops.sdf_query_grid(axis, raw_cl, wp, affine=(sc.to(dev), sh.to(dev)), x_range=(5, 17)).cpu()
+    assert torch.equal(part, a[:, 5 * Q * Q:17 * Q * Q])
+
+
 def test_sdf_query_linearity_in_fc_out(dev, vq16_sd):
     """Size-independent property at the full 128^3 size: scaling fc_out scales (logit - bias)."""
     from shapeformer_amd import ops
