@@ -80,6 +80,18 @@ int sfmi_conv3d_cl_f32(const float* x, const float* wT, const float* in_scale, c
 int sfmi_conv_pack_weight_subpixel(const float* w, int Cout, int Cin, float* out);   /* out: 64*Cout*Cin floats */
 int sfmi_conv3d_up2_cl_f32(const float* x, const float* wsub, const float* in_scale, const float* in_shift, const float* bias,
                            float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int relu, void* stream);
+/* the two convolutions with the GroupNorm statistics of THEIR OUTPUT taken in the epilogue (updown.py:119-132: Conv, ReLU, GroupNorm - the
+ * statistics pass over y disappears): partial (B, *splits, Cout, 2) f64 {sum, sum of squares} per shape and tile, consumed by
+ * sfmi_groupnorm_coeffs_partial_f32 (V = voxels of y per shape).  Return SFMI_EINVAL BEFORE launching anything when the geometry has no
+ * statistics-capable instance (64- or 32-channel stride-1 x-reuse forms): the caller then uses the plain entry + sfmi_groupnorm_coeffs_f32.
+ * y is bit-identical to the plain entries'. */
+int sfmi_conv3d_cl_stats_f32(const float* x, const float* wT, const float* in_scale, const float* in_shift, const float* bias, float* y, int B,
+                             int Di, int Hi, int Wi, int Cin, int Cout, int KS, int stride, int pad, int up, int relu, double* partial, int* splits,
+                             void* stream);
+int sfmi_conv3d_up2_cl_stats_f32(const float* x, const float* wsub, const float* in_scale, const float* in_shift, const float* bias,
+                                 float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int relu, double* partial, int* splits, void* stream);
+int sfmi_groupnorm_coeffs_partial_f32(const double* partial, const float* gamma, const float* beta, float* scale, float* shift, int B, int V, int C,
+                                      int S, int groups, float eps, void* stream);
 int sfmi_gn_splits(int V);
 /* nn.GroupNorm statistics -> scale/shift (B,C) with GN(x) == x*scale+shift; partial: B*sfmi_gn_splits(V)*C*2 doubles */
 int sfmi_groupnorm_coeffs_f32(const float* x, const float* gamma, const float* beta, float* scale, float* shift,

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsfmi.so")
 
 _lib = None
+SFMI_OK, SFMI_EINVAL = 0, -1      # include/sfmi.h
 
 c_f32p = C.c_void_p
 c_ptr = C.c_void_p
@@ -72,6 +73,9 @@ PROTOTYPES = {
     "sfmi_conv3d_cl_f32": (i32, [c_ptr] * 6 + [i32] * 11 + [c_ptr]),
     "sfmi_conv_pack_weight_subpixel": (i32, [c_ptr, i32, i32, c_ptr]),
     "sfmi_conv3d_up2_cl_f32": (i32, [c_ptr] * 6 + [i32] * 7 + [c_ptr]),
+    "sfmi_conv3d_cl_stats_f32": (i32, [c_ptr] * 6 + [i32] * 11 + [c_ptr, c_ptr, c_ptr]),
+    "sfmi_conv3d_up2_cl_stats_f32": (i32, [c_ptr] * 6 + [i32] * 7 + [c_ptr, c_ptr, c_ptr]),
+    "sfmi_groupnorm_coeffs_partial_f32": (i32, [c_ptr] * 5 + [i32, i32, i32, i32, i32, C.c_float, c_ptr]),
     "sfmi_gn_splits": (i32, [i32]),
     "sfmi_groupnorm_coeffs_f32": (i32, [c_ptr] * 6 + [i32, i32, i32, i32, C.c_float, c_ptr]),
     "sfmi_affine_cl_f32": (i32, [c_ptr] * 4 + [i32, i64, i32, c_ptr]),

@@ -28,6 +28,9 @@ struct ConvArgs {
   // leading pad per axis padz/pady/padx (instead of `pad`), output voxel (z,y,x) of the (Do,Ho,Wo) lattice is written to
   // voxel (2z+spz, 2y+spy, 2x+spx) of the (2Do,2Ho,2Wo) result
   int sp_on, spz, spy, spx, padz, pady, padx;
+  // ST instances: per-(tile, output channel) sum / sum of squares of the written values (f64 pairs, the layout gn_coeffs_kernel reads:
+  // [shape][stats_S splits][Cout][2]); this launch's tiles of a shape are splits stats_sp0 .. (a sub-pixel parity launch has its own range)
+  double* stats; int stats_S, stats_sp0;
 };
 
 // XR ("x reuse", stride-1 convolutions whose M tile is made of whole x-rows of the output; narrow output-channel tiles): the taps of
@@ -37,7 +40,9 @@ struct ConvArgs {
 // re-stages the activation tile for every tap; with 32 or 64 output channels per workgroup that staging is what bounds the kernel.
 // J = 32-voxel tiles per wave (2; 4 for the 32-channel x-reuse tile of 512 voxels: with 32 output channels a 256-voxel tile gives a wave
 // only 48 MFMAs between barriers and a workgroup 18 chunks over which to spread its voxel decode, first loads and epilogue).
-template <int CO_TILES, int WM, int WN, bool UPS, bool XR = false, int J = 2>
+// ST: the epilogue also reduces the tile's outputs to per-channel (sum, sum of squares) partials - the GroupNorm statistics of the NEXT layer
+// (updown.py:119-132: Conv, ReLU, GroupNorm) without a pass of their own over the output (WM = 1 instances: a wave holds all N_T channels).
+template <int CO_TILES, int WM, int WN, bool UPS, bool XR = false, int J = 2, bool ST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES == 1 && !XR ? 3 : 2))) void conv3d_igemm_kernel(ConvArgs a) {
   constexpr int N_T = 32 * CO_TILES * WM;
   constexpr int M_T = 32 * J * WN;
@@ -307,6 +312,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
   }
 
   // epilogue: lane (voxel, hi) holds couts 8g+4hi+j of each co tile -> 4 float4 stores per tile
+  f32x16 ssum[ST ? CO_TILES : 1], ssq[ST ? CO_TILES : 1];
+  if (ST) {
+#pragma unroll
+    for (int i = 0; i < CO_TILES; ++i)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { ssum[i][t] = 0.f; ssq[i][t] = 0.f; }
+  }
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const long long m_in = m0 + wn * 32 * J + j * 32 + pl;
@@ -333,7 +345,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CO_TILES ==
         }
         if (a.resid) v = v + *reinterpret_cast<const f32x4*>(a.resid + m * a.Cout + cob + 8 * g);
         *reinterpret_cast<f32x4*>(a.y + m * a.Cout + cob + 8 * g) = v;
+        if (ST) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ssum[i][4 * g + e] += v[e]; ssq[i][4 * g + e] = fmaf(v[e], v[e], ssq[i][4 * g + e]); }
+        }
       }
+    }
+  }
+  if (ST) {
+    // per channel: this lane's voxels (above) -> the 32 voxel lanes of its half-wave (DPP row sums + one cross-row exchange) -> the WN waves
+    // (LDS) -> one f64 pair per (tile, channel).  f32 up to here (<= 512 values per channel), f64 across tiles (gn_coeffs_kernel).
+    static_assert(!ST || WM == 1, "the statistics epilogue is written for instances whose waves hold all output channels");
+    __syncthreads();                       // every wave is done with the operand buffers: LDS is free
+    float* red = lds;                      // [WN][CO_TILES][2 (hi)][16][2]
+#pragma unroll
+    for (int i = 0; i < CO_TILES; ++i)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        float sv = row16_sum(ssum[i][t]), qv = row16_sum(ssq[i][t]);
+        sv += __shfl_xor(sv, 16, 64); qv += __shfl_xor(qv, 16, 64);
+        if (pl == 0) {
+          float* r = red + ((((wn * CO_TILES + i) * 2 + hi) * 16 + t) * 2);
+          r[0] = sv; r[1] = qv;
+        }
+      }
+    __syncthreads();
+    if (tid < N_T) {
+      const int i = tid >> 5, c = tid & 31;              // channel c of co tile i: register t = 4 (c >> 3) + (c & 3) of the lanes with hi = (c >> 2) & 1
+      const int t = 4 * (c >> 3) + (c & 3), h = (c >> 2) & 1;
+      double sv = 0.0, qv = 0.0;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) {
+        const float* r = red + ((((w * CO_TILES + i) * 2 + h) * 16 + t) * 2);
+        sv += (double)r[0]; qv += (double)r[1];
+      }
+      const long long vs = (long long)a.Do * a.Ho * a.Wo, mt = lid / nbn, tps = vs / M_T;
+      const long long b = mt / tps, sp = mt % tps + a.stats_sp0;
+      double* o = a.stats + ((b * a.stats_S + sp) * a.Cout + n0 + tid) * 2;
+      o[0] = sv; o[1] = qv;
     }
   }
 }
@@ -457,6 +506,20 @@ __global__ void upcat_cl_kernel(const float* __restrict__ skip, const float* __r
   reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
+// tiles of M_T output voxels per shape the statistics-capable instances cut a launch into (0: this geometry has no such instance and
+// the caller takes the separate statistics pass): the x-reuse forms of the Upsampler's 64- and 32-channel layers
+static int conv_stats_tile(const ConvArgs& a) {
+  const long long vs = (long long)a.Do * a.Ho * a.Wo, M = vs * a.B;
+  const bool xr = g_sfmi_tune.conv_xreuse && a.stride == 1 && !a.up && (a.KS == 2 || a.KS == 3) && a.Wo == a.Wi && a.Ho == a.Hi && a.Do == a.Di &&
+                  (a.sp_on || 2 * a.pad == a.KS - 1) && 256 % a.Wo == 0;
+  if (!xr || a.resid || a.out_group) return 0;
+  const int arows256 = (256 / a.Wo) * (a.Wo + a.KS - 1);
+  if (a.Cout == 64 && vs % 256 == 0 && (size_t)(2 * arows256 + 2 * 3 * 64) * LDS_STRIDE * 4 <= 96 * 1024) return 256;
+  if (a.Cout == 32 && g_sfmi_tune.conv_xreuse >= 2 && 512 % a.Wo == 0 && vs % 512 == 0 && (M / 512) >= 1024 &&
+      (size_t)(2 * (((512 / a.Wo) * (a.Wo + a.KS - 1) + 15) & ~15) + 2 * 3 * 32) * 16 * 4 <= 80 * 1024) return 512;
+  return 0;
+}
+
 static int conv_dispatch(const ConvArgs& a, void* stream) {
   const int Cout = a.Cout;
   const long long M = (long long)a.B * a.Do * a.Ho * a.Wo;
@@ -473,6 +536,20 @@ static int conv_dispatch(const ConvArgs& a, void* stream) {
     if (x && (N_T == 128 || M_T == 512)) return (size_t)(2 * ((arows + 15) & ~15) + 2 * 3 * N_T) * 16 * 4;   // the swizzled-row instances
     return (size_t)(2 * arows + 2 * (x ? 3 : 1) * N_T) * LDS_STRIDE * 4;
   };
+  if (a.stats) {      // only through the *_stats entry points, which checked conv_stats_tile first
+    const int mt = conv_stats_tile(a);
+    if (mt == 256) {
+      static const hipError_t at = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<2, 1, 4, false, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (at != hipSuccess) return SFMI_ELDS;
+      hipLaunchKernelGGL((conv3d_igemm_kernel<2, 1, 4, false, true, 2, true>), dim3((unsigned)(M / 256)), dim3(256), lds_bytes(256, 64, true), st, a);
+    } else if (mt == 512) {
+      static const hipError_t at = hipFuncSetAttribute((const void*)conv3d_igemm_kernel<1, 1, 4, false, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      if (at != hipSuccess) return SFMI_ELDS;
+      hipLaunchKernelGGL((conv3d_igemm_kernel<1, 1, 4, false, true, 4, true>), dim3((unsigned)(M / 512)), dim3(256), lds_bytes(512, 32, true), st, a);
+    } else return SFMI_EINVAL;
+    SFMI_CHECK_LAUNCH();
+    return SFMI_OK;
+  }
   if (Cout % 128 == 0) {
     constexpr int M_T = 128, N_T = 128;
     const long long tiles = ((M + M_T - 1) / M_T) * (Cout / N_T);
@@ -547,19 +624,35 @@ int sfmi_conv_pack_weight(const float* w, int Cout, int Cin, int KS, float* out)
 
 // replaces nn.Conv3d (+ fused input GroupNorm-apply, nearest-x2 upsample, bias, ReLU); see file header.
 // x (B,Di,Hi,Wi,Cin) -> y (B,Do,Ho,Wo,Cout), Do = ((Di<<up) + 2*pad - KS)/stride + 1.
+int sfmi_conv3d_cl_stats_f32(const float* x, const float* wT, const float* in_scale, const float* in_shift, const float* bias, float* y, int B,
+                             int Di, int Hi, int Wi, int Cin, int Cout, int KS, int stride, int pad, int up, int relu, double* partial, int* splits,
+                             void* stream);
 int sfmi_conv3d_cl_f32(const float* x, const float* wT, const float* in_scale, const float* in_shift,
                        const float* bias, float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int KS,
                        int stride, int pad, int up, int relu, void* stream) {
+  return sfmi_conv3d_cl_stats_f32(x, wT, in_scale, in_shift, bias, y, B, Di, Hi, Wi, Cin, Cout, KS, stride, pad, up, relu, nullptr, nullptr, stream);
+}
+// the same; partial != NULL: also the GroupNorm statistics of y as per-(shape, split, channel) f64 partials (see sfmi_conv3d_up2_cl_stats_f32)
+int sfmi_conv3d_cl_stats_f32(const float* x, const float* wT, const float* in_scale, const float* in_shift, const float* bias, float* y, int B,
+                             int Di, int Hi, int Wi, int Cin, int Cout, int KS, int stride, int pad, int up, int relu, double* partial, int* splits,
+                             void* stream) {
+  if ((partial == nullptr) != (splits == nullptr)) return SFMI_EINVAL;
   if (!x || !wT || !y || B <= 0 || Cin % KC || Cout % 32 || (KS != 1 && KS != 2 && KS != 3)) return SFMI_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return SFMI_EINVAL;
   ConvArgs a;
   a.x = x; a.wT = wT; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.y = y;
   a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KS = KS; a.stride = stride; a.pad = pad;
   a.up = up; a.relu = relu; a.resid = nullptr; a.out_group = 0; a.out_group_stride = 0;
-  a.sp_on = 0; a.spz = a.spy = a.spx = 0; a.padz = a.pady = a.padx = 0;
+  a.sp_on = 0; a.spz = a.spy = a.spx = 0; a.padz = a.pady = a.padx = 0; a.stats = nullptr; a.stats_S = 0; a.stats_sp0 = 0;
   a.Do = ((Di << up) + 2 * pad - KS) / stride + 1;
   a.Ho = ((Hi << up) + 2 * pad - KS) / stride + 1;
   a.Wo = ((Wi << up) + 2 * pad - KS) / stride + 1;
+  if (partial) {
+    const int mt = conv_stats_tile(a);
+    if (!mt) return SFMI_EINVAL;          // nothing launched: the caller takes the separate statistics pass
+    a.stats = partial; a.stats_S = (int)((long long)a.Do * a.Ho * a.Wo / mt); a.stats_sp0 = 0;
+    *splits = a.stats_S;
+  }
   return conv_dispatch(a, stream);
 }
 
@@ -574,7 +667,7 @@ int sfmi_gemm_f32(const float* x, const float* W, const float* bias, const float
   a.out_group = out_group; a.out_group_stride = out_group_stride;
   a.B = 1; a.Di = 1; a.Hi = 1; a.Wi = (int)M; a.Do = 1; a.Ho = 1; a.Wo = (int)M; a.Cin = K; a.Cout = N; a.KS = 1;
   a.stride = 1; a.pad = 0; a.up = 0; a.relu = act;
-  a.sp_on = 0; a.spz = a.spy = a.spx = 0; a.padz = a.pady = a.padx = 0;
+  a.sp_on = 0; a.spz = a.spy = a.spx = 0; a.padz = a.pady = a.padx = 0; a.stats = nullptr; a.stats_S = 0; a.stats_sp0 = 0;
   return conv_dispatch(a, stream);
 }
 
@@ -608,18 +701,37 @@ int sfmi_conv_pack_weight_subpixel(const float* w, int Cout, int Cin, float* out
 }
 
 // x (B,Di,Hi,Wi,Cin) low resolution -> y (B,2Di,2Hi,2Wi,Cout) = act(conv3(nearest_x2(affine(x))) + bias); 8 launches
+int sfmi_conv3d_up2_cl_stats_f32(const float* x, const float* wsub, const float* in_scale, const float* in_shift, const float* bias,
+                                 float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int relu, double* partial, int* splits, void* stream);
 int sfmi_conv3d_up2_cl_f32(const float* x, const float* wsub, const float* in_scale, const float* in_shift, const float* bias,
                            float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int relu, void* stream) {
-  if (!x || !wsub || !y || B <= 0 || Cin % KC || Cout % 32) return SFMI_EINVAL;
+  return sfmi_conv3d_up2_cl_stats_f32(x, wsub, in_scale, in_shift, bias, y, B, Di, Hi, Wi, Cin, Cout, relu, nullptr, nullptr, stream);
+}
+// the same; partial != NULL: the launches also leave the GroupNorm statistics of y - per (shape, split, channel) f64 {sum, sum of squares},
+// *splits of them per shape - for sfmi_groupnorm_coeffs_partial_f32, instead of a statistics pass over y.  SFMI_EINVAL BEFORE anything is
+// launched when this geometry has no statistics-capable instance (the caller then takes sfmi_conv3d_up2_cl_f32 + sfmi_groupnorm_coeffs_f32).
+int sfmi_conv3d_up2_cl_stats_f32(const float* x, const float* wsub, const float* in_scale, const float* in_shift, const float* bias,
+                                 float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int relu, double* partial, int* splits, void* stream) {
+  if (!x || !wsub || !y || B <= 0 || Cin % KC || Cout % 32 || ((partial == nullptr) != (splits == nullptr))) return SFMI_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return SFMI_EINVAL;
-  for (int par = 0; par < 8; ++par) {
+  int tps = 0;
+  for (int par = partial ? -1 : 0; par < 8; ++par) {      // par = -1: dry pass that only asks whether the statistics instance exists
     ConvArgs a;
-    a.x = x; a.wT = wsub + (size_t)par * 8 * Cout * Cin; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.y = y;
+    a.stats = partial; a.stats_S = 8 * tps; a.stats_sp0 = (par < 0 ? 0 : par) * tps;
+    a.x = x; a.wT = wsub + (size_t)(par < 0 ? 0 : par) * 8 * Cout * Cin; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.y = y;
     a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KS = 2; a.stride = 1; a.pad = 0; a.up = 0; a.relu = relu;
     a.resid = nullptr; a.out_group = 0; a.out_group_stride = 0;
     a.Do = Di; a.Ho = Hi; a.Wo = Wi;
-    a.sp_on = 1; a.spz = par >> 2; a.spy = (par >> 1) & 1; a.spx = par & 1;
+    const int pp = par < 0 ? 0 : par;
+    a.sp_on = 1; a.spz = pp >> 2; a.spy = (pp >> 1) & 1; a.spx = pp & 1;
     a.padz = 1 - a.spz; a.pady = 1 - a.spy; a.padx = 1 - a.spx;
+    if (par < 0) {
+      const int mt = conv_stats_tile(a);
+      if (!mt) return SFMI_EINVAL;
+      tps = (int)((long long)Di * Hi * Wi / mt);
+      *splits = 8 * tps;
+      continue;
+    }
     const int rc = conv_dispatch(a, stream);
     if (rc != SFMI_OK) return rc;
   }
@@ -637,6 +749,15 @@ int sfmi_groupnorm_coeffs_f32(const float* x, const float* gamma, const float* b
   const int S = sfmi_gn_splits(V);
   hipLaunchKernelGGL(chan_stats_kernel, dim3(S, B), dim3(256), 0, st, x, partial, V, C, S);
   hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(256), 0, st, partial, gamma, beta, scale, shift, V, C, S, groups, eps);
+  SFMI_CHECK_LAUNCH();
+  return SFMI_OK;
+}
+
+// GroupNorm coefficients from statistics partials a convolution left behind (sfmi_conv3d_*_stats_f32): partial (B, S, C, 2) f64, V voxels per shape
+int sfmi_groupnorm_coeffs_partial_f32(const double* partial, const float* gamma, const float* beta, float* scale, float* shift, int B, int V, int C,
+                                      int S, int groups, float eps, void* stream) {
+  if (!partial || !gamma || !beta || !scale || !shift || B <= 0 || V <= 0 || S <= 0 || C % 4 || C > 1024 || C % groups || groups > 64) return SFMI_EINVAL;
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, scale, shift, V, C, S, groups, eps);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

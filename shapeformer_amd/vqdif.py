@@ -111,28 +111,55 @@ class _GridOps:
     def _buf(self, name, shape, dtype=torch.float32):
         return self.ws.buf(name, shape, dtype)
 
-    def _conv(self, x, cv, name, scale=None, shift=None, up=0, relu=True, bias=None):
+    def _gn_partial_buf(self, B):
+        return self._buf("gn_partial", (B * 64 * 1024 * 2,), torch.float64)
+
+    def _conv(self, x, cv, name, scale=None, shift=None, up=0, relu=True, bias=None, stats=False):
+        """stats=True -> (y, S): the launch also leaves y's GroupNorm statistics as S per-shape partials in the `gn_partial` buffer
+        (csrc/conv3d.hip ST instances; consumed by `_gn(..., partial_S=S)`), or S = None where this geometry has no such instance."""
+        import ctypes as C
         B, Di, Hi, Wi, Cin = x.shape
         assert Cin == cv.cin, (Cin, cv.cin)
         Do = ((Di << up) + 2 * cv.pad - cv.ks) // cv.stride + 1
         y = self._buf(name, (B, Do, Do, Do, cv.cout))
+        S = C.c_int(0)
+        part = self._gn_partial_buf(B) if stats else None
         if up and cv.w_up is not None:      # upsample + conv3 as 8 parity-wise 2^3 convolutions of the low-resolution grid
-            L.check(L.lib().sfmi_conv3d_up2_cl_f32(L.ptr(x), L.ptr(cv.w_up), L.ptr(scale), L.ptr(shift), L.ptr(bias), L.ptr(y),
-                                                   B, Di, Hi, Wi, Cin, cv.cout, int(relu), L.stream_ptr()), "sfmi_conv3d_up2_cl_f32")
+            rc = L.lib().sfmi_conv3d_up2_cl_stats_f32(L.ptr(x), L.ptr(cv.w_up), L.ptr(scale), L.ptr(shift), L.ptr(bias), L.ptr(y),
+                                                      B, Di, Hi, Wi, Cin, cv.cout, int(relu), L.ptr(part), C.byref(S) if stats else None,
+                                                      L.stream_ptr()) if stats else L.SFMI_EINVAL
+            if rc == L.SFMI_EINVAL:         # no statistics instance for this geometry (or none asked for): the plain launches
+                S = None
+                rc = L.lib().sfmi_conv3d_up2_cl_f32(L.ptr(x), L.ptr(cv.w_up), L.ptr(scale), L.ptr(shift), L.ptr(bias), L.ptr(y),
+                                                    B, Di, Hi, Wi, Cin, cv.cout, int(relu), L.stream_ptr())
+            L.check(rc, "sfmi_conv3d_up2_cl_f32")
+        else:
+            rc = L.lib().sfmi_conv3d_cl_stats_f32(L.ptr(x), L.ptr(cv.w), L.ptr(scale), L.ptr(shift), L.ptr(bias), L.ptr(y),
+                                                  B, Di, Hi, Wi, Cin, cv.cout, cv.ks, cv.stride, cv.pad, up, int(relu), L.ptr(part),
+                                                  C.byref(S) if stats else None, L.stream_ptr()) if stats else L.SFMI_EINVAL
+            if rc == L.SFMI_EINVAL:
+                S = None
+                rc = L.lib().sfmi_conv3d_cl_f32(L.ptr(x), L.ptr(cv.w), L.ptr(scale), L.ptr(shift), L.ptr(bias), L.ptr(y),
+                                                B, Di, Hi, Wi, Cin, cv.cout, cv.ks, cv.stride, cv.pad, up, int(relu), L.stream_ptr())
+            L.check(rc, "sfmi_conv3d_cl_f32")
+        if not stats:
             return y
-        L.check(L.lib().sfmi_conv3d_cl_f32(L.ptr(x), L.ptr(cv.w), L.ptr(scale), L.ptr(shift), L.ptr(bias), L.ptr(y),
-                                           B, Di, Hi, Wi, Cin, cv.cout, cv.ks, cv.stride, cv.pad, up, int(relu),
-                                           L.stream_ptr()), "sfmi_conv3d_cl_f32")
-        return y
+        return y, (None if S is None else int(S.value))
 
-    def _gn(self, x, gamma, beta, name):
-        """scale/shift (B,C) such that GroupNorm8(x) == x*scale + shift."""
+    def _gn(self, x, gamma, beta, name, partial_S=None):
+        """scale/shift (B,C) such that GroupNorm8(x) == x*scale + shift.  partial_S: the convolution that wrote x left its statistics in
+        the `gn_partial` buffer (`_conv(..., stats=True)`): only the coefficient launch runs."""
         B, C = x.shape[0], x.shape[-1]
         V = x.numel() // (B * C)
-        S = L.lib().sfmi_gn_splits(V)
-        part = self._buf("gn_partial", (B * 64 * 1024 * 2,), torch.float64)
-        assert B * S * C * 2 <= part.numel()
+        part = self._gn_partial_buf(B)
         sc, sh = self._buf(name + ".scale", (B, C)), self._buf(name + ".shift", (B, C))
+        if partial_S is not None:
+            assert B * partial_S * C * 2 <= part.numel()
+            L.check(L.lib().sfmi_groupnorm_coeffs_partial_f32(L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(sc), L.ptr(sh), B, V, C, int(partial_S),
+                                                              self.GROUPS, self.EPS, L.stream_ptr()), "sfmi_groupnorm_coeffs_partial_f32")
+            return sc, sh
+        S = L.lib().sfmi_gn_splits(V)
+        assert B * S * C * 2 <= part.numel()
         L.check(L.lib().sfmi_groupnorm_coeffs_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(sc), L.ptr(sh), L.ptr(part),
                                                   B, V, C, self.GROUPS, self.EPS, L.stream_ptr()), "sfmi_groupnorm_coeffs_f32")
         return sc, sh
@@ -371,8 +398,9 @@ class LocalDecoder(_GridOps):
         x = self._conv(y, self.unet_final, "unet_out", relu=False, bias=self.unet_final.bias)
         sc = sh = None
         for i, cv in enumerate(self.up):  # nearest x2 folded into the first conv of each step
-            x = self._conv(x, cv, f"up{i}", sc, sh, up=1 if i % 2 == 0 else 0, relu=True)
-            sc, sh = self._gn(x, cv.gamma, cv.beta, f"up{i}")
+            # Conv, ReLU, GroupNorm (updown.py:119-132): the statistics of the GroupNorm are taken in the convolution's epilogue
+            x, S = self._conv(x, cv, f"up{i}", sc, sh, up=1 if i % 2 == 0 else 0, relu=True, stats=True)
+            sc, sh = self._gn(x, cv.gamma, cv.beta, f"up{i}", partial_S=S)
         if final_affine:
             return self._affine(x, sc, sh, "dec_grid")
         return x, sc, sh
@@ -464,8 +492,8 @@ class VQDIF:
     def _buf(self, name, shape, dtype=torch.float32):
         return self.ws.buf(name, shape, dtype)
 
-    def _gn(self, x, gamma, beta, name):
-        return self.decoder._gn(x, gamma, beta, name)
+    def _gn(self, x, gamma, beta, name, **kw):
+        return self.decoder._gn(x, gamma, beta, name, **kw)
 
     def _affine(self, x, sc, sh, name):
         return self.decoder._affine(x, sc, sh, name)

@@ -152,6 +152,36 @@ def test_conv_and_groupnorm_units(vq, dev):
     torch.testing.assert_close(y.cpu().permute(0, 4, 1, 2, 3), ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,D,up", [(2, 64, 64, 32, 0), (2, 128, 64, 16, 1), (16, 32, 32, 64, 0), (16, 64, 32, 32, 1), (1, 32, 32, 64, 0)])
+def test_groupnorm_statistics_from_the_convolution_epilogue(vq, dev, B, Cin, Cout, D, up):
+    """csrc/conv3d.hip ST instances (the Upsampler's Conv, ReLU, GroupNorm: updown.py:119-132): the convolution that also leaves the
+    GroupNorm statistics of its output must write the SAME output bit for bit as the plain launch, and the coefficients formed from its
+    partials must equal those of the separate statistics pass (f32 sums over <= 512 voxels, then f64: 1e-6 relative) - for the four
+    layer shapes of the res-16 Upsampler (plain and sub-pixel, 64- and 32-channel tiles).  The last case (ONE shape at 64^3 x 32: fewer
+    tiles than the 512-voxel instance asks for) has no statistics instance: `_conv` falls back and says so."""
+    from shapeformer_amd.vqdif import _Conv
+    g = torch.Generator().manual_seed(B + Cin + D)
+    sd = {"c.conv.weight": (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5).numpy(),
+          "c.groupnorm.weight": (torch.rand(Cout, generator=g) + 0.5).numpy(), "c.groupnorm.bias": torch.randn(Cout, generator=g).numpy()}
+    cv = _Conv(sd, "c.", dev, 3, 1, 1)
+    if up:
+        cv.pack_subpixel(dev)
+    x = torch.randn(B, D, D, D, Cin, generator=g).to(dev)
+    sc0, sh0 = (torch.rand(B, Cin, generator=g) + 0.5).to(dev), torch.randn(B, Cin, generator=g).to(dev)
+    plain = vq._conv(x, cv, "t_plain", sc0, sh0, up=up, relu=True).clone()
+    y, S = vq._conv(x, cv, "t_stats", sc0, sh0, up=up, relu=True, stats=True)
+    assert torch.equal(y, plain)
+    if B == 1:
+        assert S is None
+        return
+    Do = D << up
+    assert S == (Do ** 3) // (256 if Cout == 64 else 512)
+    a = [t.clone() for t in vq._gn(y, cv.gamma, cv.beta, "t_a", partial_S=S)]
+    b = [t.clone() for t in vq._gn(y, cv.gamma, cv.beta, "t_b")]
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()), float((u - v).abs().max())
+
+
 def test_per_point_encoder_stages_vs_reference_fixture(vq):
     """Stage-wise pin of the per-point encoder (enc.py:115-133) through the debug taps of sfmi_encode_points_tap_f32: the output
     of blocks[1] (after the first local max pool), of blocks[4] and c = fc_c(net), at the points the fixture sampled - until
