@@ -174,9 +174,8 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
     grid = torch.randn(B, 64, 64, 64, 32, device=dev)
     axis = torch.linspace(-1, 1, Q, device=dev)
     o = torch.empty(B, Q ** 3, 1, device=dev)
-    aff = (torch.rand(B, 32, device=dev) + 0.5, torch.randn(B, 32, device=dev))      # the product instance: last GroupNorm's affine applied in the kernel
-    ms = ev_time(lambda: ops.sdf_query_grid(axis, grid, vq.sdf_w, sigmoid=True, out=o, affine=aff), 5)
-    add("sdf_query_kernel<grid, affine> 128^3", ms, "mfma", B * Q ** 3 * 31488, 1e12, F32, "TFLOP/s",
+    ms = ev_time(lambda: ops.sdf_query_grid(axis, grid, vq.sdf_w, sigmoid=True, out=o), 5)
+    add("sdf_query_kernel<grid> 128^3", ms, "mfma", B * Q ** 3 * 31488, 1e12, F32, "TFLOP/s",
         f"{B}x128^3 pts; algorithmic HBM {(B * Q ** 3 * 4 + B * 33.55e6) / (ms * 1e-3) / 1e9:.0f} GB/s")
     del grid, o
     # ---- the remaining kernels of the path (north-star names: local-pool encoder, codebook argmin; plus convs, sampler, prefill attention)
@@ -202,12 +201,13 @@ def kernel_rooflines(vq, gpt, B, dev, lc_mean=150.0):
     ms = ev_time(lambda: vq.quantize_cl(lat), 10)
     add("vq_argmin_kernel", ms, "mfma", 2.0 * Be * 4096 * 4096 * 128, 1e12, F32, "TFLOP/s", f"{Be} x 4096 cells x 4096 codes x d128 (f32 MFMA + running argmin)")
     code = torch.randn(Be, 16, 16, 16, 128, device=dev)
-    ms = ev_time(lambda: vq.decoder_grid_cl(code, final_affine=False), 3)      # the product's lattice route: the last GroupNorm's affine is applied inside sdf_query_kernel
+    ms = ev_time(lambda: vq.decoder_grid_cl(code), 3)
     # UNet3D 31.2 GFLOP + Upsampler with the sub-pixel decomposition of its two up-sampled layers (65.2 -> 34.6 GFLOP) per shape
     conv_flop = Be * (31.2e9 + 34.6e9)
     add("conv3d_igemm_kernel (UNet3D + Upsampler, 16 layers + GroupNorm statistics)", ms, "mfma", conv_flop, 1e12, F32, "TFLOP/s",
-        f"{Be} shapes, res16 -> 64^3 x 32 grid; FLOPs as executed (sub-pixel up-sampling: 8/27 of the dense count); the apply pass of the last "
-        "GroupNorm (0.7 ms per 64 shapes until round 5) now rides in the SDF query's gather")
+        f"{Be} shapes, res16 -> 64^3 x 32 grid; FLOPs as executed (sub-pixel up-sampling: 8/27 of the dense count); round 6: the Upsampler's "
+        "GroupNorm statistics come from the convolution epilogues; the apply pass of the last GroupNorm (0.7 ms of this line) moves into the "
+        "SDF query for lattices below 128^3 (config2)")
     del lat, code
     # sampler (latency-bound): one tuple element for Bk rows
     lg = torch.randn(B, gpt.Vpad, device=dev) * 3
@@ -430,7 +430,7 @@ def vqdif_records(vq16, dev):
         grid = torch.randn(B, 64, 64, 64, 32, device=dev)
         axis = torch.linspace(-1, 1, Q, device=dev)
         o = torch.empty(B, Q ** 3, 1, device=dev)
-        aff = (torch.rand(B, 32, device=dev) + 0.5, torch.randn(B, 32, device=dev))
+        aff = (torch.rand(B, 32, device=dev) + 0.5, torch.randn(B, 32, device=dev)) if Q < vq.AFFINE_IN_QUERY_BELOW_Q else None   # the instance the product takes at this Q
         ms = ev_time(lambda: ops.sdf_query_grid(axis, grid, vq.sdf_w, sigmoid=False, out=o, affine=aff), 2, warm=1)
         pts = B * Q ** 3
         tf = pts * 31488 / (ms * 1e-3) / 1e12

@@ -430,6 +430,11 @@ class VQDIF:
     `encoder_opt` / `quantizer_opt` / `decoder_opt` classes)."""
 
     G = 64
+    # decode_index on a Q^3 lattice: below this Q the decoder grid's last GroupNorm is applied inside the SDF kernel (16 FMAs per point
+    # on the interpolated features) instead of as a pass over the 64^3 x 32 grid (67 MB per shape).  Measured round 6: the kernel form
+    # costs 2.2 % of the query (124.6 -> 121.9 TFLOP/s), the pass 0.011 ms per shape - equal at 128^3 points per shape, the kernel form
+    # 8 x cheaper at 64^3 (BASELINE config 2: 1251 -> 1266 shapes/s), 8 x dearer at 256^3
+    AFFINE_IN_QUERY_BELOW_Q = 128
     GROUPS = _GridOps.GROUPS
     EPS = _GridOps.EPS
 
@@ -558,13 +563,16 @@ class VQDIF:
         """vqdif.py:60-76. Xtg (B,N,3) arbitrary points, or grid_Q=Q for the makeGrid 'ij' Q^3 lattice (x_range = (x0, x1): only its planes
         x0 <= ix < x1 - one rank's slab of dist.sdf_query_sharded)."""
         from . import ops
-        if grid_Q is not None:
-            # lattice route: the Upsampler's last GroupNorm travels as its (B,32) affine and is applied inside the query kernel
+        if grid_Q is not None and grid_Q < self.AFFINE_IN_QUERY_BELOW_Q:
+            # small lattices: the Upsampler's last GroupNorm travels as its (B,32) affine and is applied inside the query kernel
             # (csrc/sdf_query.hip AFF) instead of in a 67 MB-per-shape pass over the 64^3 x 32 grid
             grid, sc, sh = self.decoder_grid_cl(self.get_code_cl(code_ind), final_affine=False)
             axis = torch.from_numpy(np.linspace(-1.0, 1.0, grid_Q).astype(np.float32)).to(self.dev)
             return dict(logits=ops.sdf_query_grid(axis, grid, self.sdf_w, sigmoid=sigmoid, x_range=x_range, affine=(sc, sh)))
         grid = self.decoder_grid_cl(self.get_code_cl(code_ind))
+        if grid_Q is not None:
+            axis = torch.from_numpy(np.linspace(-1.0, 1.0, grid_Q).astype(np.float32)).to(self.dev)
+            return dict(logits=ops.sdf_query_grid(axis, grid, self.sdf_w, sigmoid=sigmoid, x_range=x_range))
         return dict(logits=ops.sdf_query(Xtg.to(self.dev, torch.float32), grid, self.sdf_w, sigmoid=sigmoid))
 
     def decode(self, grid_feat, Xtg):
