@@ -30,14 +30,15 @@ def timed(fn, label, flops_of):
     return w
 
 
-def conv_flops(y, x, cv, name, scale=None, shift=None, up=0, relu=True, bias=None):
+def conv_flops(y, x, cv, name, scale=None, shift=None, up=0, relu=True, bias=None, stats=False):
+    y = y[0] if stats else y          # _conv(stats=True) -> (y, splits)
     taps = 8 if (up and cv.w_up is not None) else cv.ks ** 3
     return 2.0 * y.numel() // cv.cout * cv.cout * cv.cin * taps
 
 
 dec = vq.decoder            # the LocalDecoder sub-module owns the grid ops since round 5
 dec._conv = timed(dec._conv, lambda x, cv, name, *r, **k: f"conv {name:16s} {tuple(x.shape[1:4])}x{cv.cin}->{cv.cout} k{cv.ks}" + (" up2" if k.get("up") else ""), conv_flops)
-dec._gn = timed(dec._gn, lambda x, g, b, name: f"gn   {name}", lambda *r, **k: 0.0)
+dec._gn = timed(dec._gn, lambda x, g, b, name, partial_S=None: f"gn   {name}" + (" (coefficients from the conv's partials)" if partial_S else ""), lambda *r, **k: 0.0)
 dec._pool = timed(dec._pool, lambda x, name: f"pool {name}", lambda *r, **k: 0.0)
 dec._upcat = timed(dec._upcat, lambda s, l, name: f"cat  {name}", lambda *r, **k: 0.0)
 dec._affine = timed(dec._affine, lambda x, sc, sh, name: f"aff  {name}", lambda *r, **k: 0.0)
