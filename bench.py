@@ -237,7 +237,7 @@ def pmc_traffic(kernel, B):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r0N_pmc_traffic_B<rows>.json, newest round first: FETCH_SIZE
     doubled per the gfx950 correction + WRITE_SIZE); only valid for the configuration it was collected on."""
     f = None
-    for r in ("r05", "r04", "r03", "r02", "r01"):                        # newest collection for this launch shape (tools/pmc_run.sh)
+    for r in ("r06", "r05", "r04", "r03", "r02", "r01"):                 # newest collection for this launch shape (tools/pmc_traffic.py)
         c = os.path.join(ROOT, "profiles", f"{r}_pmc_traffic_B{B}.json")
         if os.path.exists(c):
             f = c
@@ -270,7 +270,7 @@ def kernel_trace_avg(kernel_prefix):
 
 
 def kernel_trace_file():
-    for r in ("r05", "r04"):
+    for r in ("r06", "r05", "r04"):
         f = os.path.join("profiles", f"{r}_bench_kernel_trace.txt")
         if os.path.exists(os.path.join(ROOT, f)):
             return f
@@ -279,11 +279,13 @@ def kernel_trace_file():
 
 def pmc_traffic_source(B):
     """Where `roofline.traffic` comes from: it is NOT measured in this run (PMC passes need rocprofv3 around the process)."""
-    for r in ("r05", "r04", "r03", "r02", "r01"):
+    for r in ("r06", "r05", "r04", "r03", "r02", "r01"):
         f = os.path.join("profiles", f"{r}_pmc_traffic_B{B}.json")
         if os.path.exists(os.path.join(ROOT, f)):
+            at = json.load(open(os.path.join(ROOT, f))).get("commit")
             return (f"{f}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled per the gfx950 correction) of "
-                    f"tools/pmc_decode.py at {B} rows per launch, one chain; not re-measured in this run")
+                    f"tools/pmc_decode.py at {B} rows per launch, one chain" + (f", taken at commit {at}" if at else ", commit not recorded")
+                    + "; not re-measured in this run")
     return None
 
 

@@ -9,6 +9,6 @@ rm -rf /tmp/prof_$name
 DB=$(find /tmp/prof_$name -name "*.db" | head -1)
 OUTD=${PROF_OUT:-$R/gpurun_out/r5}
 mkdir -p $OUTD
-{ echo "# rocprofv3 --kernel-trace --stats -- $*"; grep -a '^{"metric"' /tmp/prof_$name.log | python3 -c "import sys,json; [print(json.dumps({k:v for k,v in json.loads(l).items() if k in (\"metric\",\"value\",\"ms_per_step\",\"steps\",\"roofline\",\"ar_loop\",\"stages_ms\")})) for l in sys.stdin]"; python $R/tools/prof_summary.py $DB 40; } > $OUTD/prof_$name.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- $*"; [ -n "$SFMI_COMMIT" ] && echo "# taken at commit $SFMI_COMMIT"; grep -a '^{"metric"' /tmp/prof_$name.log | python3 -c "import sys,json; [print(json.dumps({k:v for k,v in json.loads(l).items() if k in (\"metric\",\"value\",\"ms_per_step\",\"steps\",\"roofline\",\"ar_loop\",\"stages_ms\")})) for l in sys.stdin]"; python $R/tools/prof_summary.py $DB 40; } > $OUTD/prof_$name.txt
 if [ -z "$DB" ]; then echo "no rocpd database produced; log tail:"; tail -n 20 /tmp/prof_$name.log; fi
 tail -n 45 $OUTD/prof_$name.txt
