@@ -509,7 +509,7 @@ def train_record(gpt, a, batches=(1, 8), steps=5, warm=2):
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
                    str(port), os.path.abspath(__file__), "--gpus", "1", "--force-dist", "--mode", "train", "--grad-sync", mode, "--steps", "5", "--warmup", "2",
                    "--train-lc", str(a.train_lc), "--train-lz", str(a.train_lz)]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
             ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
             if r.returncode != 0 or not ln:
                 one[mode] = {"error": (r.stderr or r.stdout)[-300:]}
