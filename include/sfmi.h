@@ -293,7 +293,8 @@ int sfmi_unflatten_multi_f32(float* const* p, const long long* foff, const int* 
 /* ---- the training step captured in a hipGraph (no reference counterpart: Lightning enqueues every step from the host).  A captured launch
  *      keeps its arguments, so what changes from step to step is read from DEVICE memory at run time: the dropout seed of a site
  *      (mingpt.py:62-63,85,90,105,292) through `drop_seed_dev` (NULL: the by-value seed, as in the plain entry points), AdamW's bias
- *      corrections through `bc_dev` = {1 - beta1^t, 1 - beta2^t} (sfmi_adamw_bias_corrections forms them exactly as the by-value path).
+ *      corrections and learning rate through `bc_dev` = {1 - beta1^t, 1 - beta2^t, lr} (sfmi_adamw_bias_corrections forms the first two exactly
+ *      as the by-value path).
  *      Same kernels, same arithmetic: a replayed step is bit-identical to the eager one. */
 int sfmi_sgemm_sk_sd_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, float* C2,
                          int ldc, int accumulate, const float* bias, int act, const float* aux, const float* resid, float drop_p,

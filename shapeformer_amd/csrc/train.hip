@@ -910,7 +910,7 @@ struct AdamMultiArgs {
   const int* ctensor; const long long* coff; const int* clen;
   const float* g; float* m; float* v;
   float lr, b1, b2, eps, bc1, bc2;
-  const float* bc_dev;   // optional {1 - beta1^t, 1 - beta2^t} in device memory (the captured training step: t advances between replays)
+  const float* bc_dev;   // optional {1 - beta1^t, 1 - beta2^t, lr} in device memory (the captured training step: t - and a scheduled lr - change between replays)
   float* pflat;   // optional: the updated parameter is ALSO written to pflat[flat index] (may alias g: the all-gather send buffer of the sharded update)
 };
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
@@ -918,8 +918,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
   const long long o = a.coff[c], fo = a.foff[t] + o;
   const int n = a.clen[c];
   float* p = a.p[t] + o;
-  const float bc1 = a.bc_dev ? a.bc_dev[0] : a.bc1, bc2 = a.bc_dev ? a.bc_dev[1] : a.bc2;
-  const float decay = 1.0f - a.lr * a.wd[t], sb2 = sqrtf(bc2), step = a.lr / bc1;
+  const float bc1 = a.bc_dev ? a.bc_dev[0] : a.bc1, bc2 = a.bc_dev ? a.bc_dev[1] : a.bc2, lr = a.bc_dev ? a.bc_dev[2] : a.lr;
+  const float decay = 1.0f - lr * a.wd[t], sb2 = sqrtf(bc2), step = lr / bc1;
   // 9.1 GB of pure streaming per step at d = 1024 (read p, g, m, v; write p, m, v): 16-byte nontemporal accesses (the bare-stream
   // probe of round 5 reads 7.1 TB/s nontemporal against 6.4 TB/s with the default policy); the per-element arithmetic is unchanged
   if (((fo | o | (long long)n) & 3) == 0) {
@@ -1190,8 +1190,9 @@ int sfmi_adamw_bias_corrections(float beta1, float beta2, int step, float* out2)
   out2[0] = 1.0f - powf(beta1, (float)step); out2[1] = 1.0f - powf(beta2, (float)step);
   return SFMI_OK;
 }
-// bc_dev != NULL: the bias corrections are read from device memory at run time (2 floats, sfmi_adamw_bias_corrections of the step count)
-// instead of being formed from `step` at launch time - the captured training step replays one launch for every step count
+// bc_dev != NULL: {bias correction 1, bias correction 2, learning rate} are read from device memory at run time (3 floats; the corrections as
+// sfmi_adamw_bias_corrections forms them from the step count) instead of `step` / `lr` at launch time - the captured training step replays
+// one launch for every step count and every scheduled learning rate
 int sfmi_adamw_multi_shard_bc_f32(float* const* p, const long long* foff, const float* wd, const int* ctensor, const long long* coff,
                                   const int* clen, int nchunks, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                                   float eps, int step, const float* bc_dev, float* pflat, void* stream) {

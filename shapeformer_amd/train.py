@@ -86,10 +86,11 @@ class GPTTrainer:
                               fused_optimizer=bool(fused_optimizer), graph=bool(graph))
         self.use_graph = bool(graph)
         self._graphs, self._capture, self._graph_seen = {}, None, set()
-        # per-step words read by the captured launches: [0:2] AdamW bias corrections (f32 bits), [2:] dropout seeds of the sites in capture order
-        self._words = torch.zeros(2 + 256, device=gpt.dev, dtype=torch.int32)
+        # per-step words read by the captured launches: [0:3] AdamW bias corrections and learning rate (f32 bits), [4:] dropout seeds of the sites in
+        # capture order
+        self._words = torch.zeros(4 + 256, device=gpt.dev, dtype=torch.int32)
         # a ring of pinned host mirrors: the host may run several replays ahead of the device, a mirror is rewritten only after its copy ran
-        self._words_ring = [dict(buf=torch.zeros(2 + 256, dtype=torch.int32).pin_memory(), ev=None) for _ in range(4)] if graph else []
+        self._words_ring = [dict(buf=torch.zeros(4 + 256, dtype=torch.int32).pin_memory(), ev=None) for _ in range(4)] if graph else []
         self._words_next = 0
         self.gemm_algo, self.overlap_param_gather, self.fused_optimizer = gemm, bool(overlap_param_gather), bool(fused_optimizer)
         self._fused = False
@@ -447,8 +448,8 @@ class GPTTrainer:
                 return (0.0, 0, None)
             if self._capture is not None:      # captured step: the launch reads this site's seed from the step words at run time
                 idx = self._capture["sites"].setdefault(name, len(self._capture["sites"]))
-                assert idx < self._words.numel() - 2, "too many dropout sites for the step-word table"
-                return (p, 0, self._words.data_ptr() + 4 * (2 + idx))
+                assert idx < self._words.numel() - 4, "too many dropout sites for the step-word table"
+                return (p, 0, self._words.data_ptr() + 4 * (4 + idx))
             return (p, _fnv1a32(f"dropout-{dropout_key}-{name}"), None)
 
         def drop_(x, ps, out=None):  # elementwise nn.Dropout (forward == backward): out = x * mask / (1 - p)
@@ -728,7 +729,7 @@ class GPTTrainer:
         dev = self.dev
         c = torch.as_tensor(c_indices)
         z = torch.as_tensor(z_indices)
-        gkey = (tuple(c.shape), tuple(z.shape), key is not None, self.lr, int(L.lib().sfmi_tune_generation()))
+        gkey = (tuple(c.shape), tuple(z.shape), key is not None, int(L.lib().sfmi_tune_generation()))      # (the learning rate is a step word, not a captured argument)
         G = self._graphs.get(gkey)
         if G is None and gkey not in self._graph_seen:
             # first step of this shape: eager.  It builds what the step creates lazily OUTSIDE a capture pool (per-bucket AdamW tables,
@@ -763,19 +764,22 @@ class GPTTrainer:
             finally:
                 self._capture, self._fused, self._defer_side = None, False, None
             self._graphs[gkey] = G
+            while len(self._graphs) > 4:      # every captured shape keeps its activation pool (~6 GB at batch 8): the oldest goes first
+                self._graphs.pop(next(iter(self._graphs)))
         # this step's words: AdamW bias corrections and the seed of every dropout site, one host -> device copy ahead of the replay
         import ctypes as C
-        bc = (C.c_float * 2)()
+        bc = (C.c_float * 3)()
         L.check(L.lib().sfmi_adamw_bias_corrections(self.betas[0], self.betas[1], self.step_count, bc), "bias corrections")
+        bc[2] = self.lr
         slot = self._words_ring[self._words_next]
         self._words_next = (self._words_next + 1) % len(self._words_ring)
         if slot["ev"] is not None:
             slot["ev"].synchronize()
         w = slot["buf"]
-        w[:2] = torch.frombuffer(bytearray(bytes(bc)), dtype=torch.int32)
+        w[:3] = torch.frombuffer(bytearray(bytes(bc)), dtype=torch.int32)
         for name, idx in G["sites"].items():
             v = _fnv1a32(f"dropout-{key}-{name}")
-            w[2 + idx] = v - (1 << 32) if v >= (1 << 31) else v
+            w[4 + idx] = v - (1 << 32) if v >= (1 << 31) else v
         self._words.copy_(w, non_blocking=True)
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()

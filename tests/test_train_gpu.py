@@ -264,8 +264,8 @@ def test_training_step_gemm_forms_agree(dev):
 def test_captured_training_step_is_bit_identical_to_the_eager_step(dev, pdrop):
     """GPTTrainer(graph=True): forward + backward + per-bucket AdamW of a step replayed as ONE hipGraph (three streams; token tensors,
     dropout seeds and AdamW's bias corrections read from device memory).  Five steps on two alternating batches - the first of each shape
-    eager, the second captured, then replays - must give the losses AND the weights / moments of the eager trainer bit for bit, with
-    dropout off and on (the per-step masks come from the step words)."""
+    eager, the second captured, then replays, the learning rate changed on the way - must give the losses AND the weights / moments of the
+    eager trainer bit for bit, with dropout off and on (the per-step masks, bias corrections and learning rate come from the step words)."""
     from shapeformer_amd import weights as W
     from shapeformer_amd.gpt import CondTupleGPT
     from shapeformer_amd.train import GPTTrainer
@@ -277,7 +277,11 @@ def test_captured_training_step_is_bit_identical_to_the_eager_step(dev, pdrop):
         kw = dict(n_embd=128, n_layers=(2, 1), block_size=96)
         g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=96, device=dev)
         tr = GPTTrainer(g, lr=1e-3, pdrop=pdrop, graph=graph)
-        losses = [float(tr.training_step(cc, zz).item()) for cc, zz in batches]
+        losses = []
+        for i, (cc, zz) in enumerate(batches):
+            if i == 5:
+                tr.lr = 0.5e-3       # a scheduled learning rate: a step word of the captured step, not a reason to capture again
+            losses.append(float(tr.training_step(cc, zz).item()))
         if graph:
             assert len(tr._graphs) == 2 and tr.step_count == len(batches)
             assert (len(next(iter(tr._graphs.values()))["sites"]) > 0) == any(pdrop)
