@@ -53,7 +53,10 @@ def sigmoid(x, out=None):
     """nputil.sigmoid of a device logits tensor (in-tree kernel: the SDF query's own epilogue expression)."""
     _chk_cuda(x)
     x = _c(x, torch.float32)
+    if x.data_ptr() % 16:          # a contiguous view that starts inside a 16-byte line: the kernel reads float4
+        x = x.clone()
     out = torch.empty_like(x) if out is None else out
+    assert out.data_ptr() % 16 == 0 and out.is_contiguous()
     L.check(L.lib().sfmi_sigmoid_f32(L.ptr(x), L.ptr(out), x.numel(), L.stream_ptr()), "sfmi_sigmoid_f32")
     return out
 
