@@ -203,14 +203,6 @@ int sfmi_gpt_attn_decode_f32(const float* qkv_packed, const float* unused, float
 int sfmi_gpt_attn_decode_gated_f32(const float* qkv_packed, float* Kc, float* Vc, const int* len, float* y_packed, int B, int D, int H,
                                    int Lmax, const int* shared_len, int* sem, int* blk, int lanes, unsigned long long* prof,
                                    void* stream);
-/* the same launch in its SELF-PARTITIONING form (no reference counterpart; scheduling only, results identical): workgroups that find
- * themselves on a compute unit with CU id >= cut (in its shader engine), or on one that already holds `cap` workgroups of this launch,
- * leave at once; the others pull (row, head) items from a device queue until it is empty.  part = sfmi_gpt_attn_part_ints() zeroed
- * ints per chain (re-armed by the kernel); blk required; grid = workgroups launched (0: sixteen per compute unit). */
-size_t sfmi_gpt_attn_part_ints(void);
-int sfmi_gpt_attn_decode_part_f32(const float* qkv_packed, float* Kc, float* Vc, const int* len, float* y_packed, int B, int D, int H,
-                                  int Lmax, int* sem, int* blk, int lanes, unsigned long long* prof, int* part, int cut, int cap,
-                                  int grid, void* stream);
 /* one tuple element of one sampling step per row: sampling_masker (representers.py:120-155) + filter_sampling_logits /
  * sample_logits (models/common.py:260-299: temperature, top-k with ties, top-p) + inverse-CDF draw from counter-hash uniforms
  * indexed (step, tuple, row_offset + b) + best_in_first greedy row + log-prob + optional masked-logit history; writes the

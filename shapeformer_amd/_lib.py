@@ -110,8 +110,6 @@ PROTOTYPES = {
     "sfmi_ce_rows_f32": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr]),
     "sfmi_gpt_attn_decode_f32": (i32, [c_ptr] * 6 + [i32] * 5 + [c_ptr, c_ptr]),
     "sfmi_gpt_attn_decode_gated_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [c_ptr, c_ptr, c_ptr, i32, c_ptr, c_ptr]),
-    "sfmi_gpt_attn_part_ints": (sz, []),
-    "sfmi_gpt_attn_decode_part_f32": (i32, [c_ptr] * 5 + [i32] * 4 + [c_ptr, c_ptr, i32, c_ptr, c_ptr, i32, i32, i32, c_ptr]),
     "sfmi_gpt_attn_prefill_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, f32, C.c_uint, c_ptr]),
     "sfmi_gpt_attn_prefill_lse_f32": (i32, [c_ptr] * 5 + [i32] * 5 + [c_ptr, f32, C.c_uint, c_ptr, c_ptr]),
     "sfmi_gpt_sample_f32": (i32, [c_ptr] * 12 + [i32] * 10 + [C.c_float, C.c_float] + [i32] * 4 + [C.c_uint, c_ptr, i32, i32, i32, i32, c_ptr]),

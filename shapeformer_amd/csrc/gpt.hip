@@ -424,12 +424,7 @@ struct AttnArgs {
   int* sem;      // optional turnstile words {next ticket, finished launches, gate time-outs}: the LAST workgroup of a launch bumps sem[1]
   int* blk;      // this chain's finished-workgroup counter (re-armed by the last workgroup)
   unsigned long long* prof;   // optional in-situ launch timing sink of this chain (prof_begin / prof_end_last; needs blk)
-  // self-partitioning form (attn_decode_kernel<.., PART = true>): this chain's scratch {[0] item-queue head, [16 ..) per-CU claim counts},
-  // all zero between launches; compute units with a CU id below part_cut (in their shader engine) are the attention's, at most
-  // part_cap workgroups of ONE launch stay on each
-  int* part; int part_cut, part_cap;
 };
-#define SFMI_ATTN_PART_INTS (16 + 8 * 8 * 16)      // head word (padded) + claim table indexed by (XCC 0..7, SE 0..7, CU 0..15)
 template <int NWV>
 struct AttnLds {
   __attribute__((aligned(16))) float qs[64];
@@ -584,59 +579,6 @@ __global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : U <= 8 ? 4 : 2) void attn_de
   }
   if ((a.sem || a.prof) && threadIdx.x == 0) {     // turnstile release: the launch's last workgroup to finish admits the next KV stream
     if (__hip_atomic_fetch_add(a.blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-      __hip_atomic_store(a.blk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.sem) __hip_atomic_fetch_add(a.sem + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.prof) prof_end_last(a.prof);
-    }
-  }
-}
-
-// SELF-PARTITIONING form (round 6, profiles/r06_overlap.md).  The KV stream of the decode attention saturates HBM from ~160 of the 256
-// compute units, the decode GEMMs of the other chains are latency-bound and lose nothing on the remaining ones - but a captured hipGraph
-// cannot carry a CU-masked stream, and as one-item workgroups spread over every CU the two families only time-share the chip
-// (7.1 ms per 384-row step against 4.9 + 2.6 alone).  So the launch confines ITSELF: a workgroup reads its own place (XCC_ID / HW_ID
-// registers); on a compute unit outside the attention's set (CU id >= part_cut in its shader engine), or on one that already holds
-// part_cap workgroups of this launch, it leaves at once - its slot goes to a decode-GEMM workgroup of another chain.  The workgroups
-// that stay are persistent: they pull (row, head) items from a queue in device memory until it is empty, so every item is computed
-// exactly once whatever the placement; which workgroup computes an item changes nothing in its arithmetic (bit-identical to the plain
-// form).  The last workgroup of the grid never leaves while nobody has started on the queue (a launch always completes).
-template <int NWV, int U>
-__global__ __launch_bounds__(64 * NWV, U <= 4 ? 8 : U <= 8 ? 4 : 2) void attn_decode_part_kernel(AttnArgs a) {
-  __shared__ AttnLds<NWV> s;
-  __shared__ int s_it[2], s_last;
-  const int nitems = a.B * a.H, tid = threadIdx.x;
-  prof_begin(a.prof, blockIdx.x);
-  int* head = a.part;
-  if (tid == 0) {
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const int cu = (hw >> 8) & 15, se = (hw >> 13) & 7;
-    bool mine = false;
-    if (cu < a.part_cut)
-      mine = __hip_atomic_fetch_add(a.part + 16 + (((xcc & 7) * 8 + se) * 16 + cu), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.part_cap;
-    if (!mine && blockIdx.x == gridDim.x - 1) mine = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-    s_it[0] = mine ? __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : nitems;
-  }
-  __syncthreads();
-  int par = 0, it = s_it[0];
-  while (it < nitems) {
-    // the next item is requested now: the atomic's round trip runs under this item's KV stream
-    int nxt = 0;
-    if (tid == 0) nxt = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int h = __builtin_amdgcn_readfirstlane(it / a.B);
-    attn_decode_item<NWV, U, false>(s, a, __builtin_amdgcn_readfirstlane(it - h * a.B), h);
-    if (tid == 0) s_it[par ^ 1] = nxt;
-    __syncthreads();                                       // also: the next item rewrites the hand-off tiles
-    par ^= 1;
-    it = s_it[par];
-  }
-  // every workgroup, also one that left at once, is counted; the last one re-arms the queue and the claim table for the chain's next launch
-  if (tid == 0) s_last = __hip_atomic_fetch_add(a.blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (s_last) {
-    for (int i = tid; i < SFMI_ATTN_PART_INTS; i += 64 * NWV) __hip_atomic_store(a.part + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0) {
       __hip_atomic_store(a.blk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.sem) __hip_atomic_fetch_add(a.sem + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.prof) prof_end_last(a.prof);
@@ -1410,7 +1352,7 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
   AttnArgs a;
   a.qkv = qkv_part; a.Kc = Kc; a.Vc = Vc; a.len = len; a.y = y; a.shared_len = shared_len;
   a.B = B; a.H = H; a.D = D; a.Lmax = Lmax; a.HD = D / H; a.scale = 1.0f / sqrtf((float)a.HD);
-  a.sem = sem; a.blk = blk; a.prof = prof; a.part = nullptr; a.part_cut = 0; a.part_cap = 0;
+  a.sem = sem; a.blk = blk; a.prof = prof;
   const int nitems = B * H;
   const int grid = g_tune.attn_blocks > 0 ? min(g_tune.attn_blocks, nitems) : nitems;
   const size_t pad = (size_t)g_tune.attn_lds_pad;
@@ -1433,29 +1375,6 @@ int sfmi_gpt_attn_decode_gated_f32(const float* qkv_part, float* Kc, float* Vc, 
   else if (g_tune.attn_waves == 4) { if (g_tune.attn_unroll == 16) AT(4, 16); else AT(4, 8); }      // light-occupancy experiment (round 5)
   else { if (g_tune.attn_unroll == 8) AT(8, 8); else if (g_tune.attn_unroll == 2) AT(8, 2); else AT(8, 4); }
 #undef AT
-  SFMI_CHECK_LAUNCH();
-  return SFMI_OK;
-}
-// the same launch in its SELF-PARTITIONING form (attn_decode_part_kernel): `part` = SFMI_ATTN_PART_INTS ints of this chain, zero before the
-// first launch (the kernel re-arms them); compute units with CU id < cut (per shader engine) are the attention's, at most cap workgroups
-// of one launch per unit; grid = workgroups launched (0: sixteen per compute unit of the device).  blk is required.  Bit-identical results.
-size_t sfmi_gpt_attn_part_ints(void) { return SFMI_ATTN_PART_INTS; }
-int sfmi_gpt_attn_decode_part_f32(const float* qkv_part, float* Kc, float* Vc, const int* len, float* y, int B, int D, int H, int Lmax,
-                                  int* sem, int* blk, int lanes, unsigned long long* prof, int* part, int cut, int cap, int grid, void* stream) {
-  if (!qkv_part || !Kc || !Vc || !len || !y || D % H || (D / H) > 64 || (D / H) % 4 || Lmax > 1024) return SFMI_EINVAL;
-  if (!blk || !part || cut <= 0 || cut > 16 || cap <= 0 || grid < 0 || (sem && lanes <= 0)) return SFMI_EINVAL;
-  AttnArgs a;
-  a.qkv = qkv_part; a.Kc = Kc; a.Vc = Vc; a.len = len; a.y = y; a.shared_len = nullptr;
-  a.B = B; a.H = H; a.D = D; a.Lmax = Lmax; a.HD = D / H; a.scale = 1.0f / sqrtf((float)a.HD);
-  a.sem = sem; a.blk = blk; a.prof = prof; a.part = part; a.part_cut = cut; a.part_cap = cap;
-  if (grid == 0) {
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return SFMI_EINVAL; ncu = pr.multiProcessorCount; }
-    grid = 16 * ncu;      // a small grid is burnt through on the first CU of each shader engine (the dispatcher is first-fit and a leaving workgroup frees its slot at once): 4 per CU left one or two workgroups with all the items (280 ms per step), 16 per CU fills the chip
-  }
-  hipStream_t st = (hipStream_t)stream;
-  if (sem) hipLaunchKernelGGL(attn_gate_kernel, dim3(1), dim3(64), 0, st, sem, lanes);
-  hipLaunchKernelGGL((attn_decode_part_kernel<16, 4>), dim3(grid), dim3(1024), 0, st, a);
   SFMI_CHECK_LAUNCH();
   return SFMI_OK;
 }

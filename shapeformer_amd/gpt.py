@@ -210,7 +210,6 @@ class CondTupleGPT:
                   Kc=f(len(self.layers), B, self.Lmax + 1, D), Vc=f(len(self.layers), B, self.Lmax + 1, D),
                   logp=torch.zeros(B, max_steps, 2, device=dev, dtype=torch.float32),
                   blk=torch.zeros(1, device=dev, dtype=torch.int32),      # attention turnstile: this chain's finished-workgroup counter
-                  part=torch.zeros(int(L.lib().sfmi_gpt_attn_part_ints()), device=dev, dtype=torch.int32),   # self-partitioning attention: item queue + per-CU claims
                   pblk=torch.zeros(1, device=dev, dtype=torch.int32),     # in-situ launch timing: finished workgroups of the decode-GEMM launch
                   prof=self._prof_zero(dev),                              # in-situ launch timing sinks {t0, sum, launches, -} x {attn, gemm}
                   shared=torch.zeros(1, device=dev, dtype=torch.int32),  # shared-prefix length of the sample_n mode (device-resident)
@@ -441,10 +440,6 @@ class CondTupleGPT:
     # Two lanes measured best with four chains (6.48 against 6.68 ms per 320-row step ungated, 6.98 with one lane;
     # profiles/r03_ar_overlap.md).
     ATTN_LANES = 2
-    # Self-partitioning decode attention of the interleaved chains (csrc/gpt.hip:attn_decode_part_kernel): (cut, cap, grid) - compute units
-    # with CU id < cut in their shader engine (of 8-9) belong to the KV streams, at most cap workgroups of one launch per unit, grid
-    # workgroups launched (0 = sixteen per CU); cut 0 = off (one workgroup per item on every CU).  Scheduling only: bit-identical tokens.
-    ATTN_PART = (0, 1, 0)
     MAX_CHAIN_ROWS = 192   # rows per decode chain: row groups of up to 6 row tiles (96 rows) per decode-GEMM workgroup; larger batches = several chains
     # shared_prefix="auto" (the sample_n copies of one condition, shapeformer.py:222-260): one prefill and one copy of the condition's
     # keys / values for all rows, bit-identical to expanded rows, but its decode attention walks two caches per row.  Whole-call
@@ -463,7 +458,6 @@ class CondTupleGPT:
         if "@" in skip:      # per-chain form "gemm@0,attn@1,attn@2": chain index = micro-batch slot
             skip = ",".join(t.split("@")[0] for t in skip.split(",") if int(t.split("@")[1]) == sp.get("chain", 0))
         lanes = int(sp.get("gate_lanes", 0))
-        part = tuple(sp.get("attn_part") or (0, 0, 0))     # (cut, cap, grid) of the self-partitioning attention launch; cut 0 = the plain launch
         pa, pg = "attn" in self._profile, "gemm" in self._profile      # in-situ launch timing (results untouched)
         # in-kernel split-K per GEMM (only the K = 4 n_embd product, and proj at <= 16 rows, use it)
         Sqkv, Sproj, Sfc1, Sfc2, Shead = 1, self.S_PROJ if B <= 16 else self.S_PROJ_M, 1, self.S_FC2, 1
@@ -471,12 +465,7 @@ class CondTupleGPT:
             stage_end = li + 1 == len(self.layers) or self.layers[li + 1].stage != ly.stage
             if "gemm" not in skip:
                 self._dgemm(r, ly.pqkv, ly.c1qkv, ly.c2qkv, None, st["qkv"], B, 3 * D, D, 3 * D, 1, 0, S=Sqkv, st=st, prof=pg)
-            if "attn" not in skip and part[0] > 0 and not sp.get("shared_prefix"):
-                L.check(lib.sfmi_gpt_attn_decode_part_f32(L.ptr(st["qkv"]), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]), L.ptr(st["len"]), L.ptr(st["y"]),
-                                                          B, D, self.H, self.Lmax + 1, L.ptr(self._sem) if lanes else None, L.ptr(st["blk"]), lanes,
-                                                          L.ptr(st["prof"]) if pa else None, L.ptr(st["part"]), part[0], part[1], part[2],
-                                                          L.stream_ptr()), "sfmi_gpt_attn_decode_part_f32")
-            elif "attn" not in skip:
+            if "attn" not in skip:
                 L.check(lib.sfmi_gpt_attn_decode_gated_f32(L.ptr(st["qkv"]), L.ptr(st["Kc"][li]), L.ptr(st["Vc"][li]),
                                                            L.ptr(st["len"]), L.ptr(st["y"]), B, D, self.H, self.Lmax + 1,
                                                            L.ptr(st["shared"]) if sp.get("shared_prefix") else None,
@@ -534,9 +523,6 @@ class CondTupleGPT:
         hist = None
         if return_logits:
             hist = [torch.full((B, max_steps, self.V), float("nan"), device=self.dev) for _ in range(2)]
-        if slot >= 100 and self.ATTN_PART[0] > 0:      # a chain of an interleaved batch: its attention launches confine themselves to their CU set
-            sp_kw = dict(sp_kw, attn_part=tuple(int(v) for v in self.ATTN_PART))
-            st["part"].zero_(); st["blk"].zero_()
         sp = dict(sp_kw, max_steps=int(max_steps), hist=hist, row_offset=int(row_offset),
                   rows_total=int(rows_total if rows_total is not None else B), chain=int(slot - 100 if slot >= 100 else 0),
                   shared_prefix=bool(shared_prefix), step_offset=Lz, gate_lanes=int(gate_lanes))

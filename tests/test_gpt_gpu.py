@@ -322,41 +322,6 @@ def test_attention_turnstile_is_scheduling_only(dev):
     assert sem[0] == sem[1] == 3 * 3 * steps and sem[2] == 0, sem      # 3 chains x 3 layers x steps launches, no time-outs
 
 
-@pytest.mark.parametrize("part", [(6, 1, 0), (3, 2, 64), (16, 1, 7), (1, 1, 3)])
-def test_self_partitioning_attention_is_scheduling_only(dev, part):
-    """ATTN_PART (csrc/gpt.hip:attn_decode_part_kernel): the decode attention whose workgroups confine themselves to a set of compute units
-    and pull (row, head) items from a device queue - three interleaved chains, with and without the turnstile - gives exactly the tokens /
-    log-probabilities of the plain launch, whatever the CU cut, the per-CU cap and the grid (also a grid far smaller than the item
-    count, and a cut that leaves one CU id: the launch must still complete); the queue and claim words are re-armed (zero) afterwards."""
-    from shapeformer_amd import weights as W
-    from shapeformer_amd.gpt import CondTupleGPT
-    kw = dict(n_embd=128, n_layers=(2, 1), block_size=400)
-    g = CondTupleGPT(W.make_state_dict(W.gpt_spec(**kw)), n_embd=128, n_head=2, n_layers=(2, 1), block_size=400, device=dev)
-    rs = np.random.RandomState(6)
-    B, steps = 45, 14
-    Lc = rs.randint(8, 30, B).astype(np.int32)
-    tok = np.full((B, 64, 2), 4096, np.int32)
-    for b in range(B):
-        tok[b, :Lc[b] - 1, 0] = np.sort(rs.choice(4096, Lc[b] - 1, replace=False)); tok[b, :Lc[b] - 1, 1] = rs.randint(0, 4096, Lc[b] - 1)
-    ct, lt = torch.from_numpy(tok), torch.from_numpy(Lc)
-    g.ATTN_LANES = 0
-    ref = g.sample_microbatched(ct, lt, n_micro=3, max_steps=steps, stop_early=False, seed=3)
-    want = {k: v.clone() for k, v in ref["state"].items()}
-    try:
-        for lanes in (0, 2):
-            g.ATTN_LANES, g.ATTN_PART = lanes, part
-            got = g.sample_microbatched(ct, lt, n_micro=3, max_steps=steps, stop_early=False, seed=3)
-            for k in ("seq", "len", "logp"):
-                assert torch.equal(got["state"][k], want[k]), (k, lanes)
-            for st in g._states.values():
-                assert int(st["part"].abs().sum()) == 0 and int(st["blk"].item()) == 0
-            if lanes:
-                sem = g._sem.cpu().tolist()
-                assert sem[0] == sem[1] == 3 * 3 * steps and sem[2] == 0, sem
-    finally:
-        g.ATTN_LANES, g.ATTN_PART = 0, (0, 1, 0)
-
-
 def test_more_rows_than_the_chains_hold_run_as_rounds(dev):
     """400 rows on 2 chains (2 x 192 rows at most) = two successive rounds of 2 x 100-row chains (each two row groups of the decode
     GEMM); the same rows as 3 chains in one round must give the same tokens / log-probs (uniforms and the greedy row are indexed

@@ -8,8 +8,7 @@ with HIP events, optionally with one kernel family disabled (timing-only ablatio
 A configuration line is `name key=value ...`; keys: the sfmi_tune_set knobs (attn_blocks, attn_unroll, attn_waves,
 attn_lds_pad, ...), `ablate=gemm|attn`, `rows=`, `chains=`, `lanes=` (gpt.ATTN_LANES: attention turnstile, at most that many
 chains stream their KV cache at a time), `prefetch=` (gpt.PREFETCH_BLOCKS: Infinity-Cache weight prefetch branch of a single chain),
-`profile=attn,gemm` (in-situ launch timing: prints launches and mean us per family), `part=cut[:cap[:grid]]` (gpt.ATTN_PART: the
-self-partitioning decode attention - CU ids below `cut` per shader engine, `cap` workgroups of a launch per CU), `cus=<n>` (every chain on a stream restricted to
+`profile=attn,gemm` (in-situ launch timing: prints launches and mean us per family), `cus=<n>` (every chain on a stream restricted to
 the first n compute-unit mask bits = n / 8 CUs of every XCD; hipExtStreamCreateWithCUMask), `cusplit=<n>` (chains 0, 1 on the first n
 bits, chains 2, 3 on the other 256 - n: spatial partition of the two kernel families together with a per-chain ablate=),
 `cumode=block` (mask bits taken as contiguous blocks instead: bits [0, n) vs [n, 256)), `hwid=1` (print which XCC / SE / CU the masked
@@ -180,7 +179,8 @@ def main():
         gpt.ATTN_LANES = int(kv.pop("lanes", "0"))
         gpt.S_PROJ_M, gpt.S_FC2 = int(kv.pop("sproj", "1")), int(kv.pop("sfc2", "4"))      # in-kernel split-K of proj / fc2 (part of the graph key)
         gpt._profile = kv.pop("profile", "")
-        gpt.ATTN_PART = tuple(int(v) for v in (kv.pop("part", "0").split(":") + ["1", "0"])[:3])     # part=cut[:cap[:grid]]: self-partitioning attention
+        if kv.pop("part", "0") != "0":
+            raise ValueError("part=: the self-placing attention launch was removed from the library after round 6's measurements (profiles/r06_overlap.md; code from commit ac5c852 on)")
         bg = kv.pop("bgsdf", None)
         cus, cusplit, cumode, hwid = int(kv.pop("cus", "0")), int(kv.pop("cusplit", "0")), kv.pop("cumode", "interleave"), int(kv.pop("hwid", "0"))
         if cus or cusplit:
