@@ -202,6 +202,21 @@ try:
     ok = False                                                                              # refused on EVERY rank (nobody waits in a collective)
 except ValueError:
     pass
+# SURVEY 8(e), the other single-shape option (dist.sdf_query_sharded): lattice planes split over the ranks (uneven: 5 planes on 2 ranks), slabs
+# padded to the largest, all-gathered and cut - with a stand-in decoder whose "logit" of lattice point p is p itself
+class FakeVQ:
+    def decode_index(self, code_ind, grid_Q=None, sigmoid=False, x_range=None):
+        x0, x1 = x_range if x_range is not None else (0, grid_Q)
+        pts = torch.arange(x0 * grid_Q * grid_Q, x1 * grid_Q * grid_Q, dtype=torch.float32)
+        return dict(logits=(pts + (1000.0 if sigmoid else 0.0))[None, :, None].repeat(code_ind.shape[0], 1, 1))
+for sg in (False, True):
+    lg = D.sdf_query_sharded(FakeVQ(), torch.zeros(3, 2, 2, 2), 5, dist, sigmoid=sg)["logits"]
+    ok = ok and lg.shape == (3, 125, 1) and torch.equal(lg[1, :, 0], torch.arange(125, dtype=torch.float32) + (1000.0 if sg else 0.0))
+try:
+    D.sdf_query_sharded(FakeVQ(), torch.zeros(1, 2, 2, 2), 1, dist)      # fewer planes than ranks
+    ok = False
+except ValueError:
+    pass
 try:      # 2 x 768 + 1 rows: only rank 1's shard (769) is over the limit, but the test is on ceil(S / world): BOTH ranks refuse
     D.sample_n_sharded(FakeGPT(), c1, torch.tensor([5], dtype=torch.int32), 2 * 4 * 192 + 1, dist, stop_early=False)
     ok = False
