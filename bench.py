@@ -509,10 +509,20 @@ def train_record(gpt, a, batches=(1, 8), steps=5, warm=2):
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
                    str(port), os.path.abspath(__file__), "--gpus", "1", "--force-dist", "--mode", "train", "--grad-sync", mode, "--steps", "5", "--warmup", "2",
                    "--train-lc", str(a.train_lc), "--train-lz", str(a.train_lz)]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-            ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
-            if r.returncode != 0 or not ln:
-                one[mode] = {"error": (r.stderr or r.stdout)[-300:]}
+            # its own process group, killed as a whole on a time-out: a hung rank must not outlive the launcher that started it
+            pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                                  env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+            try:
+                out_, err_ = pr.communicate(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.communicate()
+                one[mode] = {"error": "timed out after 150 s (process group killed)"}
+                continue
+            ln = [x for x in out_.splitlines() if x.startswith("{")]
+            if pr.returncode != 0 or not ln:
+                one[mode] = {"error": (err_ or out_)[-300:]}
                 continue
             d = json.loads(ln[-1])
             one[mode] = {k: d.get(k) for k in ("ms_per_step", "allreduce_wait_ms", "param_allgather_wait_ms", "host_enqueue_ms_per_step")}
